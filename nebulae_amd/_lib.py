@@ -1,0 +1,87 @@
+"""ctypes binding of libnebulae_hip.so (include/nebulae_hip.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc, and if
+that fails, or a GPU call is made with no device, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+NEB_OK = 0
+PLANE_RADIANCE, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOMENTS, PLANE_VARIANCE, PLANE_SCRATCH = 0, 1, 2, 3, 4, 5
+PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS = 6, 7, 8
+SLOT_CURRENT, SLOT_HISTORY = -1, -2
+
+
+class NebError(RuntimeError):
+    pass
+
+
+class CreateInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32),
+                ("row_end", C.c_uint32), ("atrous_levels", C.c_uint32)]
+
+
+class SvgfParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("depthSigma", "alpha", "varianceEps", "phiColor", "phiNormal", "phiDepth")]
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "neb_create": (C.c_int, [C.POINTER(CreateInfo), C.POINTER(C.c_void_p)]),
+    "neb_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "neb_destroy": (C.c_int, [C.c_void_p]),
+    "neb_last_error": (C.c_char_p, [C.c_void_p]),
+    "neb_version": (C.c_char_p, []),
+    "neb_begin_frame": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "neb_end_frame": (C.c_int, [C.c_void_p]),
+    "neb_current_index": (C.c_int, [C.c_void_p]),
+    "neb_history_index": (C.c_int, [C.c_void_p]),
+    "neb_svgf_default_params": (C.c_int, [C.POINTER(SvgfParams)]),
+    "neb_svgf_set_params": (C.c_int, [C.c_void_p, C.POINTER(SvgfParams)]),
+    "neb_svgf_get_params": (C.c_int, [C.c_void_p, C.POINTER(SvgfParams)]),
+    "neb_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "neb_get_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_uint32)]),
+    "neb_upload_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "neb_download_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "neb_stream_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neb_svgf_reset_history": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neb_svgf_temporal": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neb_svgf_atrous": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neb_svgf_temporal_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "neb_svgf_atrous_level_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "neb_svgf_atrous_level_planes": (C.c_int, [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_int)] * 4),
+}
+
+_LIB = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load(build_if_missing=True):
+    """Load (building first if needed) libnebulae_hip.so.  Raises if it cannot be had."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if build_if_missing and _build.needs_build():
+        _build.build()
+    if not os.path.exists(path):
+        raise NebError(f"{path} is missing and could not be built; nebulae_amd has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(lib, ctx, rc, what):
+    if rc != NEB_OK:
+        msg = lib.neb_last_error(ctx)
+        raise NebError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

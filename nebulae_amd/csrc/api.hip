@@ -1,0 +1,414 @@
+// api.hip -- the C ABI of libnebulae_hip.so (include/nebulae_hip.h): context, planes, SVGF frame logic.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "neb_internal.h"
+
+namespace neb {
+const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT] = {
+    {16, 2}, // RADIANCE     R32G32B32A32_FLOAT
+    {8, 2},  // NORMAL       R16G16B16A16_FLOAT
+    {4, 2},  // DEPTH        R24G8
+    {4, 2},  // MOMENTS      R16G16_FLOAT
+    {2, 1},  // VARIANCE     R16_FLOAT
+    {16, 1}, // SCRATCH      R32G32B32A32_FLOAT
+    {4, 1},  // ALBEDO       R11G11B10_FLOAT
+    {4, 1},  // ROUGH_METAL  R16G16_FLOAT
+    {8, 1},  // WORLDPOS     R16G16B16A16_FLOAT
+};
+} // namespace neb
+
+using namespace neb;
+
+static thread_local std::string g_create_error;
+
+static int fail(neb_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof(buf), "%s", what);
+    if (ctx)
+        ctx->last_error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define NEB_HIP(ctx, call)                                  \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess)                               \
+            return fail((ctx), NEB_ERR_HIP, #call, e_);     \
+    } while (0)
+
+static void free_planes(neb_ctx* ctx)
+{
+    for (int p = 0; p < NEB_PLANE_COUNT; ++p)
+        for (int s = 0; s < 2; ++s)
+            if (ctx->planes[p][s]) {
+                (void)hipFree(ctx->planes[p][s]);
+                ctx->planes[p][s] = nullptr;
+            }
+}
+
+static int alloc_planes(neb_ctx* ctx)
+{
+    // InitSVGFResources (SVGFDenoiser.cpp:283-359).  The reference never clears radiance/moments
+    // (SURVEY.md quirk 8); this build defines zero-initialised planes.
+    const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
+    for (int p = 0; p < NEB_PLANE_COUNT; ++p)
+        for (uint32_t s = 0; s < kPlaneInfo[p].slots; ++s) {
+            const size_t bytes = npx * kPlaneInfo[p].bytes_per_px;
+            NEB_HIP(ctx, hipMalloc(&ctx->planes[p][s], bytes));
+            NEB_HIP(ctx, hipMemset(ctx->planes[p][s], 0, bytes));
+        }
+    NEB_HIP(ctx, hipDeviceSynchronize());
+    return NEB_OK;
+}
+
+extern "C" {
+
+const char* neb_version(void) { return "nebulae_hip 0.1 (gfx950)"; }
+
+const char* neb_last_error(const neb_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int neb_create(const neb_create_info* info, neb_ctx** out_ctx)
+{
+    if (!info || !out_ctx)
+        return fail(nullptr, NEB_ERR_INVALID_ARG, "neb_create: null argument");
+    *out_ctx = nullptr;
+    if (info->width == 0 || info->height == 0)
+        return fail(nullptr, NEB_ERR_INVALID_ARG, "neb_create: zero-sized image");
+    const uint32_t row_end = info->row_end ? info->row_end : info->height;
+    if (info->row_begin >= row_end || row_end > info->height)
+        return fail(nullptr, NEB_ERR_INVALID_ARG, "neb_create: bad resident row range");
+    if (info->atrous_levels > 16)
+        return fail(nullptr, NEB_ERR_INVALID_ARG, "neb_create: atrous_levels > 16");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, NEB_ERR_NO_DEVICE, "neb_create: no HIP device (this library has no CPU fallback)", e);
+    if (info->device < 0 || info->device >= ndev)
+        return fail(nullptr, NEB_ERR_INVALID_ARG, "neb_create: device ordinal out of range");
+    e = hipSetDevice(info->device);
+    if (e != hipSuccess)
+        return fail(nullptr, NEB_ERR_HIP, "hipSetDevice", e);
+    neb_ctx* ctx = new (std::nothrow) neb_ctx();
+    if (!ctx)
+        return fail(nullptr, NEB_ERR_HIP, "neb_create: out of host memory");
+    ctx->device = info->device;
+    ctx->W = info->width;
+    ctx->H = info->height;
+    ctx->row_begin = info->row_begin;
+    ctx->row_end = row_end;
+    ctx->levels = info->atrous_levels;
+    neb_svgf_default_params(&ctx->params);
+    int rc = alloc_planes(ctx);
+    if (rc != NEB_OK) {
+        g_create_error = ctx->last_error;
+        free_planes(ctx);
+        delete ctx;
+        return rc;
+    }
+    *out_ctx = ctx;
+    return NEB_OK;
+}
+
+int neb_resize(neb_ctx* ctx, uint32_t width, uint32_t height)
+{
+    if (!ctx || width == 0 || height == 0)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_resize: bad argument");
+    if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
+        return fail(ctx, NEB_ERR_STATE, "neb_resize: only a full-image context can be resized");
+    NEB_HIP(ctx, hipSetDevice(ctx->device));
+    NEB_HIP(ctx, hipDeviceSynchronize());
+    free_planes(ctx);
+    ctx->W = width;
+    ctx->H = height;
+    ctx->row_begin = 0;
+    ctx->row_end = height;
+    return alloc_planes(ctx);
+}
+
+int neb_destroy(neb_ctx* ctx)
+{
+    if (!ctx)
+        return NEB_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_planes(ctx);
+    delete ctx;
+    return NEB_OK;
+}
+
+int neb_begin_frame(neb_ctx* ctx, uint32_t frame_index)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    ctx->cur = (int)(frame_index & 1u); // SVGFDenoiser.cpp:41-42
+    ctx->hist = ctx->cur ^ 1;
+    return NEB_OK;
+}
+
+int neb_end_frame(neb_ctx* ctx) { return ctx ? NEB_OK : NEB_ERR_INVALID_ARG; } // SVGFDenoiser.cpp:45-47
+
+int neb_current_index(const neb_ctx* ctx) { return ctx ? ctx->cur : NEB_ERR_INVALID_ARG; }
+int neb_history_index(const neb_ctx* ctx) { return ctx ? ctx->hist : NEB_ERR_INVALID_ARG; }
+
+int neb_svgf_default_params(neb_svgf_params* out)
+{
+    if (!out)
+        return NEB_ERR_INVALID_ARG;
+    out->depthSigma = 0.002f; // SVGFDenoiser.h:79-81
+    out->alpha = 0.9f;
+    out->varianceEps = 1e-4f;
+    out->phiColor = 4.0f / 255.0f; // SVGFDenoiser.h:89-91
+    out->phiNormal = 128.0f;
+    out->phiDepth = 0.002f;
+    return NEB_OK;
+}
+
+int neb_svgf_set_params(neb_ctx* ctx, const neb_svgf_params* p)
+{
+    if (!ctx || !p)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_set_params: null argument");
+    if (!(p->depthSigma > 0.f) || !(p->phiDepth > 0.f) || !(p->phiNormal > 0.f))
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_set_params: depthSigma, phiDepth, phiNormal must be > 0");
+    ctx->params = *p;
+    return NEB_OK;
+}
+
+int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out)
+{
+    if (!ctx || !out)
+        return NEB_ERR_INVALID_ARG;
+    *out = ctx->params;
+    return NEB_OK;
+}
+
+int neb_set_option(neb_ctx* ctx, const char* key, int value)
+{
+    if (!ctx || !key)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: null argument");
+    if (!strcmp(key, "atrous_variant")) {
+        if (value < 0 || value > 1)
+            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: atrous_variant must be 0 or 1");
+        ctx->atrous_variant = value;
+        return NEB_OK;
+    }
+    return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: unknown key");
+}
+
+static int resolve_slot(const neb_ctx* ctx, int plane, int slot)
+{
+    if (plane < 0 || plane >= NEB_PLANE_COUNT)
+        return -1;
+    if (kPlaneInfo[plane].slots == 1)
+        return (slot == 0 || slot == NEB_SLOT_CURRENT) ? 0 : -1;
+    if (slot == NEB_SLOT_CURRENT)
+        return ctx->cur;
+    if (slot == NEB_SLOT_HISTORY)
+        return ctx->hist;
+    return (slot == 0 || slot == 1) ? slot : -1;
+}
+
+int neb_get_plane(neb_ctx* ctx, int plane, int slot, void** dptr, size_t* pitch_bytes, uint32_t* rows)
+{
+    if (!ctx || !dptr)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_get_plane: null argument");
+    const int s = resolve_slot(ctx, plane, slot);
+    if (s < 0)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_get_plane: bad plane/slot");
+    *dptr = ctx->planes[plane][s];
+    if (pitch_bytes)
+        *pitch_bytes = (size_t)ctx->W * kPlaneInfo[plane].bytes_per_px;
+    if (rows)
+        *rows = ctx->row_end - ctx->row_begin;
+    return NEB_OK;
+}
+
+static int copy_rows(neb_ctx* ctx, int plane, int slot, uint32_t row0, uint32_t nrows, void* host, bool upload,
+                     neb_stream stream)
+{
+    if (!ctx || !host)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "copy rows: null argument");
+    const int s = resolve_slot(ctx, plane, slot);
+    if (s < 0)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "copy rows: bad plane/slot");
+    if (row0 < ctx->row_begin || row0 + nrows > ctx->row_end)
+        return fail(ctx, NEB_ERR_OUT_OF_RANGE, "copy rows: rows not resident in this context");
+    const size_t pitch = (size_t)ctx->W * kPlaneInfo[plane].bytes_per_px;
+    char* d = (char*)ctx->planes[plane][s] + (size_t)(row0 - ctx->row_begin) * pitch;
+    NEB_HIP(ctx, hipSetDevice(ctx->device));
+    if (upload)
+        NEB_HIP(ctx, hipMemcpyAsync(d, host, pitch * nrows, hipMemcpyHostToDevice, (hipStream_t)stream));
+    else
+        NEB_HIP(ctx, hipMemcpyAsync(host, d, pitch * nrows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return NEB_OK;
+}
+
+int neb_upload_rows(neb_ctx* ctx, int plane, int slot, uint32_t row0, uint32_t nrows, const void* host, neb_stream stream)
+{
+    return copy_rows(ctx, plane, slot, row0, nrows, const_cast<void*>(host), true, stream);
+}
+
+int neb_download_rows(neb_ctx* ctx, int plane, int slot, uint32_t row0, uint32_t nrows, void* host, neb_stream stream)
+{
+    return copy_rows(ctx, plane, slot, row0, nrows, host, false, stream);
+}
+
+int neb_stream_synchronize(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    NEB_HIP(ctx, hipSetDevice(ctx->device));
+    NEB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return NEB_OK;
+}
+
+// ---- SVGF ----
+
+int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    // CopyResource(history <- current); moments/variance are NOT reset (SVGFDenoiser.cpp:57).
+    const size_t bytes = (size_t)ctx->W * (ctx->row_end - ctx->row_begin) * 16;
+    NEB_HIP(ctx, hipMemcpyAsync(ctx->planes[NEB_PLANE_RADIANCE][ctx->hist], ctx->planes[NEB_PLANE_RADIANCE][ctx->cur],
+                                bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return NEB_OK;
+}
+
+static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
+{
+    SvgfLaunch L;
+    L.W = ctx->W;
+    L.H = ctx->H;
+    L.row_begin = ctx->row_begin;
+    L.row0 = row0;
+    L.row1 = row1;
+    L.p = ctx->params;
+    return L;
+}
+
+int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
+        return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_temporal_rows: rows not resident");
+    const int c = ctx->cur, h = ctx->hist;
+    hipError_t e = launch_temporal(make_launch(ctx, row0, row1), (float4*)ctx->planes[NEB_PLANE_RADIANCE][c],
+                                   (const float4*)ctx->planes[NEB_PLANE_RADIANCE][h],
+                                   (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][c],
+                                   (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][h],
+                                   (const uint2*)ctx->planes[NEB_PLANE_NORMAL][c],
+                                   (const uint2*)ctx->planes[NEB_PLANE_NORMAL][h],
+                                   (const uint32_t*)ctx->planes[NEB_PLANE_MOMENTS][h],
+                                   (uint32_t*)ctx->planes[NEB_PLANE_MOMENTS][c],
+                                   (uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0], (hipStream_t)stream);
+    if (e != hipSuccess)
+        return fail(ctx, NEB_ERR_HIP, "svgf_temporal launch", e);
+    return NEB_OK;
+}
+
+int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    return neb_svgf_temporal_rows(ctx, ctx->row_begin, ctx->row_end, stream);
+}
+
+// Ping-pong chain of SubmitATrousComputeWavelet (SVGFDenoiser.cpp:146-196): src = cur, dst = hist,
+// swapped every level.  The reference asserts an even level count (:197); for odd counts the
+// chain runs cur -> hist -> scratch -> hist -> ... -> scratch -> cur through the third radiance
+// plane (the reference's unused m_denoisedOutput) so the final image still lands in
+// radiance[cur] and becomes next frame's history.  L == 1 filters into
+// scratch and copies back.
+static void chain_link(const neb_ctx* ctx, uint32_t level, int* sp, int* ss, int* dp, int* ds)
+{
+    const uint32_t L = ctx->levels;
+    auto node = [&](uint32_t i, int* plane, int* slot) { // buffer holding the input of level i (i == L: result)
+        *plane = NEB_PLANE_RADIANCE;
+        if (i == 0 || (i == L && L != 1)) {
+            *slot = ctx->cur;
+        } else if (L == 1) {
+            *plane = NEB_PLANE_SCRATCH;
+            *slot = 0;
+        } else if ((L & 1u) == 0) {
+            *slot = (i & 1u) ? ctx->hist : ctx->cur;
+        } else if (i & 1u) {
+            *slot = ctx->hist;
+        } else {
+            *plane = NEB_PLANE_SCRATCH;
+            *slot = 0;
+        }
+    };
+    node(level, sp, ss);
+    node(level + 1, dp, ds);
+}
+
+int neb_svgf_atrous_level_planes(const neb_ctx* ctx, uint32_t level, int* src_plane, int* src_slot, int* dst_plane,
+                                 int* dst_slot)
+{
+    if (!ctx || !src_plane || !src_slot || !dst_plane || !dst_slot || level >= ctx->levels)
+        return NEB_ERR_INVALID_ARG;
+    chain_link(ctx, level, src_plane, src_slot, dst_plane, dst_slot);
+    return NEB_OK;
+}
+
+int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint32_t row1, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    if (level >= ctx->levels)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_atrous_level_rows: level >= atrous_levels");
+    if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
+        return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_atrous_level_rows: rows not resident");
+    const uint32_t step = 1u << level;
+    // every (globally clamped) tap row must be resident: rows [row0 - 2*step, row1 - 1 + 2*step] clamped to the image
+    const uint32_t Hd = (ctx->H / 8u) * 8u;
+    const uint32_t r1 = row1 < Hd ? row1 : Hd;
+    if (row0 < r1) {
+        const uint32_t lo = row0 >= 2 * step ? row0 - 2 * step : 0;
+        uint32_t hi = r1 - 1 + 2 * step;
+        if (hi > ctx->H - 1)
+            hi = ctx->H - 1;
+        if (lo < ctx->row_begin || hi >= ctx->row_end)
+            return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_atrous_level_rows: tap rows (halo) not resident");
+    }
+    int sp, ss, dp, ds;
+    chain_link(ctx, level, &sp, &ss, &dp, &ds);
+    hipError_t e = launch_atrous(make_launch(ctx, row0, row1), ctx->atrous_variant, step,
+                                 (const float4*)ctx->planes[sp][ss], (float4*)ctx->planes[dp][ds],
+                                 (const uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0],
+                                 (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][ctx->cur],
+                                 (const uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur], (hipStream_t)stream);
+    if (e != hipSuccess)
+        return fail(ctx, NEB_ERR_HIP, "svgf_atrous launch", e);
+    return NEB_OK;
+}
+
+int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
+        return fail(ctx, NEB_ERR_STATE, "neb_svgf_atrous: context holds a row strip; use neb_svgf_atrous_level_rows");
+    for (uint32_t i = 0; i < ctx->levels; ++i) {
+        int rc = neb_svgf_atrous_level_rows(ctx, i, 0, ctx->H, stream);
+        if (rc != NEB_OK)
+            return rc;
+    }
+    if (ctx->levels == 1) {
+        const size_t bytes = (size_t)ctx->W * ctx->H * 16;
+        NEB_HIP(ctx, hipMemcpyAsync(ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], ctx->planes[NEB_PLANE_SCRATCH][0], bytes,
+                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return NEB_OK;
+}
+
+} // extern "C"

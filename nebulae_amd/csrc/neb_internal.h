@@ -1,0 +1,42 @@
+// neb_internal.h -- context layout and kernel launchers behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/nebulae_hip.h"
+
+namespace neb {
+
+struct PlaneInfo {
+    uint32_t bytes_per_px;
+    uint32_t slots;
+};
+extern const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT];
+
+struct SvgfLaunch {
+    uint32_t W, H;         // full image size (global clamp uses these)
+    uint32_t row_begin;    // first resident image row: plane address of (x, y) is (y - row_begin) * W + x
+    uint32_t row0, row1;   // image rows to process
+    neb_svgf_params p;
+};
+
+// Kernel launchers (enqueue only).  All pointers are device pointers to resident row `row_begin`.
+hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* rad_hist, const uint32_t* depth_cur,
+                           const uint32_t* depth_hist, const uint2* normal_cur, const uint2* normal_hist,
+                           const uint32_t* mom_hist, uint32_t* mom_cur, uint16_t* variance, hipStream_t s);
+
+hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
+                         const uint16_t* variance, const uint32_t* depth, const uint2* normal, hipStream_t s);
+
+} // namespace neb
+
+struct neb_ctx {
+    int device = 0;
+    uint32_t W = 0, H = 0, row_begin = 0, row_end = 0, levels = 4;
+    void* planes[NEB_PLANE_COUNT][2] = {};
+    int cur = 0, hist = 1;
+    neb_svgf_params params{};
+    int atrous_variant = 1; // 0 = direct-load kernel, 1 = LDS row-lattice kernel
+    std::string last_error;
+};

@@ -1,0 +1,61 @@
+"""CPU tests of the C-ABI boundary: the library builds, loads, and exports every declared symbol."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from nebulae_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            text = open(os.path.join(inc, fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names |= set(re.findall(r"\b(neb_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    build.build()
+    lib = C.CDLL(build.LIB_PATH)
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    # the ctypes binding covers the same set
+    assert set(_lib.exported_symbols()) == set(decl)
+
+
+def test_binding_loads_and_reports_version():
+    lib = _lib.load()
+    assert b"gfx950" in lib.neb_version()
+    p = _lib.SvgfParams()
+    assert lib.neb_svgf_default_params(C.byref(p)) == 0
+    assert abs(p.phiColor - 4.0 / 255.0) < 1e-9 and p.phiNormal == 128.0 and abs(p.alpha - 0.9) < 1e-7
+
+
+def test_create_rejects_bad_arguments_without_touching_a_gpu():
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.neb_create(None, C.byref(ctx)) == -1
+    info = _lib.CreateInfo(0, 0, 16, 0, 0, 4)
+    assert lib.neb_create(C.byref(info), C.byref(ctx)) == -1
+    info = _lib.CreateInfo(0, 16, 16, 8, 4, 4)
+    assert lib.neb_create(C.byref(info), C.byref(ctx)) == -1
+    assert b"row range" in lib.neb_last_error(None)
+
+
+def test_no_cpu_fallback_when_no_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nebulae_amd.svgf import SVGFDenoiser, NebError
+    d = SVGFDenoiser()
+    with pytest.raises(NebError):
+        d.init(64, 64)
