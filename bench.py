@@ -42,7 +42,8 @@ def cpu_baseline(W, H, L, frames, g, rads):
     """Times oracle/svgf_ref.c (kind "port") on all host cores over `frames` full frames."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import OracleSVGF
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)  # the 1-GPU box shares its host: 16 cores is this job's CPU share
     o = OracleSVGF(W, H, L, threads=cores)
     # one untimed frame so history is populated (frame 1 is all-history, quirk 2)
     times = []

@@ -18,11 +18,13 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def half_ulp_mismatch(a, b, max_ulp=1):
-    """fraction of fp16 values that differ by more than max_ulp units in the last place"""
-    ai = a.view(np.uint16).astype(np.int32)
-    bi = b.view(np.uint16).astype(np.int32)
-    return float((np.abs(ai - bi) > max_ulp).mean())
+def half_ulp_mismatch(a, b, max_ulp=1, abs_tol=1e-6):
+    """fraction of fp16 values that differ by more than max_ulp fp16 ulps of the expected value
+    (values whose difference is below abs_tol -- fp16-denormal rounding noise -- always agree)"""
+    af = a.astype(np.float64)
+    bf = b.astype(np.float64)
+    ulp = np.maximum(np.abs(bf) * 2.0 ** -10, 2.0 ** -24)
+    return float((np.abs(af - bf) > np.maximum(max_ulp * ulp, abs_tol)).mean())
 
 
 def load_golden(path):
