@@ -96,7 +96,8 @@ int neb_svgf_default_params(neb_svgf_params* out);
 int neb_svgf_set_params(neb_ctx* ctx, const neb_svgf_params* p);
 int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
 /* Implementation knobs with no reference counterpart (A/B arms for profiling):
- *   "atrous_variant": 1 = LDS row-lattice kernel (default), 0 = direct-load kernel. */
+ *   "atrous_variant": 1 = LDS row-lattice kernel (default), 0 = direct-load kernel;
+ *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene). */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
 /* ---- resource sharing: the ~25 getters of SVGFDenoiser.h:24-70 collapse into one call.
@@ -125,6 +126,87 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
 int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint32_t row1, neb_stream stream);
 /* Which plane/slot level `level` reads and writes (for halo exchange between levels). */
 int neb_svgf_atrous_level_planes(const neb_ctx* ctx, uint32_t level, int* src_plane, int* src_slot, int* dst_plane, int* dst_slot);
+
+/* ======================= GI: one-bounce indirect diffuse =========================================
+ * Replaces DeferredRenderer::SubmitCommandsGIPathtrace (src/DeferredRenderer.cpp:396-591) driving
+ * assets/shaders/pathtracer.hlsl with the NRC calls stubbed (rtxgi/Nrc.hlsli:579-621), and the DXR
+ * driver BVH (src/nri/raytracing/RTAccelerationStructureBuilder.cpp:14-130) with an on-device LBVH. */
+
+/* One submesh: StaticMeshGeometryData (src/nri/GIProcessedScene.h:17-31; shader mirror
+ * pathtracer.hlsl:73-87).  The bindless (bufferIndex, offset) pairs become host pointers to the
+ * first element; strides are in bytes.  Attribute order (src/nri/StaticMesh.h:14-21): position float3,
+ * normal float3, texcoord float2, tangent float4.  neb_gi_set_scene copies everything. */
+typedef struct neb_geometry_desc {
+    float surfaceToWorld[16]; /* row-major, row-vector convention: world = (p,1) * M (SimpleMath Mat4) */
+    int32_t materialIndex;    /* PathtracerInvalidBindlessIndex (-1) = none */
+    uint32_t indexStride;     /* 2 or 4 */
+    uint32_t numIndices;
+    uint32_t numVertices;
+    const void* indices;
+    const void* attributes[4]; /* NULL = missing: hits on this submesh terminate the path (pathtracer.hlsl:313-318) */
+    uint32_t attributeStrides[4];
+    uint32_t _pad;
+} neb_geometry_desc;
+
+/* StaticMeshMaterialData (src/nri/GIProcessedScene.h:33-39; pathtracer.hlsl:99-105) */
+typedef struct neb_material_desc {
+    int32_t textureIndices[3]; /* albedo, normal, roughnessMetalness; -1 = use the factors */
+    float albedo[4];
+    float roughnessMetalness[2];
+    uint32_t _pad;
+} neb_material_desc;
+
+/* R8G8B8A8_UNORM, one mip, no sRGB decode (src/core/GLTFSceneImporter.cpp:156); sampled linear/wrap at mip 0. */
+typedef struct neb_texture_desc {
+    const void* rgba8;
+    uint32_t width, height;
+} neb_texture_desc;
+
+/* GlobalConstants (src/DeferredRenderer.h:219-238, pathtracer.hlsl:11-30) minus the NRC-only members. */
+typedef struct neb_gi_constants {
+    uint32_t frameIndex;
+    uint32_t samplesPerPixel;
+    uint32_t maxPathVertices; /* nrcMaxPathVertices; 2 = one bounce (the supported value) */
+    float cameraWorldPos[3];
+    float skyColor[3];
+    float sunLightDirection[3];
+    float sunLightRadiance[3];
+    float sunTanHalfAngle;    /* tan(radians(diameter / 2)), DeferredRenderer.cpp:418 */
+    float throughputThreshold;
+} neb_gi_constants;
+
+/* Per-pixel record of the last sample's bounce ray (the reference's debug UAVs, pathtracer.hlsl:41-42). */
+typedef struct neb_gi_hit {
+    float t;            /* < 0: miss */
+    uint32_t geometry;  /* GeometryIndex() */
+    uint32_t primitive; /* PrimitiveIndex() */
+    uint32_t flags;     /* bit 0: sun shadow ray unoccluded */
+} neb_gi_hit;
+
+typedef struct neb_camera {
+    float eye[3], target[3], up[3]; /* Mat4::CreateLookAt (RH), src/core/InspectCamera.h:44-48 */
+    float vfov_deg, znear, zfar;    /* CreatePerspectiveFieldOfView(60 deg, aspect, 0.1, 100), DeferredRenderer.cpp:147-148 */
+} neb_camera;
+
+/* DeferredRenderer::InitPathtracerScene -> GIProcessedScene::InitScene (src/nri/GIProcessedScene.cpp:16-137):
+ * uploads geometry/material tables and textures and bakes world-space triangles. */
+int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_geoms, const neb_material_desc* mats,
+                     uint32_t n_mats, const neb_texture_desc* texs, uint32_t n_texs);
+/* DeferredRenderer::InitRTAccelerationStructures (src/DeferredRenderer.cpp:978-1030): builds the LBVH on the device. */
+int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream);
+int neb_gi_scene_info(const neb_ctx* ctx, uint32_t* n_triangles, uint32_t* n_nodes);
+/* DeferredRenderer::SubmitCommandsGIPathtrace: radiance[cur].rgb += mean over spp of the path radiance
+ * (stands in for NRC Resolve, DeferredRenderer.cpp:586).  Reads the ALBEDO / ROUGH_METAL / WORLDPOS planes and
+ * normal[cur].  _rows: image rows [row0,row1) only (multi-GPU strips). */
+int neb_gi_trace(neb_ctx* ctx, const neb_gi_constants* constants, neb_stream stream);
+int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* constants, uint32_t row0, uint32_t row1, neb_stream stream);
+/* Rays traced (bounce + shadow) by all GI dispatches since the last reset.  Synchronises `stream`. */
+int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream);
+/* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
+int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);
+/* "next" row f2: primary-visibility G-buffer producer with the encodings of
+ * assets/shaders/deferred_gbuffers.hlsl:71-103 (writes ALBEDO, ROUGH_METAL, WORLDPOS, normal[cur], depth[cur]). */
+int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* camera, neb_stream stream);
 
 #ifdef __cplusplus
 }

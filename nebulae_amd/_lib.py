@@ -55,11 +55,28 @@ _SIGS = {
     "neb_svgf_atrous_level_planes": (C.c_int, [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_int)] * 4),
 }
 
+
+
+def _gi_sigs():
+    from . import scene as S
+    return {
+        "neb_gi_set_scene": (C.c_int, [C.c_void_p, C.POINTER(S.GeometryDesc), C.c_uint32, C.POINTER(S.MaterialDesc), C.c_uint32,
+                                       C.POINTER(S.TextureDesc), C.c_uint32]),
+        "neb_gi_build_bvh": (C.c_int, [C.c_void_p, C.c_void_p]),
+        "neb_gi_scene_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "neb_gi_trace": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_void_p]),
+        "neb_gi_trace_rows": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_uint32, C.c_uint32, C.c_void_p]),
+        "neb_gi_ray_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
+        "neb_gi_download_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+        "neb_gbuffer_raycast": (C.c_int, [C.c_void_p, C.POINTER(S.CameraDesc), C.c_void_p]),
+    }
+
+
 _LIB = None
 
 
 def exported_symbols():
-    return sorted(_SIGS)
+    return sorted(set(_SIGS) | set(_gi_sigs()))
 
 
 def load(build_if_missing=True):
@@ -73,7 +90,7 @@ def load(build_if_missing=True):
     if not os.path.exists(path):
         raise NebError(f"{path} is missing and could not be built; nebulae_amd has no CPU fallback")
     lib = C.CDLL(path)
-    for name, (res, args) in _SIGS.items():
+    for name, (res, args) in {**_SIGS, **_gi_sigs()}.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

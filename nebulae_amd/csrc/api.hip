@@ -140,6 +140,7 @@ int neb_destroy(neb_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     free_planes(ctx);
+    gi_destroy(ctx->gi);
     delete ctx;
     return NEB_OK;
 }
@@ -197,6 +198,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
         if (value < 0 || value > 1)
             return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: atrous_variant must be 0 or 1");
         ctx->atrous_variant = value;
+        return NEB_OK;
+    }
+    if (!strcmp(key, "gi_debug_hits")) {
+        if (gi_set_debug_hits(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_debug_hits needs a scene (neb_gi_set_scene)");
         return NEB_OK;
     }
     return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: unknown key");

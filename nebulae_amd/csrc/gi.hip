@@ -1,0 +1,1219 @@
+// gi.hip -- one-bounce indirect-diffuse GI on gfx950: scene tables, on-device LBVH, traversal + shading.
+//
+// Reference behaviour (paths relative to the reference checkout):
+//   assets/shaders/pathtracer.hlsl:397-625 (PathtracerRG, query variant, NRC stubbed per
+//   rtxgi/Nrc.hlsli:579-621, nrcMaxPathVertices = 2), :299-395 ReconstructSurfaceData, :209-228
+//   EvaluateDirectBRDF; brdf.hlsli; rand.hlsli; sun_disk_sampling.hlsli:45-52;
+//   src/nri/GIProcessedScene.cpp:16-137 (scene tables); RTAccelerationStructureBuilder.cpp:14-130
+//   (driver BVH -> replaced by a Karras LBVH built here); deferred_gbuffers.hlsl:36-104 (G-buffer encodings).
+// Not a DXR transliteration: there is no ray-gen/miss/closest-hit pipeline and no driver BVH.  A wave
+// owns an 8x8 pixel tile; each lane generates its ray from the G-buffer, walks the LBVH with a per-lane
+// stack kept in LDS (lane-contiguous, conflict-free), shades its hit from SoA attribute pools and
+// fires the sun shadow ray through the same traverser in any-hit mode.
+//
+// Floating-point contraction is OFF in this file so that ray setup and the Moeller-Trumbore test
+// round exactly like the scalar CPU oracle (hit/miss decisions at triangle edges then agree).
+#pragma clang fp contract(off)
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "neb_device.h"
+#include "neb_internal.h"
+
+namespace neb {
+
+// ------------------------------------------------------------------------------------------------
+// Device-side scene
+// ------------------------------------------------------------------------------------------------
+struct DevGeom {
+    float m[9];          // upper 3x3 of surfaceToWorld (row-vector convention)
+    int32_t material;
+    uint32_t firstIndex; // into the uint32 index pool
+    uint32_t vertexBase; // into the SoA vertex pools
+    uint32_t valid;      // all four attribute streams + indices present
+    uint32_t pad[3];
+};
+struct DevMat {
+    int32_t tex[3];
+    float albedo[3];
+    float rough, metal;
+};
+struct DevTex {
+    uint32_t offset; // in texels, into the RGBA8 pool
+    uint32_t w, h, pad;
+};
+// 64-byte BVH2 node: both children's boxes live in the parent, so one node fetch decides both.
+struct BvhNode {
+    float c0min[3];
+    int32_t c0; // >= 0: inner node, < 0: leaf, triangle = ~c
+    float c0max[3];
+    int32_t c1;
+    float c1min[3];
+    uint32_t pad0;
+    float c1max[3];
+    uint32_t pad1;
+};
+
+struct SceneView {
+    const float4* tris;      // 3 x float4 per triangle: {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, geom, prim, -}
+    const BvhNode* nodes;
+    const DevGeom* geoms;
+    const DevMat* mats;
+    const DevTex* texs;
+    const uint32_t* indices;
+    const float* normals;    // 3 per vertex
+    const float* uvs;        // 2 per vertex
+    const float* tangents;   // 4 per vertex
+    const uint32_t* texels;  // RGBA8
+    uint32_t n_tris;
+    int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
+};
+
+struct GiState {
+    SceneView view{};
+    std::vector<void*> allocs;
+    // host copies kept for the build
+    std::vector<float> h_tris; // 12 floats per triangle
+    float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
+    uint32_t n_tris = 0, n_nodes = 0;
+    bool built = false;
+    unsigned long long* d_ray_counter = nullptr;
+    neb_gi_hit* d_hits = nullptr;
+    bool debug_hits = false;
+};
+
+void gi_destroy(GiState* g)
+{
+    if (!g)
+        return;
+    for (void* p : g->allocs)
+        (void)hipFree(p);
+    delete g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small vector helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 operator*(float3 a, float3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ float3 operator-(float3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b)
+{
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float3 normalize3(float3 a)
+{
+    const float l = sqrtf(dot3(a, a));
+    return f3(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ float saturate1(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float lerp1(float a, float b, float t) { return a + t * (b - a); }
+
+constexpr float kPi = 3.14159265f;      // brdf.hlsli:28
+constexpr float kPiInv = 1.0f / kPi;
+constexpr float kPiTwo = 2.0f * kPi;
+constexpr float kTraceMax = 10000.0f;   // TRACING_MAX_DISTANCE, pathtracer.hlsl:9
+
+// rand.hlsli:6-55
+__device__ __forceinline__ uint32_t jenkins(uint32_t x)
+{
+    x += x << 10;
+    x ^= x >> 6;
+    x += x << 3;
+    x ^= x >> 11;
+    x += x << 15;
+    return x;
+}
+__device__ __forceinline__ float rand01(uint32_t& s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return __uint_as_float(0x3f800000u | (s >> 9)) - 1.0f;
+}
+
+// octahedron_encoding.hlsli:16-34
+__device__ __forceinline__ float3 oct_unpack(float ex, float ey)
+{
+    float3 v = f3(ex, ey, 1.0f - fabsf(ex) - fabsf(ey));
+    if (v.z < 0.0f) {
+        const float sx = (v.x > 0.f) ? 1.f : -1.f, sy = (v.y > 0.f) ? 1.f : -1.f;
+        const float nx = (1.0f - fabsf(v.y)) * sx, ny = (1.0f - fabsf(v.x)) * sy;
+        v.x = nx;
+        v.y = ny;
+    }
+    return normalize3(v);
+}
+__device__ __forceinline__ float2 oct_pack(float3 v)
+{
+    const float s = 1.0f / (fabsf(v.x) + fabsf(v.y) + fabsf(v.z));
+    const float px = v.x * s, py = v.y * s;
+    if (v.z <= 0.0f) {
+        const float sx = (px > 0.f) ? 1.f : -1.f, sy = (py > 0.f) ? 1.f : -1.f;
+        return make_float2((1.0f - fabsf(py)) * sx, (1.0f - fabsf(px)) * sy);
+    }
+    return make_float2(px, py);
+}
+
+// R11G11B10_FLOAT: unsigned small floats, 5-bit exponent (bias 15), 6/6/5-bit mantissa.
+__device__ __forceinline__ float small_float_decode(uint32_t bits, int mbits)
+{
+    const uint32_t e = bits >> mbits, m = bits & ((1u << mbits) - 1u);
+    const float scale = (float)(1u << mbits);
+    if (e == 0)
+        return ldexpf((float)m / scale, -14);
+    if (e == 31)
+        return m ? __uint_as_float(0x7fc00000u) : __uint_as_float(0x7f800000u);
+    return ldexpf(1.0f + (float)m / scale, (int)e - 15);
+}
+__device__ __forceinline__ uint32_t small_float_encode(float f, int mbits)
+{
+    // negatives / NaN -> 0, round-to-nearest-even, overflow -> largest finite (DESIGN.md "G-buffer encodings")
+    if (!(f > 0.0f))
+        return 0;
+    const uint32_t max_bits = (30u << mbits) | ((1u << mbits) - 1u);
+    int e;
+    const float m = frexpf(f, &e);
+    e -= 1;
+    if (e > 15)
+        return max_bits;
+    if (e < -14)
+        return (uint32_t)rintf(ldexpf(f, 14 + mbits));
+    const float q = rintf(ldexpf(2.0f * m - 1.0f, mbits));
+    const uint32_t bits = ((uint32_t)(e + 15) << mbits) + (uint32_t)q;
+    return bits > max_bits ? max_bits : bits;
+}
+__device__ __forceinline__ float3 unpack_r11g11b10(uint32_t v)
+{
+    return f3(small_float_decode(v & 0x7ffu, 6), small_float_decode((v >> 11) & 0x7ffu, 6),
+              small_float_decode((v >> 22) & 0x3ffu, 5));
+}
+
+// brdf.hlsli
+__device__ __forceinline__ float luminance3(float3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+__device__ __forceinline__ float3 specular_f0(float3 albedo, float metal)
+{
+    return f3(lerp1(0.04f, albedo.x, metal), lerp1(0.04f, albedo.y, metal), lerp1(0.04f, albedo.z, metal));
+}
+__device__ __forceinline__ float3 fresnel_schlick(float3 f0, float vdoth) // brdf.hlsli:22-25, as written
+{
+    const float k = 1.0f - powf(vdoth, 5.0f);
+    return f3(f0.x + (1.0f - f0.x) * k, f0.y + (1.0f - f0.y) * k, f0.z + (1.0f - f0.z) * k);
+}
+__device__ __forceinline__ float specular_probability(float vdotn, float3 f0, float3 albedo) // brdf.hlsli:129-143
+{
+    const float dr = luminance3(albedo);
+    const float fres = saturate1(luminance3(fresnel_schlick(f0, saturate1(vdotn))));
+    const float diff = dr * (1.0f - fres);
+    const float p = diff / fmaxf(0.0001f, fres + diff);
+    return fminf(fmaxf(p, 0.1f), 0.9f);
+}
+__device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
+{
+    const float a = sqrtf(u0), b = kPiTwo * u1;
+    const float3 z = f3(a * cosf(b), a * sinf(b), sqrtf(1.0f - u0));
+    const float3 up = fabsf(sn.z) < 0.999f ? f3(0, 0, 1) : f3(1, 0, 0);
+    const float3 tx = normalize3(cross3(up, sn));
+    const float3 ty = cross3(sn, tx);
+    return normalize3(tx * z.x + ty * z.y + sn * z.z);
+}
+__device__ __forceinline__ float3 perpendicular(float3 u) // sun_disk_sampling.hlsli:45-52
+{
+    const float3 a = f3(fabsf(u.x), fabsf(u.y), fabsf(u.z));
+    const uint32_t xm = ((a.x - a.y) < 0 && (a.x - a.z) < 0) ? 1 : 0;
+    const uint32_t ym = (a.y - a.z) < 0 ? (1 ^ xm) : 0;
+    const uint32_t zm = 1 ^ (xm | ym);
+    return cross3(u, f3((float)xm, (float)ym, (float)zm));
+}
+
+struct Surface {
+    float3 GN, SN, albedo;
+    float roughness, metalness;
+};
+
+// EvaluateDirectBRDF (pathtracer.hlsl:209-228).  A zero Cook-Torrance denominator gives 0 instead of
+// the reference's 0 * inf = NaN (which NRC discards there) -- DESIGN.md "Deliberate divergences".
+__device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
+{
+    const float3 N = s.SN;
+    const float3 Hv = normalize3(V + L);
+    const float LdotN = dot3(L, N), VdotH = saturate1(dot3(V, Hv)), VdotN = dot3(V, N), NdotH = dot3(N, Hv);
+    const float3 F0 = specular_f0(s.albedo, s.metalness);
+    const float3 F = fresnel_schlick(F0, saturate1(VdotH));
+    const float3 Kd = f3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
+    const float3 diff = Kd * (s.albedo * kPiInv);
+    const float vn = saturate1(VdotN), ln = saturate1(LdotN), nh = saturate1(NdotH);
+    float3 spec = f3(0, 0, 0);
+    const float den = 4.0f * vn * ln;
+    if (den > 0.0f) {
+        const float alpha = s.roughness * s.roughness;
+        const float a2 = alpha * alpha;
+        const float dd = (nh * nh) * (a2 - 1.0f) + 1.0f;
+        const float ndf = a2 / (kPi * dd * dd);
+        const float k = alpha * 0.5f;
+        const float gv = vn * (1.0f / (vn * (1.0f - k) + k));
+        const float gl = ln * (1.0f / (ln * (1.0f - k) + k));
+        const float c = ndf * (gv * gl);
+        const float inv = 1.0f / den;
+        spec = f3(c * F.x * inv, c * F.y * inv, c * F.z * inv);
+    }
+    return diff + spec;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traversal
+// ------------------------------------------------------------------------------------------------
+constexpr int kStackDepth = 64;
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri;
+};
+
+__device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, uint32_t ti, float3 o, float3 d, float tmin,
+                                              float tmax, float& t, float& u, float& v)
+{
+    const float4 a = tris[3 * ti], b = tris[3 * ti + 1], c = tris[3 * ti + 2];
+    const float3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+    // Moeller-Trumbore, same operation order as oracle/trace_ref.cpp
+    const float3 p = cross3(d, e2);
+    const float det = dot3(e1, p);
+    if (det == 0.0f)
+        return false;
+    const float inv = 1.0f / det;
+    const float3 tv = o - v0;
+    u = dot3(tv, p) * inv;
+    if (u < 0.0f || u > 1.0f)
+        return false;
+    const float3 q = cross3(tv, e1);
+    v = dot3(d, q) * inv;
+    if (v < 0.0f || u + v > 1.0f)
+        return false;
+    t = dot3(e2, q) * inv;
+    return t > tmin && t < tmax;
+}
+
+__device__ __forceinline__ bool slab(const float* bmin, const float* bmax, float3 o, float3 inv, float tmin, float tmax,
+                                     float& tnear)
+{
+    const float ax = (bmin[0] - o.x) * inv.x, bx = (bmax[0] - o.x) * inv.x;
+    const float ay = (bmin[1] - o.y) * inv.y, by = (bmax[1] - o.y) * inv.y;
+    const float az = (bmin[2] - o.z) * inv.z, bz = (bmax[2] - o.z) * inv.z;
+    // fminf/fmaxf drop NaNs (0 * inf): the interval then stays conservative
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = t0;
+    return t0 <= t1;
+}
+
+// Closest-hit (any_hit = false) or first-hit (any_hit = true) traversal.  `stack` is this lane's column of
+// an LDS array [kStackDepth][64].
+__device__ bool traverse(const SceneView& S, float3 o, float3 d, float tmin, float tmax, bool any_hit, int* stack, Hit& hit)
+{
+    hit.t = tmax;
+    hit.tri = ~0u;
+    if (S.n_tris == 0)
+        return false;
+    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    bool found = false;
+    int sp = 0;
+    int node = S.root;
+    while (true) {
+        if (node >= 0) {
+            const BvhNode n = S.nodes[node];
+            float t0, t1;
+            const bool h0 = slab(n.c0min, n.c0max, o, inv, tmin, hit.t, t0);
+            const bool h1 = slab(n.c1min, n.c1max, o, inv, tmin, hit.t, t1);
+            if (h0 && h1) {
+                const bool near0 = t0 <= t1;
+                node = near0 ? n.c0 : n.c1;
+                if (sp < kStackDepth) { // a full stack drops the far child rather than run past the LDS column
+                    stack[64 * sp] = near0 ? n.c1 : n.c0;
+                    sp++;
+                }
+                continue;
+            }
+            if (h0) {
+                node = n.c0;
+                continue;
+            }
+            if (h1) {
+                node = n.c1;
+                continue;
+            }
+        } else {
+            const uint32_t ti = (uint32_t)~node;
+            float t, u, v;
+            if (intersect_tri(S.tris, ti, o, d, tmin, hit.t, t, u, v)) {
+                hit.t = t;
+                hit.u = u;
+                hit.v = v;
+                hit.tri = ti;
+                found = true;
+                if (any_hit)
+                    return true;
+            }
+        }
+        if (sp == 0)
+            break;
+        sp--;
+        node = stack[64 * sp];
+    }
+    return found;
+}
+
+// SampleLevel(linear, wrap, mip 0) of an RGBA8 UNORM texture (pathtracer.hlsl:359,377,390).
+__device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
+{
+    const DevTex t = S.texs[ti];
+    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    const int W = (int)t.w, H = (int)t.h;
+    int x0 = (int)fx0 % W, y0 = (int)fy0 % H;
+    if (x0 < 0)
+        x0 += W;
+    if (y0 < 0)
+        y0 += H;
+    const int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
+    const uint32_t* px = S.texels + t.offset;
+    const uint32_t p00 = px[y0 * W + x0], p10 = px[y0 * W + x1], p01 = px[y1 * W + x0], p11 = px[y1 * W + x1];
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a = (float)((p00 >> (8 * c)) & 0xffu) / 255.0f, b = (float)((p10 >> (8 * c)) & 0xffu) / 255.0f;
+        const float cc = (float)((p01 >> (8 * c)) & 0xffu) / 255.0f, dd = (float)((p11 >> (8 * c)) & 0xffu) / 255.0f;
+        const float top = a + fx * (b - a), bot = cc + fx * (dd - cc);
+        r[c] = top + fy * (bot - top);
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+__device__ __forceinline__ float3 load3(const float* p, uint32_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ float3 xform_dir(const float* m, float3 p) // (p,0) * M, row-vector convention
+{
+    return f3(p.x * m[0] + p.y * m[3] + p.z * m[6], p.x * m[1] + p.y * m[4] + p.z * m[7], p.x * m[2] + p.y * m[5] + p.z * m[8]);
+}
+
+// ReconstructSurfaceData (pathtracer.hlsl:299-395)
+__device__ bool reconstruct_surface(const SceneView& S, uint32_t prim, uint32_t geom, float bu, float bv, Surface& out)
+{
+    const DevGeom g = S.geoms[geom];
+    const float b0 = 1.0f - (bu + bv), b1 = bu, b2 = bv;
+    if (!g.valid)
+        return false; // :313-318
+    const uint32_t i0 = g.vertexBase + S.indices[g.firstIndex + 3 * prim], i1 = g.vertexBase + S.indices[g.firstIndex + 3 * prim + 1],
+                   i2 = g.vertexBase + S.indices[g.firstIndex + 3 * prim + 2];
+    const float3 n0 = load3(S.normals, i0), n1 = load3(S.normals, i1), n2 = load3(S.normals, i2);
+    const float3 gn = normalize3(f3(n0.x * b0 + n1.x * b1 + n2.x * b2, n0.y * b0 + n1.y * b1 + n2.y * b2, n0.z * b0 + n1.z * b1 + n2.z * b2));
+    out.GN = normalize3(xform_dir(g.m, gn)); // :340
+    const float u = S.uvs[2 * i0] * b0 + S.uvs[2 * i1] * b1 + S.uvs[2 * i2] * b2;
+    const float v = S.uvs[2 * i0 + 1] * b0 + S.uvs[2 * i1 + 1] * b1 + S.uvs[2 * i2 + 1] * b2;
+    if (g.material < 0)
+        return false; // :349
+    const DevMat m = S.mats[g.material];
+    if (m.tex[0] < 0) {
+        out.albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    } else {
+        const float4 t = sample_texture(S, m.tex[0], u, v);
+        out.albedo = f3(t.x, t.y, t.z);
+    }
+    if (m.tex[1] < 0) {
+        out.SN = out.GN;
+    } else {
+        float tg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            tg[k] = S.tangents[4 * i0 + k] * b0 + S.tangents[4 * i1 + k] * b1 + S.tangents[4 * i2 + k] * b2;
+        const float l4 = sqrtf(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2] + tg[3] * tg[3]); // normalize(float4), :371
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            tg[k] /= l4;
+        const float3 T = f3(tg[0], tg[1], tg[2]);
+        const float3 B = normalize3(cross3(out.GN, T) * tg[3]);
+        const float4 t = sample_texture(S, m.tex[1], u, v);
+        const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
+        out.SN = normalize3(T * N.x + B * N.y + out.GN * N.z); // mul(N, float3x3(T, B, GN))
+    }
+    if (m.tex[2] < 0) {
+        out.roughness = m.rough;
+        out.metalness = m.metal;
+    } else {
+        const float4 t = sample_texture(S, m.tex[2], u, v);
+        out.roughness = t.y; // .g
+        out.metalness = t.z; // .b
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GI kernel: one wave per 8x8 pixel tile
+// ------------------------------------------------------------------------------------------------
+struct GiArgs {
+    SceneView S;
+    neb_gi_constants c;
+    const uint32_t* albedo;
+    const uint32_t* rough_metal; // 2 x fp16
+    const uint2* world_pos;      // 4 x fp16
+    const uint2* normal;         // 4 x fp16 (.zw = shading normal)
+    float4* radiance;
+    neb_gi_hit* hits;            // may be null
+    unsigned long long* ray_counter;
+    uint32_t W, row_begin, row0, row1, tiles_x;
+};
+
+__global__ __launch_bounds__(64) void gi_trace_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kStackDepth * 64];
+    const uint32_t lane = threadIdx.x;
+    int* stack = stack_mem + lane;
+    const uint32_t tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const uint32_t x = tile_x * 8 + (lane & 7), y = a.row0 + tile_y * 8 + (lane >> 3);
+    const bool active = x < a.W && y < a.row1;
+    uint32_t rays = 0;
+    if (active) {
+        const size_t i = (size_t)(y - a.row_begin) * a.W + x;
+        uint32_t rng = jenkins((x + y * a.W) ^ jenkins(a.c.frameIndex)); // InitRNG, rand.hlsli:26-30
+        const float3 albedo = unpack_r11g11b10(a.albedo[i]);
+        const uint2 wp = a.world_pos[i];
+        const float3 worldPos = f3(half_bits_to_float(wp.x & 0xffffu), half_bits_to_float(wp.x >> 16), half_bits_to_float(wp.y & 0xffffu));
+        const uint32_t nzw = a.normal[i].y;
+        const float3 SN = oct_unpack(half_bits_to_float(nzw & 0xffffu), half_bits_to_float(nzw >> 16));
+        const float metalness = half_bits_to_float(a.rough_metal[i] >> 16);
+        const float3 cam = f3(a.c.cameraWorldPos[0], a.c.cameraWorldPos[1], a.c.cameraWorldPos[2]);
+        const float3 sky = f3(a.c.skyColor[0], a.c.skyColor[1], a.c.skyColor[2]);
+        const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
+        const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
+        float3 V = cam - worldPos; // :431 -- survives across samples, overwritten at :522 (reference behaviour)
+        float3 sum = f3(0, 0, 0);
+        neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
+        for (uint32_t s = 0; s < a.c.samplesPerPixel; ++s) {
+            (void)rand01(rng); // consumed by NrcCreatePathState (:438)
+            float3 throughput = f3(1, 1, 1);
+            float3 rad = f3(0, 0, 0);
+            const float3 F0 = specular_f0(albedo, metalness);
+            throughput = throughput * (albedo * (1.0f - metalness)); // :474
+            const float pd = 1.0f - specular_probability(saturate1(dot3(normalize3(V), SN)), F0, albedo);
+            if (rand01(rng) < pd)
+                throughput = f3(throughput.x / pd, throughput.y / pd, throughput.z / pd); // :476-479
+            const float u0 = rand01(rng), u1 = rand01(rng);
+            const float3 dir = cosine_hemisphere_aligned(u0, u1, SN);
+            const float3 org = worldPos + SN * 1e-2f; // :138
+            dbg = {-1.0f, ~0u, ~0u, 0u};
+            if (a.c.maxPathVertices > 1) {
+                Hit h;
+                rays++;
+                if (!traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack, h)) {
+                    rad = rad + sky * throughput; // :508
+                } else {
+                    const float4 ids = a.S.tris[3 * h.tri + 2];
+                    const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
+                    dbg.t = h.t;
+                    dbg.geometry = geom;
+                    dbg.primitive = prim;
+                    Surface surf;
+                    if (reconstruct_surface(a.S, prim, geom, h.u, h.v, surf)) {
+                        const float3 hitP = org + dir * h.t;
+                        V = normalize3(-dir); // :522
+                        const float a0 = rand01(rng), a1 = rand01(rng);
+                        const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
+                        const float3 L = normalize3(-sun_dir);
+                        const float3 Bv = normalize3(perpendicular(L));
+                        const float3 T = cross3(Bv, L);
+                        const float3 inc = normalize3(L + (Bv * sinf(angle) + T * cosf(angle)) * a.c.sunTanHalfAngle * dist);
+                        const bool transition = dot3(surf.GN, inc) <= 0.0f;
+                        const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
+                        Hit sh;
+                        rays++;
+                        if (!traverse(a.S, so, inc, 0.001f, kTraceMax, true, stack, sh)) {
+                            const float3 O = evaluate_direct_brdf(surf, V, L) * sun_rad;
+                            rad = rad + O * throughput; // :574
+                            dbg.flags |= 1u;
+                        }
+                    }
+                }
+            }
+            sum = sum + rad;
+        }
+        const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
+        float4 r = a.radiance[i];
+        r.x += sum.x * inv_spp;
+        r.y += sum.y * inv_spp;
+        r.z += sum.z * inv_spp;
+        a.radiance[i] = r;
+        if (a.hits)
+            a.hits[i] = dbg;
+    }
+    // one atomic per wave
+    uint32_t total = rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        total += __shfl_down(total, off);
+    if (lane == 0 && total)
+        atomicAdd(a.ray_counter, (unsigned long long)total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// G-buffer producer ("next" row f2): primary visibility through the same LBVH
+// ------------------------------------------------------------------------------------------------
+struct GbufArgs {
+    SceneView S;
+    float eye[3], xaxis[3], yaxis[3], zaxis[3];
+    float tan_half, aspect, m22, m32;
+    uint32_t* albedo;
+    uint32_t* rough_metal;
+    uint2* world_pos;
+    uint2* normal;
+    uint32_t* depth;
+    uint32_t W, H, row_begin, row0, row1, tiles_x;
+};
+
+__global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
+{
+    __shared__ int stack_mem[kStackDepth * 64];
+    const uint32_t lane = threadIdx.x;
+    int* stack = stack_mem + lane;
+    const uint32_t tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+    const uint32_t x = tile_x * 8 + (lane & 7), y = a.row0 + tile_y * 8 + (lane >> 3);
+    if (x >= a.W || y >= a.row1)
+        return;
+    const size_t i = (size_t)(y - a.row_begin) * a.W + x;
+    const float3 eye = f3(a.eye[0], a.eye[1], a.eye[2]), xa = f3(a.xaxis[0], a.xaxis[1], a.xaxis[2]),
+                 ya = f3(a.yaxis[0], a.yaxis[1], a.yaxis[2]), za = f3(a.zaxis[0], a.zaxis[1], a.zaxis[2]);
+    const float ndc_x = ((float)x + 0.5f) / (float)a.W * 2.0f - 1.0f;
+    const float ndc_y = 1.0f - ((float)y + 0.5f) / (float)a.H * 2.0f;
+    const float3 dir = normalize3(xa * (ndc_x * a.aspect * a.tan_half) + ya * (ndc_y * a.tan_half) - za);
+    Hit h;
+    bool hit = traverse(a.S, eye, dir, 0.0f, 1e30f, false, stack, h);
+    float depth = 1.0f;
+    float3 hitP = f3(0, 0, 0);
+    if (hit) {
+        hitP = eye + dir * h.t;
+        const float zv = dot3(hitP - eye, za);
+        depth = (a.m22 * zv + a.m32) / (-zv);
+        if (!(depth >= 0.0f && depth <= 1.0f))
+            hit = false;
+    }
+    float3 alb = f3(0, 0, 0);
+    float rm0 = 0.f, rm1 = 0.f;
+    float2 egn = make_float2(0.f, 0.f), esn = make_float2(0.f, 0.f);
+    uint32_t ds = 0x00ffffffu;
+    if (hit) {
+        const float4 ids = a.S.tris[3 * h.tri + 2];
+        const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
+        const DevGeom g = a.S.geoms[geom];
+        const float b1 = h.u, b2 = h.v, b0 = 1.0f - (b1 + b2);
+        rm0 = 1.0f; // deferred_gbuffers.hlsl:91
+        float3 GN = f3(0, 0, 1), SN = f3(0, 0, 1);
+        if (g.valid) {
+            const uint32_t i0 = g.vertexBase + a.S.indices[g.firstIndex + 3 * prim], i1 = g.vertexBase + a.S.indices[g.firstIndex + 3 * prim + 1],
+                           i2 = g.vertexBase + a.S.indices[g.firstIndex + 3 * prim + 2];
+            const float3 n0 = load3(a.S.normals, i0), n1 = load3(a.S.normals, i1), n2 = load3(a.S.normals, i2);
+            const float3 w0 = normalize3(xform_dir(g.m, n0)), w1 = normalize3(xform_dir(g.m, n1)), w2 = normalize3(xform_dir(g.m, n2));
+            GN = normalize3(w0 * b0 + w1 * b1 + w2 * b2);
+            SN = GN;
+            const float u = a.S.uvs[2 * i0] * b0 + a.S.uvs[2 * i1] * b1 + a.S.uvs[2 * i2] * b2;
+            const float v = a.S.uvs[2 * i0 + 1] * b0 + a.S.uvs[2 * i1 + 1] * b1 + a.S.uvs[2 * i2 + 1] * b2;
+            if (g.material >= 0) {
+                const DevMat m = a.S.mats[g.material];
+                if (m.tex[0] >= 0) {
+                    const float4 t = sample_texture(a.S, m.tex[0], u, v);
+                    alb = f3(t.x, t.y, t.z);
+                }
+                if (m.tex[1] >= 0) {
+                    const float* tp = a.S.tangents;
+                    const float3 tg0 = f3(tp[4 * i0], tp[4 * i0 + 1], tp[4 * i0 + 2]), tg1 = f3(tp[4 * i1], tp[4 * i1 + 1], tp[4 * i1 + 2]),
+                                 tg2 = f3(tp[4 * i2], tp[4 * i2 + 1], tp[4 * i2 + 2]);
+                    const float3 bt0 = normalize3(cross3(normalize3(n0), tg0) * tp[4 * i0 + 3]);
+                    const float3 bt1 = normalize3(cross3(normalize3(n1), tg1) * tp[4 * i1 + 3]);
+                    const float3 bt2 = normalize3(cross3(normalize3(n2), tg2) * tp[4 * i2 + 3]);
+                    const float3 T = normalize3(tg0 * b0 + tg1 * b1 + tg2 * b2);
+                    const float3 B = normalize3(bt0 * b0 + bt1 * b1 + bt2 * b2);
+                    const float4 t = sample_texture(a.S, m.tex[1], u, v);
+                    const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
+                    SN = normalize3(T * N.x + B * N.y + GN * N.z);
+                }
+                if (m.tex[2] >= 0) {
+                    const float4 t = sample_texture(a.S, m.tex[2], u, v);
+                    rm0 = t.y;
+                    rm1 = t.z;
+                }
+            }
+        }
+        egn = oct_pack(GN);
+        esn = oct_pack(SN);
+        ds = (uint32_t)rint((double)depth * 16777215.0) | 0xff000000u;
+    }
+    a.albedo[i] = small_float_encode(alb.x, 6) | (small_float_encode(alb.y, 6) << 11) | (small_float_encode(alb.z, 5) << 22);
+    a.rough_metal[i] = float_to_half_bits(rm0) | (float_to_half_bits(rm1) << 16);
+    a.world_pos[i] = make_uint2(float_to_half_bits(hitP.x) | (float_to_half_bits(hitP.y) << 16), float_to_half_bits(hitP.z));
+    a.normal[i] = make_uint2(float_to_half_bits(egn.x) | (float_to_half_bits(egn.y) << 16),
+                             float_to_half_bits(esn.x) | (float_to_half_bits(esn.y) << 16));
+    a.depth[i] = ds;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LBVH build (Karras 2012): Morton keys -> radix sort -> hierarchy -> bottom-up refit
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void lbvh_morton_kernel(const float* __restrict__ tris12, uint32_t n, float3 smin, float3 sinv, uint64_t* keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float* t = tris12 + 12 * (size_t)i;
+    const float3 v0 = f3(t[0], t[1], t[2]), v1 = f3(t[0] + t[3], t[1] + t[4], t[2] + t[5]), v2 = f3(t[0] + t[6], t[1] + t[7], t[2] + t[8]);
+    const float cx = (fminf(v0.x, fminf(v1.x, v2.x)) + fmaxf(v0.x, fmaxf(v1.x, v2.x))) * 0.5f;
+    const float cy = (fminf(v0.y, fminf(v1.y, v2.y)) + fmaxf(v0.y, fmaxf(v1.y, v2.y))) * 0.5f;
+    const float cz = (fminf(v0.z, fminf(v1.z, v2.z)) + fmaxf(v0.z, fmaxf(v1.z, v2.z))) * 0.5f;
+    const uint32_t qx = (uint32_t)fminf(fmaxf((cx - smin.x) * sinv.x * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf((cy - smin.y) * sinv.y * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf((cz - smin.z) * sinv.z * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t m = (expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz);
+    keys[i] = ((uint64_t)m << 32) | i; // the index makes every key unique
+}
+
+__global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint64_t* __restrict__ keys, uint32_t n, float4* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float* t = tris12 + 12 * (size_t)(uint32_t)(keys[i] & 0xffffffffu);
+    out[3 * i] = make_float4(t[0], t[1], t[2], t[3]);
+    out[3 * i + 1] = make_float4(t[4], t[5], t[6], t[7]);
+    out[3 * i + 2] = make_float4(t[8], t[9], t[10], t[11]);
+}
+
+__device__ __forceinline__ int lbvh_delta(const uint64_t* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n)
+        return -1;
+    return __clzll(keys[i] ^ keys[j]);
+}
+
+// one thread per inner node i in [0, n-2]
+__global__ void lbvh_hierarchy_kernel(const uint64_t* __restrict__ keys, int n, int2* children, int* parent_inner, int* parent_leaf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1)
+        return;
+    const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin)
+        lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin)
+            l += t;
+    const int j = i + l * d;
+    const int dnode = lbvh_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode)
+            s += t;
+        if (t <= 1)
+            break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const int c0 = (lo == gamma) ? ~gamma : gamma;             // leaf codes are ~index
+    const int c1 = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    children[i] = make_int2(c0, c1);
+    if (c0 < 0)
+        parent_leaf[gamma] = i;
+    else
+        parent_inner[gamma] = i;
+    if (c1 < 0)
+        parent_leaf[gamma + 1] = i;
+    else
+        parent_inner[gamma + 1] = i;
+}
+
+// one thread per leaf: walk up; the second arrival at a node owns it (boxes of both children are then visible)
+__global__ void lbvh_refit_kernel(const float4* __restrict__ tris, int n, const int2* __restrict__ children, const int* __restrict__ parent_inner,
+                                  const int* __restrict__ parent_leaf, float* node_min, float* node_max, uint32_t* visit, BvhNode* nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    int node = parent_leaf[i];
+    while (true) {
+        __threadfence();
+        if (atomicAdd(&visit[node], 1u) == 0u)
+            return; // first arrival: the sibling subtree is not finished yet
+        __threadfence();
+        const int2 ch = children[node];
+        float bmin[2][3], bmax[2][3];
+        const int cc[2] = {ch.x, ch.y};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (cc[k] < 0) {
+                const uint32_t ti = (uint32_t)~cc[k];
+                const float4 a = tris[3 * ti], b = tris[3 * ti + 1], c = tris[3 * ti + 2];
+                const float3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.x + a.w, a.y + b.x, a.z + b.y), v2 = f3(a.x + b.z, a.y + b.w, a.z + c.x);
+                bmin[k][0] = fminf(v0.x, fminf(v1.x, v2.x));
+                bmin[k][1] = fminf(v0.y, fminf(v1.y, v2.y));
+                bmin[k][2] = fminf(v0.z, fminf(v1.z, v2.z));
+                bmax[k][0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+                bmax[k][1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+                bmax[k][2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    bmin[k][q] = __hip_atomic_load(&node_min[3 * cc[k] + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bmax[k][q] = __hip_atomic_load(&node_max[3 * cc[k] + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        BvhNode out;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            out.c0min[q] = bmin[0][q];
+            out.c0max[q] = bmax[0][q];
+            out.c1min[q] = bmin[1][q];
+            out.c1max[q] = bmax[1][q];
+            __hip_atomic_store(&node_min[3 * node + q], fminf(bmin[0][q], bmin[1][q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&node_max[3 * node + q], fmaxf(bmax[0][q], bmax[1][q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        out.c0 = ch.x;
+        out.c1 = ch.y;
+        out.pad0 = out.pad1 = 0;
+        nodes[node] = out;
+        if (node == 0)
+            return; // root
+        node = parent_inner[node];
+    }
+}
+
+} // namespace neb
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace neb;
+
+static int gi_fail(neb_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof(buf), "%s", what);
+    ctx->last_error = buf;
+    return code;
+}
+
+#define GI_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess)                               \
+            return gi_fail((ctx), NEB_ERR_HIP, #call, e_);  \
+    } while (0)
+
+template <typename T>
+static hipError_t upload(GiState* g, const std::vector<T>& h, const T** out)
+{
+    *out = nullptr;
+    if (h.empty())
+        return hipSuccess;
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, h.size() * sizeof(T));
+    if (e != hipSuccess)
+        return e;
+    g->allocs.push_back(d);
+    *out = (const T*)d;
+    return hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+extern "C" {
+
+int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_geoms, const neb_material_desc* mats,
+                     uint32_t n_mats, const neb_texture_desc* texs, uint32_t n_texs)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    if ((n_geoms && !geoms) || (n_mats && !mats) || (n_texs && !texs))
+        return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_set_scene: null table");
+    GI_HIP(ctx, hipSetDevice(ctx->device));
+    GI_HIP(ctx, hipDeviceSynchronize());
+    gi_destroy(ctx->gi);
+    ctx->gi = nullptr;
+    GiState* g = new GiState();
+    std::vector<DevGeom> dgeoms(n_geoms);
+    std::vector<DevMat> dmats(n_mats);
+    std::vector<DevTex> dtexs(n_texs);
+    std::vector<uint32_t> indices, texels;
+    std::vector<float> normals, uvs, tangents;
+    uint32_t vertex_base = 0;
+    float smin[3] = {3.4e38f, 3.4e38f, 3.4e38f}, smax[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (uint32_t gi = 0; gi < n_geoms; ++gi) {
+        const neb_geometry_desc& s = geoms[gi];
+        if (s.indices && s.indexStride != 2 && s.indexStride != 4) {
+            delete g;
+            return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_set_scene: indexStride must be 2 or 4");
+        }
+        DevGeom& d = dgeoms[gi];
+        const float* m = s.surfaceToWorld;
+        const float m3[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+        memcpy(d.m, m3, sizeof(m3));
+        d.material = (s.materialIndex >= 0 && (uint32_t)s.materialIndex < n_mats) ? s.materialIndex : -1;
+        d.firstIndex = (uint32_t)indices.size();
+        d.vertexBase = vertex_base;
+        d.valid = (s.indices && s.attributes[0] && s.attributes[1] && s.attributes[2] && s.attributes[3]) ? 1u : 0u;
+        d.pad[0] = d.pad[1] = d.pad[2] = 0;
+        auto rd_index = [&](uint32_t i) -> uint32_t {
+            const uint8_t* p = (const uint8_t*)s.indices + (size_t)i * s.indexStride;
+            if (s.indexStride == 2) {
+                uint16_t v;
+                memcpy(&v, p, 2);
+                return v;
+            }
+            uint32_t v;
+            memcpy(&v, p, 4);
+            return v;
+        };
+        auto rd_attr = [&](int a, uint32_t vtx, float* out, int n) {
+            if (s.attributes[a])
+                memcpy(out, (const uint8_t*)s.attributes[a] + (size_t)vtx * s.attributeStrides[a], sizeof(float) * n);
+            else
+                for (int k = 0; k < n; ++k)
+                    out[k] = 0.f;
+        };
+        const uint32_t ntri = s.indices ? s.numIndices / 3 : 0;
+        for (uint32_t i = 0; i < ntri * 3; ++i) {
+            const uint32_t v = rd_index(i);
+            if (v >= s.numVertices) {
+                delete g;
+                return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_gi_set_scene: index beyond numVertices");
+            }
+            indices.push_back(v);
+        }
+        for (uint32_t v = 0; v < s.numVertices; ++v) {
+            float t[4];
+            rd_attr(1, v, t, 3);
+            normals.insert(normals.end(), t, t + 3);
+            rd_attr(2, v, t, 2);
+            uvs.insert(uvs.end(), t, t + 2);
+            rd_attr(3, v, t, 4);
+            tangents.insert(tangents.end(), t, t + 4);
+        }
+        vertex_base += s.numVertices;
+        // bake world-space triangles: world = (p,1) * M (the correct instance transform)
+        if (s.attributes[0]) {
+            for (uint32_t p = 0; p < ntri; ++p) {
+                float w[3][3];
+                for (int k = 0; k < 3; ++k) {
+                    float a[3];
+                    rd_attr(0, rd_index(3 * p + k), a, 3);
+                    w[k][0] = a[0] * m[0] + a[1] * m[4] + a[2] * m[8] + m[12];
+                    w[k][1] = a[0] * m[1] + a[1] * m[5] + a[2] * m[9] + m[13];
+                    w[k][2] = a[0] * m[2] + a[1] * m[6] + a[2] * m[10] + m[14];
+                    for (int q = 0; q < 3; ++q) {
+                        smin[q] = fminf(smin[q], w[k][q]);
+                        smax[q] = fmaxf(smax[q], w[k][q]);
+                    }
+                }
+                float t12[12] = {w[0][0], w[0][1], w[0][2], w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2],
+                                 w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2], 0.f, 0.f, 0.f};
+                memcpy(&t12[9], &gi, 4);
+                memcpy(&t12[10], &p, 4);
+                g->h_tris.insert(g->h_tris.end(), t12, t12 + 12);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n_mats; ++i) {
+        DevMat& d = dmats[i];
+        for (int k = 0; k < 3; ++k)
+            d.tex[k] = (mats[i].textureIndices[k] >= 0 && (uint32_t)mats[i].textureIndices[k] < n_texs) ? mats[i].textureIndices[k] : -1;
+        d.albedo[0] = mats[i].albedo[0];
+        d.albedo[1] = mats[i].albedo[1];
+        d.albedo[2] = mats[i].albedo[2];
+        d.rough = mats[i].roughnessMetalness[0];
+        d.metal = mats[i].roughnessMetalness[1];
+    }
+    for (uint32_t i = 0; i < n_texs; ++i) {
+        if (!texs[i].rgba8 || !texs[i].width || !texs[i].height) {
+            delete g;
+            return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_set_scene: empty texture");
+        }
+        dtexs[i].offset = (uint32_t)texels.size();
+        dtexs[i].w = texs[i].width;
+        dtexs[i].h = texs[i].height;
+        dtexs[i].pad = 0;
+        const uint32_t* px = (const uint32_t*)texs[i].rgba8;
+        texels.insert(texels.end(), px, px + (size_t)texs[i].width * texs[i].height);
+    }
+    g->n_tris = (uint32_t)(g->h_tris.size() / 12);
+    memcpy(g->scene_min, smin, sizeof(smin));
+    memcpy(g->scene_max, smax, sizeof(smax));
+    hipError_t e = hipSuccess;
+    if ((e = upload(g, dgeoms, &g->view.geoms)) != hipSuccess || (e = upload(g, dmats, &g->view.mats)) != hipSuccess ||
+        (e = upload(g, dtexs, &g->view.texs)) != hipSuccess || (e = upload(g, indices, &g->view.indices)) != hipSuccess ||
+        (e = upload(g, normals, &g->view.normals)) != hipSuccess || (e = upload(g, uvs, &g->view.uvs)) != hipSuccess ||
+        (e = upload(g, tangents, &g->view.tangents)) != hipSuccess || (e = upload(g, texels, &g->view.texels)) != hipSuccess) {
+        gi_destroy(g);
+        return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: upload", e);
+    }
+    void* ctr = nullptr;
+    if ((e = hipMalloc(&ctr, sizeof(unsigned long long))) != hipSuccess || (e = hipMemset(ctr, 0, sizeof(unsigned long long))) != hipSuccess) {
+        gi_destroy(g);
+        return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: counter", e);
+    }
+    g->allocs.push_back(ctr);
+    g->d_ray_counter = (unsigned long long*)ctr;
+    g->view.n_tris = g->n_tris;
+    ctx->gi = g;
+    return NEB_OK;
+}
+
+int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (!g)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_build_bvh: no scene (call neb_gi_set_scene first)");
+    hipStream_t stream = (hipStream_t)stream_;
+    GI_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = g->n_tris;
+    g->built = true;
+    g->n_nodes = 0;
+    g->view.root = -1;
+    if (n == 0)
+        return NEB_OK;
+    auto dalloc = [&](size_t bytes, bool keep) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess)
+            return nullptr;
+        if (keep)
+            g->allocs.push_back(p);
+        return p;
+    };
+    float* d_tris12 = (float*)dalloc((size_t)n * 48, false);
+    float4* d_sorted = (float4*)dalloc((size_t)n * 48, true);
+    uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8, false);
+    uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8, false);
+    const uint32_t n_inner = n > 1 ? n - 1 : 1;
+    BvhNode* d_nodes = (BvhNode*)dalloc((size_t)n_inner * sizeof(BvhNode), true);
+    int2* d_children = (int2*)dalloc((size_t)n_inner * sizeof(int2), false);
+    int* d_parent_inner = (int*)dalloc((size_t)n_inner * 4, false);
+    int* d_parent_leaf = (int*)dalloc((size_t)n * 4, false);
+    float* d_nmin = (float*)dalloc((size_t)n_inner * 12, false);
+    float* d_nmax = (float*)dalloc((size_t)n_inner * 12, false);
+    uint32_t* d_visit = (uint32_t*)dalloc((size_t)n_inner * 4, false);
+    void* temps[] = {d_tris12, d_keys, d_keys2, d_children, d_parent_inner, d_parent_leaf, d_nmin, d_nmax, d_visit};
+    auto free_temps = [&]() {
+        for (void* p : temps)
+            if (p)
+                (void)hipFree(p);
+    };
+    if (!d_tris12 || !d_sorted || !d_keys || !d_keys2 || !d_nodes || !d_children || !d_parent_inner || !d_parent_leaf || !d_nmin ||
+        !d_nmax || !d_visit) {
+        free_temps();
+        return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh: out of device memory");
+    }
+    hipError_t e = hipMemcpyAsync(d_tris12, g->h_tris.data(), (size_t)n * 48, hipMemcpyHostToDevice, stream);
+    const float3 smin = make_float3(g->scene_min[0], g->scene_min[1], g->scene_min[2]);
+    const float3 sinv = make_float3(1.0f / fmaxf(g->scene_max[0] - g->scene_min[0], 1e-20f), 1.0f / fmaxf(g->scene_max[1] - g->scene_min[1], 1e-20f),
+                                    1.0f / fmaxf(g->scene_max[2] - g->scene_min[2], 1e-20f));
+    const uint32_t nb = (n + 255) / 256;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, n, smin, sinv, d_keys);
+        e = hipGetLastError();
+    }
+    size_t temp_bytes = 0;
+    void* d_temp = nullptr;
+    if (e == hipSuccess)
+        e = hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
+    if (e == hipSuccess)
+        e = hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16);
+    if (e == hipSuccess)
+        e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, d_keys2, n, d_sorted);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && n > 1) {
+        e = hipMemsetAsync(d_visit, 0, (size_t)n_inner * 4, stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, d_keys2, (int)n, d_children,
+                               d_parent_inner, d_parent_leaf);
+            hipLaunchKernelGGL(lbvh_refit_kernel, dim3(nb), dim3(256), 0, stream, d_sorted, (int)n, d_children, d_parent_inner, d_parent_leaf,
+                               d_nmin, d_nmax, d_visit, d_nodes);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(stream); // the temporaries are freed below; the build is a one-time setup step
+    if (d_temp)
+        (void)hipFree(d_temp);
+    free_temps();
+    if (e != hipSuccess)
+        return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh", e);
+    g->view.tris = d_sorted;
+    g->view.nodes = d_nodes;
+    g->view.root = (n > 1) ? 0 : ~0; // single triangle: the root is leaf 0
+    g->n_nodes = (n > 1) ? n - 1 : 0;
+    std::vector<float>().swap(g->h_tris);
+    return NEB_OK;
+}
+
+int neb_gi_scene_info(const neb_ctx* ctx, uint32_t* n_triangles, uint32_t* n_nodes)
+{
+    if (!ctx || !ctx->gi)
+        return NEB_ERR_STATE;
+    if (n_triangles)
+        *n_triangles = ctx->gi->n_tris;
+    if (n_nodes)
+        *n_nodes = ctx->gi->n_nodes;
+    return NEB_OK;
+}
+
+int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, uint32_t row1, neb_stream stream)
+{
+    if (!ctx || !c)
+        return ctx ? gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: null constants") : NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (!g || !g->built)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
+    if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
+        return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_gi_trace: rows not resident");
+    if (c->samplesPerPixel == 0 || c->maxPathVertices > 2)
+        return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: samplesPerPixel must be >= 1 and maxPathVertices <= 2 (one bounce)");
+    if (row0 == row1)
+        return NEB_OK;
+    const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
+    if (g->debug_hits && !g->d_hits) {
+        void* p = nullptr;
+        GI_HIP(ctx, hipMalloc(&p, npx * sizeof(neb_gi_hit)));
+        GI_HIP(ctx, hipMemset(p, 0, npx * sizeof(neb_gi_hit)));
+        g->allocs.push_back(p);
+        g->d_hits = (neb_gi_hit*)p;
+    }
+    GiArgs a;
+    a.S = g->view;
+    a.c = *c;
+    a.albedo = (const uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
+    a.rough_metal = (const uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
+    a.world_pos = (const uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
+    a.normal = (const uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur];
+    a.radiance = (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur];
+    a.hits = g->debug_hits ? g->d_hits : nullptr;
+    a.ray_counter = g->d_ray_counter;
+    a.W = ctx->W;
+    a.row_begin = ctx->row_begin;
+    a.row0 = row0;
+    a.row1 = row1;
+    a.tiles_x = (ctx->W + 7) / 8;
+    const uint32_t tiles_y = (row1 - row0 + 7) / 8;
+    hipLaunchKernelGGL(gi_trace_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
+    GI_HIP(ctx, hipGetLastError());
+    return NEB_OK;
+}
+
+int neb_gi_trace(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    return neb_gi_trace_rows(ctx, c, ctx->row_begin, ctx->row_end, stream);
+}
+
+int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
+{
+    if (!ctx || !ctx->gi)
+        return ctx ? gi_fail(ctx, NEB_ERR_STATE, "neb_gi_ray_count: no scene") : NEB_ERR_INVALID_ARG;
+    unsigned long long v = 0;
+    GI_HIP(ctx, hipMemcpyAsync(&v, ctx->gi->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (reset)
+        GI_HIP(ctx, hipMemsetAsync(ctx->gi->d_ray_counter, 0, sizeof(v), (hipStream_t)stream));
+    if (rays)
+        *rays = v;
+    return NEB_OK;
+}
+
+int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream)
+{
+    if (!ctx || !host)
+        return NEB_ERR_INVALID_ARG;
+    if (!ctx->gi || !ctx->gi->d_hits)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_download_hits: set option gi_debug_hits=1 and trace first");
+    const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
+    GI_HIP(ctx, hipMemcpyAsync(host, ctx->gi->d_hits, npx * sizeof(neb_gi_hit), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return NEB_OK;
+}
+
+int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
+{
+    if (!ctx || !cam)
+        return NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (!g || !g->built)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gbuffer_raycast: scene/BVH not ready");
+    auto norm = [](float* v) {
+        const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        v[0] /= l;
+        v[1] /= l;
+        v[2] /= l;
+    };
+    GbufArgs a;
+    a.S = g->view;
+    float z[3] = {cam->eye[0] - cam->target[0], cam->eye[1] - cam->target[1], cam->eye[2] - cam->target[2]};
+    norm(z);
+    float x[3] = {cam->up[1] * z[2] - cam->up[2] * z[1], cam->up[2] * z[0] - cam->up[0] * z[2], cam->up[0] * z[1] - cam->up[1] * z[0]};
+    norm(x);
+    const float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    memcpy(a.eye, cam->eye, 12);
+    memcpy(a.xaxis, x, 12);
+    memcpy(a.yaxis, y, 12);
+    memcpy(a.zaxis, z, 12);
+    a.tan_half = tanf(cam->vfov_deg * (3.14159265f / 180.0f) * 0.5f);
+    a.aspect = (float)ctx->W / (float)ctx->H;
+    a.m22 = cam->zfar / (cam->znear - cam->zfar); // XMMatrixPerspectiveFovRH
+    a.m32 = cam->znear * cam->zfar / (cam->znear - cam->zfar);
+    a.albedo = (uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
+    a.rough_metal = (uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
+    a.world_pos = (uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
+    a.normal = (uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur];
+    a.depth = (uint32_t*)ctx->planes[NEB_PLANE_DEPTH][ctx->cur];
+    a.W = ctx->W;
+    a.H = ctx->H;
+    a.row_begin = ctx->row_begin;
+    a.row0 = ctx->row_begin;
+    a.row1 = ctx->row_end;
+    a.tiles_x = (ctx->W + 7) / 8;
+    const uint32_t tiles_y = (a.row1 - a.row0 + 7) / 8;
+    hipLaunchKernelGGL(gbuffer_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
+    GI_HIP(ctx, hipGetLastError());
+    return NEB_OK;
+}
+
+} // extern "C"
+
+namespace neb {
+int gi_set_debug_hits(neb_ctx* ctx, int on)
+{
+    if (!ctx->gi)
+        return NEB_ERR_STATE;
+    ctx->gi->debug_hits = on != 0;
+    return NEB_OK;
+}
+} // namespace neb

@@ -29,6 +29,10 @@ hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* r
 hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
                          const uint16_t* variance, const uint32_t* depth, const uint2* normal, hipStream_t s);
 
+struct GiState;               // gi.hip: scene tables, LBVH, counters
+void gi_destroy(GiState* g);
+int gi_set_debug_hits(neb_ctx* ctx, int on);
+
 } // namespace neb
 
 struct neb_ctx {
@@ -38,5 +42,6 @@ struct neb_ctx {
     int cur = 0, hist = 1;
     neb_svgf_params params{};
     int atrous_variant = 1; // 0 = direct-load kernel, 1 = LDS row-lattice kernel
+    neb::GiState* gi = nullptr;
     std::string last_error;
 };

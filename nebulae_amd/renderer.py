@@ -1,0 +1,164 @@
+"""Host-side mirror of the GI + SVGF portion of the reference's ``Neb::DeferredRenderer``.
+
+Names follow /root/reference/src/DeferredRenderer.h:45-81 (snake_case): ``init``, ``begin_frame``
+(with a ``RenderInfo``), ``submit_commands_gi_pathtrace``, ``submit_commands_svgf_denoising``,
+``end_frame``.  The frame policy is the reference's: SVGF is skipped while the camera (or sun) moves
+and history is reset on the first static frame (src/DeferredRenderer.cpp:133-146,593-614); the first
+rendered frame index is 1 (src/Renderer.cpp:262-273).  The raster G-buffer, PBR and tonemap passes
+of the reference are outside this path: the G-buffer comes from ``submit_commands_gbuffer`` (a
+primary-visibility ray cast with the reference encodings) or is uploaded by the caller.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib, scene as S
+from .svgf import PLANE_RADIANCE, SLOT_CURRENT, NebError, SVGFDenoiser  # noqa: F401
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("geometry", np.uint32), ("primitive", np.uint32), ("flags", np.uint32)])
+
+
+@dataclass
+class SceneSunUI:  # src/DeferredRenderer.h:111-116
+    rough_diameter: float = 0.58
+    direction: tuple = (0.5, -1.0, -0.2)
+    radiance: tuple = (20.0, 20.0, 20.0)
+
+
+@dataclass
+class GlobalIlluminationUI:  # src/DeferredRenderer.h:118-125 (nrcMaxPathVertices: 2 = one bounce, the supported value)
+    sky_color: tuple = (8.0, 8.0, 8.0)
+    gi_samples_per_pixel: int = 1
+    max_path_vertices: int = 2
+    throughput_threshold: float = 0.01
+
+
+@dataclass
+class RenderInfo:  # src/DeferredRenderer.h:56-63
+    scene: object
+    camera: S.CameraDesc
+    frame_index: int
+    stream: int = 0
+    timestep: float = 0.0
+
+
+class DeferredRenderer:
+    def __init__(self):
+        self.svgf = SVGFDenoiser()
+        self.sun = SceneSunUI()
+        self.gi_ui = GlobalIlluminationUI()
+        self._scene = None
+        self._eye = None
+        self._sun_key = None
+        self.dynamic_scene_this_frame = False
+        self.reset_history = False
+        self.info = None
+
+    # ---- DeferredRenderer::Init (src/DeferredRenderer.cpp:26-57) ----
+    def init(self, width, height, atrous_levels=None, device=0, row_begin=0, row_end=0):
+        self.svgf.init(width, height, atrous_levels=atrous_levels, device=device, row_begin=row_begin, row_end=row_end)
+        self.width, self.height = width, height
+        return True
+
+    @property
+    def _lib(self):
+        return self.svgf._lib
+
+    @property
+    def _ctx(self):
+        return self.svgf._ctx
+
+    def _check(self, rc, what):
+        _lib.check(self._lib, self._ctx, rc, what)
+
+    # ---- DeferredRenderer::InitPathtracerScene + InitRTAccelerationStructures (:978-1030,1083-1086) ----
+    def init_pathtracer_scene(self, scene, stream=0):
+        G, ng, M, nm, T, nt = scene.descs()
+        self._check(self._lib.neb_gi_set_scene(self._ctx, G, ng, M, nm, T, nt), "neb_gi_set_scene")
+        self._check(self._lib.neb_gi_build_bvh(self._ctx, C.c_void_p(stream)), "neb_gi_build_bvh")
+        self._scene = scene
+
+    def scene_info(self):
+        t, n = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.neb_gi_scene_info(self._ctx, C.byref(t), C.byref(n)), "neb_gi_scene_info")
+        return t.value, n.value
+
+    # ---- DeferredRenderer::BeginFrame (src/DeferredRenderer.cpp:89-149) ----
+    def begin_frame(self, info):
+        self.info = info
+        if info.scene is not None and info.scene is not self._scene:
+            self.init_pathtracer_scene(info.scene, info.stream)
+        self.svgf.begin_frame(info.frame_index)
+        eye = tuple(info.camera.eye)
+        sun_key = (self.sun.rough_diameter, tuple(self.sun.direction), tuple(self.sun.radiance))
+        moved = (eye != self._eye) or (self._sun_key is not None and sun_key != self._sun_key)  # :133-146,169-171
+        self._sun_key = sun_key
+        if moved:
+            self._eye = eye
+            self.dynamic_scene_this_frame = True
+        elif self.dynamic_scene_this_frame:
+            self.dynamic_scene_this_frame = False  # camera stopped: reset history and start denoising
+            self.reset_history = True
+
+    def end_frame(self):
+        self.svgf.end_frame()
+
+    def global_constants(self):
+        """GlobalConstants upload of SubmitCommandsGIPathtrace (src/DeferredRenderer.cpp:403-421)."""
+        import math
+        c = S.GIConstants()
+        c.frameIndex = self.info.frame_index & 0xFFFFFFFF
+        c.samplesPerPixel = int(self.gi_ui.gi_samples_per_pixel)
+        c.maxPathVertices = int(self.gi_ui.max_path_vertices)
+        c.cameraWorldPos[:] = tuple(self.info.camera.eye)
+        c.skyColor[:] = self.gi_ui.sky_color
+        c.sunLightDirection[:] = self.sun.direction
+        c.sunLightRadiance[:] = self.sun.radiance
+        c.sunTanHalfAngle = math.tan(math.radians(self.sun.rough_diameter * 0.5))
+        c.throughputThreshold = self.gi_ui.throughput_threshold
+        return c
+
+    # ---- passes ----
+    def submit_commands_gbuffer(self):
+        """Stand-in for SubmitCommandsGbuffer (:254-324): primary visibility by ray cast, reference encodings."""
+        self._check(self._lib.neb_gbuffer_raycast(self._ctx, C.byref(self.info.camera), C.c_void_p(self.info.stream)),
+                    "neb_gbuffer_raycast")
+
+    def submit_commands_gi_pathtrace(self, rows=None):
+        c = self.global_constants()
+        if rows is None:
+            rc = self._lib.neb_gi_trace(self._ctx, C.byref(c), C.c_void_p(self.info.stream))
+        else:
+            rc = self._lib.neb_gi_trace_rows(self._ctx, C.byref(c), rows[0], rows[1], C.c_void_p(self.info.stream))
+        self._check(rc, "neb_gi_trace")
+
+    def submit_commands_svgf_denoising(self):
+        if self.dynamic_scene_this_frame:  # :595
+            return False
+        if self.reset_history:
+            self.reset_history = False
+            self.svgf.reset_history(self.info.stream)
+        self.svgf.submit_temporal_accumulation(self.info.stream)
+        self.svgf.submit_atrous_compute_wavelet(self.info.stream)
+        return True
+
+    # ---- introspection ----
+    def ray_count(self, reset=False):
+        v = C.c_uint64()
+        self._check(self._lib.neb_gi_ray_count(self._ctx, C.byref(v), int(reset), C.c_void_p(self.info.stream if self.info else 0)),
+                    "neb_gi_ray_count")
+        return v.value
+
+    def set_debug_hits(self, on=True):
+        self.svgf.set_option("gi_debug_hits", int(on))
+
+    def download_hits(self):
+        rows = self.svgf.row_end - self.svgf.row_begin
+        out = np.zeros((rows, self.width), HIT_DTYPE)
+        self._check(self._lib.neb_gi_download_hits(self._ctx, out.ctypes.data_as(C.c_void_p),
+                                                   C.c_void_p(self.info.stream if self.info else 0)), "neb_gi_download_hits")
+        return out
+
+    def destroy(self):
+        self.svgf.destroy()

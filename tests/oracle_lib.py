@@ -93,3 +93,84 @@ class OracleSVGF:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# trace_ref (GI path tracer + G-buffer producer)
+# ---------------------------------------------------------------------------------------------
+class TraceHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("geometry", C.c_uint32), ("primitive", C.c_uint32), ("flags", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("geometry", np.uint32), ("primitive", np.uint32), ("flags", np.uint32)])
+
+
+def _trace_lib():
+    from nebulae_amd import scene as S
+    L = lib()
+    if not hasattr(L, "_trace_ready"):
+        L.trace_ref_scene_create.restype = C.c_void_p
+        L.trace_ref_scene_create.argtypes = [C.POINTER(S.GeometryDesc), C.c_uint32, C.POINTER(S.MaterialDesc), C.c_uint32,
+                                             C.POINTER(S.TextureDesc), C.c_uint32]
+        L.trace_ref_scene_destroy.argtypes = [C.c_void_p]
+        L.trace_ref_scene_triangles.argtypes = [C.c_void_p]
+        L.trace_ref_scene_triangles.restype = C.c_uint32
+        L.trace_ref_gi.restype = C.c_uint64
+        L.trace_ref_gi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(S.GIConstants),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.trace_ref_gbuffer.restype = None
+        L.trace_ref_gbuffer.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(S.CameraDesc), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.trace_ref_pack_r11g11b10.restype = C.c_uint32
+        L.trace_ref_pack_r11g11b10.argtypes = [C.POINTER(C.c_float)]
+        L.trace_ref_unpack_r11g11b10.restype = None
+        L.trace_ref_unpack_r11g11b10.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L._trace_ready = True
+    return L
+
+
+class OracleTracer:
+    """CPU checker for the GI path: owns a trace_ref_scene built from a nebulae_amd.scene.Scene."""
+
+    def __init__(self, scene, threads=None):
+        import os
+        self.L = _trace_lib()
+        self.scene = scene  # keeps the numpy arrays alive
+        self._descs = scene.descs()
+        G, ng, M, nm, T, nt = self._descs
+        self.p = self.L.trace_ref_scene_create(G, ng, M, nm, T, nt)
+        self.threads = threads or min(16, os.cpu_count() or 1)
+
+    @property
+    def triangles(self):
+        return self.L.trace_ref_scene_triangles(self.p)
+
+    def gbuffer(self, W, H, cam):
+        out = dict(albedo=np.zeros((H, W), np.uint32), rough_metal=np.zeros((H, W, 2), np.float16),
+                   world_pos=np.zeros((H, W, 4), np.float16), normal=np.zeros((H, W, 4), np.float16),
+                   depth=np.zeros((H, W), np.uint32))
+        self.L.trace_ref_gbuffer(self.p, W, H, C.byref(cam), out["albedo"].ctypes.data, out["rough_metal"].ctypes.data,
+                                 out["world_pos"].ctypes.data, out["normal"].ctypes.data, out["depth"].ctypes.data,
+                                 self.threads)
+        return out
+
+    def gi(self, gb, consts, radiance=None, rows=None, want_hits=True):
+        H, W = gb["albedo"].shape
+        rad = np.zeros((H, W, 4), np.float32) if radiance is None else np.ascontiguousarray(radiance, np.float32)
+        hits = np.zeros((H, W), HIT_DTYPE) if want_hits else None
+        r0, r1 = rows or (0, H)
+        rays = self.L.trace_ref_gi(self.p, W, H, r0, r1, C.byref(consts), gb["albedo"].ctypes.data,
+                                   gb["rough_metal"].ctypes.data, gb["world_pos"].ctypes.data, gb["normal"].ctypes.data,
+                                   rad.ctypes.data, hits.ctypes.data if want_hits else None, self.threads)
+        return rad, hits, int(rays)
+
+    def close(self):
+        if self.p:
+            self.L.trace_ref_scene_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
