@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-One "step" = one frame of the hot path on device-resident inputs: refresh radiance[cur] with the
-frame's noisy input (device-to-device, stands in for the PBR + GI writes that precede SVGF in
-Renderer::RenderSceneDeferred, src/Renderer.cpp:123-133), SVGF temporal accumulation, and the
-a-trous wavelet levels.  Workload at N=1: BASELINE.json configs[2] -- 1920x1080, 1 spp, 5 a-trous
-levels ("sponza-gltf-pbr"; the Sponza geometry blobs are stripped from the reference checkout, so
-the G-buffer is the synthetic stand-in of nebulae_amd/synth.py).
+One "step" = one frame of the hot path on device-resident inputs, in the order of
+Renderer::RenderSceneDeferred (/root/reference/src/Renderer.cpp:123-133): radiance[cur] <- the
+direct-light term (device-to-device copy of a resident plane; stands in for the PBR pass that
+overwrites it), the GI dispatch (one-bounce indirect diffuse, adds into radiance[cur]), SVGF temporal
+accumulation and the a-trous wavelet levels.  Workload at N=1: BASELINE.json configs[2] --
+1920x1080, 1 spp, 5 a-trous levels on "sponza-standin" (the Sponza geometry blobs are stripped from
+the reference checkout; nebulae_amd/scene.py:atrium_standin matches Sponza.gltf's statistics).
+The G-buffer is produced once, outside the timed region, by neb_gbuffer_raycast (static camera).
 
-Prints ONE JSON line (rank 0).  Extra keys: "roofline" (dominant kernel: a-trous level, HBM bound,
-algorithmic 46 B/px/level) and "cpu_baseline" (the scalar C oracle timed on the host cores).
+N > 1 (weak scaling): the frame grows with N -- rank r owns a 1080p-equivalent row strip of a
+(1920*a) x (1080*b) image, a*b = N (N=4 is BASELINE.json configs[3], 3840x2160) -- and the strips
+exchange a-trous halo rows over RCCL (nebulae_amd/strips.py).  `value` is in 1080p-frame
+equivalents per second: N x (global frames/s).
+
+Prints ONE JSON line (rank 0) with "roofline" (dominant kernel = a-trous level, HBM bound,
+algorithmic 46 B/px/level) and "cpu_baseline" (the scalar C/C++ oracle on the host cores).
 """
 import argparse
 import json
@@ -30,40 +37,56 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920, help="per-GPU-equivalent frame width")
+    ap.add_argument("--height", type=int, default=1080, help="per-GPU-equivalent frame height")
     ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--atrous-variant", type=int, default=1)
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU oracle to time (0 = skip)")
+    ap.add_argument("--triangles", type=int, default=262267)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="SVGF frames of the CPU oracle to time (0 = skip the CPU leg)")
+    ap.add_argument("--svgf-only", action="store_true", help="skip the GI dispatch (synthetic noisy radiance instead)")
     return ap.parse_args()
 
 
-def cpu_baseline(W, H, L, frames, g, rads):
-    """Times oracle/svgf_ref.c (kind "port") on all host cores over `frames` full frames."""
+def host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))  # a 1-GPU box shares its host: 16 cores is this job's CPU share
+
+
+def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
+    """Times the oracle (kind "port": oracle/svgf_ref.c + oracle/trace_ref.cpp) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import OracleSVGF
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 16)  # the 1-GPU box shares its host: 16 cores is this job's CPU share
+    import numpy as np
+    from oracle_lib import OracleSVGF, OracleTracer
+    cores = host_cores()
+    t_gi, rays = 0.0, 0
+    if do_gi:
+        tr = OracleTracer(scene, threads=cores)
+        t0 = time.perf_counter()
+        noisy, _, rays = tr.gi(gb, consts, radiance=np.zeros((H, W, 4), np.float32), want_hits=False)
+        t_gi = time.perf_counter() - t0
+        tr.close()
     o = OracleSVGF(W, H, L, threads=cores)
-    # one untimed frame so history is populated (frame 1 is all-history, quirk 2)
     times = []
-    for f in range(1, frames + 2):
+    for f in range(1, frames + 2):  # frame 1 (all-history, quirk 2) is warm-up
         o.begin_frame(f)
         c = o.cur
-        o.depth[c][...] = g["depth"]
-        o.normal[c][...] = g["normal"]
+        o.depth[c][...] = gb["depth"]
+        o.normal[c][...] = gb["normal"]
+        o.radiance[c][...] = noisy
         t0 = time.perf_counter()
-        o.radiance[c][...] = rads[f % len(rads)]
         o.temporal_pass()
         o.atrous_pass()
-        t1 = time.perf_counter()
         if f > 1:
-            times.append(t1 - t0)
+            times.append(time.perf_counter() - t0)
     o.close()
-    dt = sum(times) / len(times)
+    t_svgf = sum(times) / len(times)
+    dt = t_gi + t_svgf
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} full {W}x{H} frames (temporal + {L} a-trous levels) of oracle/svgf_ref.c, "
-                      f"OpenMP row-parallel on {cores} threads, mean frame {dt * 1e3:.1f} ms"}
+            "gi_mrays_per_s": (rays / t_gi / 1e6) if do_gi else None,
+            "sample": (f"1 full {W}x{H} GI frame ({rays} rays, {t_gi * 1e3:.0f} ms) of oracle/trace_ref.cpp + " if do_gi else "")
+                      + f"{len(times)} full {W}x{H} SVGF frames (temporal + {L} a-trous levels, mean {t_svgf * 1e3:.0f} ms) of "
+                        f"oracle/svgf_ref.c; OpenMP row-parallel on {cores} threads"}
 
 
 def main():
@@ -83,35 +106,56 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from nebulae_amd import synth
-    from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE, SLOT_CURRENT, SVGFDenoiser
+    from nebulae_amd import scene as S
+    from nebulae_amd import strips, synth
+    from nebulae_amd.renderer import RenderInfo
+    from nebulae_amd.svgf import PLANE_ALBEDO, PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE, PLANE_ROUGH_METAL, PLANE_WORLDPOS
 
-    W, H, L = args.width, args.height, args.levels
-    den = SVGFDenoiser()
-    den.init(W, H, atrous_levels=L, device=local_rank)
-    den.set_option("atrous_variant", args.atrous_variant)
-
-    g = synth.synth_gbuffer(W, H)
-    n_inputs = 4
-    rads_host = [synth.synth_radiance(g["base"], f + 1) for f in range(n_inputs)]
-    rads_dev = [torch.from_numpy(r).cuda() for r in rads_host]
-    for slot in (0, 1):  # static camera: both G-buffer slots hold the same depth/normals
-        den.upload(PLANE_DEPTH, slot, g["depth"])
-        den.upload(PLANE_NORMAL, slot, g["normal"])
-    rad_view = [den.plane_tensor(PLANE_RADIANCE, 0), den.plane_tensor(PLANE_RADIANCE, 1)]
+    L = args.levels
+    # weak scaling: the global frame is (W*a) x (H*b) with a*b = world; every rank owns W*H pixels of it
+    a, b = strips.frame_factors(world)
+    GW, GH = args.width * a, args.height * b
+    part = strips.StripPartition(GW, GH, world, L)
+    r = strips.StripRenderer(part, rank, device=local_rank, group=dist.group.WORLD if world > 1 else None)
+    r.svgf.set_option("atrous_variant", args.atrous_variant)
+    r.gi_ui.gi_samples_per_pixel = args.spp
+    own0, own1 = part.owned(rank)
+    res0, res1 = part.resident(rank)
 
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
-    frame = [0]
+    do_gi = not args.svgf_only
+    sc = S.atrium_standin(target_triangles=args.triangles)
+    cam = S.sponza_camera()
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=sh))
+    r.submit_commands_gbuffer()          # G-buffer of this rank's resident rows, slot "current" of frame 1
+    torch.cuda.synchronize()
+    for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: the other slot holds the same G-buffer
+        r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
+    rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
+    direct = torch.zeros_like(rad_view[0])
+    direct[..., 3] = 1.0
+    noisy_dev = None
+    if not do_gi:
+        g = synth.synth_gbuffer(GW, GH)
+        noisy_dev = [torch.from_numpy(synth.synth_radiance(g["base"][res0:res1], f + 1)).cuda() for f in range(4)]
+    frame = [1]
+    ran_svgf = []
 
-    def step():
+    def step(timed_events=None):
         frame[0] += 1
         f = frame[0]
-        den.begin_frame(f)
-        rad_view[den.get_current_resource_index()].copy_(rads_dev[f % n_inputs], non_blocking=True)
-        den.submit_temporal_accumulation(stream=sh)
-        den.submit_atrous_compute_wavelet(stream=sh)
-        den.end_frame()
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=sh))
+        cur = r.svgf.get_current_resource_index()
+        rad_view[cur].copy_(direct if do_gi else noisy_dev[f % 4], non_blocking=True)
+        if timed_events is not None:
+            timed_events["gi0"].record(stream)
+        if do_gi:
+            r.submit_commands_gi_pathtrace()
+        if timed_events is not None:
+            timed_events["gi1"].record(stream)
+        ran_svgf.append(r.submit_commands_svgf_denoising(timed_events))
+        r.end_frame()
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,69 +163,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):  # >= 2: frame 2 is "camera moved", frame 3 resets history
         step()
     barrier()
+    del ran_svgf[:]
+    if do_gi:
+        r.ray_count(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    rays_timed = r.ray_count(reset=True) if do_gi else 0
+    assert all(ran_svgf), "SVGF was skipped inside the timed region"
+    stats = torch.tensor([dt, float(rays_timed)], device="cuda", dtype=torch.float64)
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dt, rays_total = float(mx[0].item()), float(stats[1].item())
+    else:
+        rays_total = float(rays_timed)
 
-    # ---- dominant kernel: per-launch duration of the a-trous level kernel (HIP events on its stream) ----
+    # ---- per-kernel durations: HIP events on the launch stream, 8 extra frames ----
     ev = []
     for _ in range(8):
-        frame[0] += 1
-        den.begin_frame(frame[0])
-        rad_view[den.get_current_resource_index()].copy_(rads_dev[frame[0] % n_inputs], non_blocking=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        den.submit_temporal_accumulation(stream=sh)
-        e1.record(stream)
-        lv = []
-        for i in range(L):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            den.submit_atrous_level(i, (0, H), stream=sh)
-            b.record(stream)
-            lv.append((a, b))
-        ev.append(((e0, e1), lv))
+        e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1")}
+        e["levels"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
+        step(e)
+        ev.append(e)
     torch.cuda.synchronize()
-    t_temporal = float(np.mean([a.elapsed_time(b) for (a, b), _ in ev])) * 1e-3
-    per_level = [float(np.mean([lv[i][0].elapsed_time(lv[i][1]) for _, lv in ev])) * 1e-3 for i in range(L)]
+    rays_ev = r.ray_count(reset=True) if do_gi else 0
+    t_gi = float(np.mean([e["gi0"].elapsed_time(e["gi1"]) for e in ev])) * 1e-3
+    t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev])) * 1e-3
+    per_level = [float(np.mean([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev])) * 1e-3 for i in range(L)]
     t_atrous = float(np.mean(per_level))
 
     if rank == 0:
-        px = W * H
-        fps = args.steps / dt * world  # every rank denoises its own W x H frame (replicas until strips land)
-        achieved = ATROUS_BYTES_PX * px / t_atrous / 1e9
+        own_px = (own1 - own0) * GW                       # pixels a rank owns (= one 1080p frame)
+        fps_equiv = args.steps / dt * world               # 1080p-frame equivalents per second, whole job
+        achieved = ATROUS_BYTES_PX * own_px / t_atrous / 1e9
         out = {
-            "metric": "denoised frames/s (SVGF temporal + a-trous, 1920x1080 1 spp)", "value": fps, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"sponza-standin(synthetic G-buffer) {W}x{H}, 1 spp, SVGF temporal + {L} a-trous levels",
-                       "width": W, "height": H, "atrous_levels": L, "atrous_variant": args.atrous_variant,
-                       "frames_per_rank": args.steps, "parallelism": f"replicas x{world}" if world > 1 else "single"},
-            "frame_algorithmic_GBps": (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L) * px * (args.steps / dt) / 1e9,
-            "kernel_us": {"temporal": t_temporal * 1e6, "atrous_levels": [t * 1e6 for t in per_level]},
+            "metric": "denoised frames/s (1920x1080-frame equivalents: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
+                      "denoised frames/s (1920x1080-frame equivalents: SVGF temporal + a-trous only)",
+            "value": fps_equiv, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sponza-standin {GW}x{GH} ({sc.num_triangles} triangles, {len(sc.geometries)} submeshes), "
+                                   f"{args.spp} spp one-bounce GI + SVGF temporal + {L} a-trous levels"
+                                   + ("" if do_gi else " [GI skipped: --svgf-only]"),
+                       "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
+                       "parallelism": f"row-strips x{world} + RCCL a-trous halo exchange" if world > 1 else "single GPU"},
+            "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
+            "gi_kernel_mrays_per_s": (rays_ev / 8 / t_gi / 1e6) if do_gi else None,
+            "frame_algorithmic_GBps": (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L) * own_px * world * (args.steps / dt) / 1e9,
+            "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": t_temporal * 1e6, "atrous_levels": [t * 1e6 for t in per_level]},
             "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None},
-            "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS,
+            "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s"},
         }
-        if args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(W, H, L, args.cpu_frames, g, rads_host)
+        if args.cpu_frames > 0 and world == 1:
+            gb = {"albedo": r.svgf.download(PLANE_ALBEDO, 0), "rough_metal": r.svgf.download(PLANE_ROUGH_METAL, 0),
+                  "world_pos": r.svgf.download(PLANE_WORLDPOS, 0), "normal": r.svgf.download(PLANE_NORMAL, 0),
+                  "depth": r.svgf.download(PLANE_DEPTH, 0)}
+            noisy = noisy_dev[0].cpu().numpy() if not do_gi else None
+            out["cpu_baseline"] = cpu_baseline(GW, GH, L, args.cpu_frames, gb, r.global_constants(), sc, noisy, do_gi)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    den.destroy()
+    r.destroy()
 
 
 if __name__ == "__main__":

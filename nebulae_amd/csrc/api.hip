@@ -294,6 +294,7 @@ static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
     L.W = ctx->W;
     L.H = ctx->H;
     L.row_begin = ctx->row_begin;
+    L.row_end = ctx->row_end;
     L.row0 = row0;
     L.row1 = row1;
     L.p = ctx->params;

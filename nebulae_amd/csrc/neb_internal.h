@@ -17,6 +17,7 @@ extern const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT];
 struct SvgfLaunch {
     uint32_t W, H;         // full image size (global clamp uses these)
     uint32_t row_begin;    // first resident image row: plane address of (x, y) is (y - row_begin) * W + x
+    uint32_t row_end;      // one past the last resident row
     uint32_t row0, row1;   // image rows to process
     neb_svgf_params p;
 };

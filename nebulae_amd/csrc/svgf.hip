@@ -114,7 +114,7 @@ struct AtrousArgs {
     const uint32_t* depth;
     const uint2* normal;
     int W, H, Wd;               // image size and floor-dispatched width
-    int row_begin;              // first resident image row
+    int row_begin, row_end;     // resident image rows [row_begin, row_end)
     int row0, row1;             // image rows to write (row1 already clipped to (H/8)*8)
     int step;
     int tiles_x, tiles_j;       // LDS kernel: tiles per row segment / per residue class
@@ -226,7 +226,11 @@ __global__ __launch_bounds__(256, 4) void svgf_atrous_lds_kernel(AtrousArgs a)
 #pragma unroll 4
     for (int i = threadIdx.x; i < TOTAL; i += 256) {
         const int lr = i / COLS, lc = i - lr * COLS;
-        const int y = min(max(r + S * (jbase + lr - 2), 0), a.H - 1);
+        // clamp to the image (the reference's edge rule), then to the resident rows: a partial tile
+        // also stages rows that no valid output taps; on a row strip those may lie outside the
+        // allocation, so they are redirected to a resident row (their values are never used)
+        int y = min(max(r + S * (jbase + lr - 2), 0), a.H - 1);
+        y = min(max(y, a.row_begin), a.row_end - 1);
         const int x = min(max(x0 - 2 * S + lc, 0), a.W - 1);
         const size_t q = (size_t)(y - a.row_begin) * a.W + x;
         const float4 c = src[q];
@@ -345,6 +349,7 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
     a.H = (int)L.H;
     a.Wd = (int)Wd;
     a.row_begin = (int)L.row_begin;
+    a.row_end = (int)L.row_end;
     a.row0 = (int)L.row0;
     a.row1 = (int)row1;
     a.step = (int)step;
