@@ -1,0 +1,114 @@
+// nebulae_hip.hpp -- C++ host-side mirror of the reference classes over the C ABI (nebulae_hip.h).
+//
+// Same member names and argument meaning as Neb::SVGFDenoiser (src/SVGFDenoiser.h:11-93) and the GI
+// methods of Neb::DeferredRenderer (src/DeferredRenderer.h:50-81); ID3D12GraphicsCommandList4* becomes a
+// HIP stream.  Error behaviour follows the reference: failures throw (the reference throws HrException
+// through ThrowIfFailed/ThrowIfFalse, src/nri/stdafx.h:44-98); here the exception carries neb_last_error().
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "nebulae_hip.h"
+
+namespace Neb
+{
+
+    struct NebException : std::runtime_error
+    {
+        int Status;
+        NebException(int status, const std::string& what) : std::runtime_error(what), Status(status) {}
+    };
+
+    inline void ThrowIfFailed(neb_ctx* ctx, int status, const char* what)
+    {
+        if (status != NEB_OK)
+            throw NebException(status, std::string(what) + ": " + neb_last_error(ctx));
+    }
+
+    class SVGFDenoiser
+    {
+    public:
+        SVGFDenoiser() = default;
+        SVGFDenoiser(const SVGFDenoiser&) = delete;
+        SVGFDenoiser& operator=(const SVGFDenoiser&) = delete;
+        ~SVGFDenoiser() { neb_destroy(m_ctx); }
+
+        bool IsInitialized() const { return m_ctx != nullptr; }
+
+        // SVGFDenoiser::Init (src/SVGFDenoiser.cpp:14-26).  rowBegin/rowEnd select a multi-GPU row strip.
+        bool Init(uint32_t width, uint32_t height, uint32_t numAtrousPasses = NumAtrousPasses, int device = 0,
+                  uint32_t rowBegin = 0, uint32_t rowEnd = 0)
+        {
+            if (IsInitialized())
+                throw NebException(NEB_ERR_STATE, "SVGFDenoiser::Init: already initialised");
+            neb_create_info info{device, width, height, rowBegin, rowEnd, numAtrousPasses};
+            ThrowIfFailed(nullptr, neb_create(&info, &m_ctx), "neb_create");
+            return true;
+        }
+        // The reference returns false on success (src/SVGFDenoiser.cpp:36) and its caller throws on it; fixed here.
+        bool Resize(uint32_t width, uint32_t height)
+        {
+            ThrowIfFailed(m_ctx, neb_resize(m_ctx, width, height), "neb_resize");
+            return true;
+        }
+
+        void BeginFrame(uint32_t frameIndex) { ThrowIfFailed(m_ctx, neb_begin_frame(m_ctx, frameIndex), "neb_begin_frame"); }
+        void EndFrame() { ThrowIfFailed(m_ctx, neb_end_frame(m_ctx), "neb_end_frame"); }
+        uint32_t GetCurrentResourceIndex() const { return (uint32_t)neb_current_index(m_ctx); }
+        uint32_t GetHistoryResourceIndex() const { return (uint32_t)neb_history_index(m_ctx); }
+
+        // One accessor instead of the ~25 descriptor getters: device pointer of a plane (borrowed).
+        void* GetPlane(neb_plane plane, int slot = NEB_SLOT_CURRENT, size_t* pitchBytes = nullptr, uint32_t* rows = nullptr)
+        {
+            void* p = nullptr;
+            ThrowIfFailed(m_ctx, neb_get_plane(m_ctx, plane, slot, &p, pitchBytes, rows), "neb_get_plane");
+            return p;
+        }
+        void* GetCurrentRadianceTexture() { return GetPlane(NEB_PLANE_RADIANCE, NEB_SLOT_CURRENT); }
+        void* GetHistoryRadianceTexture() { return GetPlane(NEB_PLANE_RADIANCE, NEB_SLOT_HISTORY); }
+
+        void ResetHistory(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_reset_history(m_ctx, commandList), "neb_svgf_reset_history"); }
+        void SubmitTemporalAccumulation(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_temporal(m_ctx, commandList), "neb_svgf_temporal"); }
+        void SubmitATrousComputeWavelet(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_atrous(m_ctx, commandList), "neb_svgf_atrous"); }
+
+        // GetTemporalConstants()/GetATrousConstants(): one POD with the six tunables (SVGFDenoiser.h:76-92).
+        neb_svgf_params GetConstants() const
+        {
+            neb_svgf_params p;
+            ThrowIfFailed(m_ctx, neb_svgf_get_params(m_ctx, &p), "neb_svgf_get_params");
+            return p;
+        }
+        void SetConstants(const neb_svgf_params& p) { ThrowIfFailed(m_ctx, neb_svgf_set_params(m_ctx, &p), "neb_svgf_set_params"); }
+
+        neb_ctx* Context() const { return m_ctx; }
+        static constexpr uint32_t NumAtrousPasses = 4; // src/SVGFDenoiser.h:199
+
+    private:
+        neb_ctx* m_ctx = nullptr;
+    };
+
+    // The GI methods of DeferredRenderer that sit on the hot path (src/DeferredRenderer.h:79, .cpp:396-591,978-1030).
+    class GIPathtracer
+    {
+    public:
+        explicit GIPathtracer(SVGFDenoiser& svgf) : m_svgf(svgf) {}
+        void InitPathtracerScene(const neb_geometry_desc* geoms, uint32_t nGeoms, const neb_material_desc* mats, uint32_t nMats,
+                                 const neb_texture_desc* texs, uint32_t nTexs)
+        {
+            ThrowIfFailed(m_svgf.Context(), neb_gi_set_scene(m_svgf.Context(), geoms, nGeoms, mats, nMats, texs, nTexs), "neb_gi_set_scene");
+        }
+        void InitRTAccelerationStructures(neb_stream commandList)
+        {
+            ThrowIfFailed(m_svgf.Context(), neb_gi_build_bvh(m_svgf.Context(), commandList), "neb_gi_build_bvh");
+        }
+        void SubmitCommandsGIPathtrace(const neb_gi_constants& globalConstants, neb_stream commandList)
+        {
+            ThrowIfFailed(m_svgf.Context(), neb_gi_trace(m_svgf.Context(), &globalConstants, commandList), "neb_gi_trace");
+        }
+
+    private:
+        SVGFDenoiser& m_svgf;
+    };
+
+} // namespace Neb

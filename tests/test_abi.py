@@ -59,3 +59,18 @@ def test_no_cpu_fallback_when_no_device():
     d = SVGFDenoiser()
     with pytest.raises(NebError):
         d.init(64, 64)
+
+
+def test_cpp_mirror_header_compiles_against_the_abi(tmp_path):
+    """include/nebulae_hip.hpp (Neb::SVGFDenoiser / Neb::GIPathtracer over the C ABI) compiles and links."""
+    import subprocess
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "nebulae_hip.hpp"\n'
+                   'int main() { Neb::SVGFDenoiser d; Neb::GIPathtracer g(d);\n'
+                   '  try { d.Init(0, 0); } catch (const Neb::NebException& e) { return e.Status == NEB_ERR_INVALID_ARG ? 0 : 2; }\n'
+                   '  return 1; }\n')
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(build.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lnebulae_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([str(exe)]) == 0
