@@ -96,7 +96,8 @@ int neb_svgf_default_params(neb_svgf_params* out);
 int neb_svgf_set_params(neb_ctx* ctx, const neb_svgf_params* p);
 int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
 /* Implementation knobs with no reference counterpart (A/B arms for profiling):
- *   "atrous_variant": 1 = LDS row-lattice kernel (default), 0 = direct-load kernel;
+ *   "atrous_variant": 1 = LDS row-lattice kernel (default; 4 rows per lane for steps <= 4, 2 for wider steps),
+ *                     2 / 3 = LDS kernel with 2 / 4 rows per lane everywhere, 0 = direct-load kernel;
  *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene). */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
@@ -202,6 +203,9 @@ int neb_gi_trace(neb_ctx* ctx, const neb_gi_constants* constants, neb_stream str
 int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* constants, uint32_t row0, uint32_t row1, neb_stream stream);
 /* Rays traced (bounce + shadow) by all GI dispatches since the last reset.  Synchronises `stream`. */
 int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream);
+/* Diagnostics: counters as of the last neb_gi_ray_count call: {rays, bounce node visits, bounce triangle tests,
+ * shadow node visits, shadow triangle tests}; the shadow entries are only collected while "gi_debug_hits" is 1. */
+int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5]);
 /* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);
 /* "next" row f2: primary-visibility G-buffer producer with the encodings of

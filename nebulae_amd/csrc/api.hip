@@ -100,6 +100,11 @@ int neb_create(const neb_create_info* info, neb_ctx** out_ctx)
     if (!ctx)
         return fail(nullptr, NEB_ERR_HIP, "neb_create: out of host memory");
     ctx->device = info->device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, info->device) == hipSuccess && cus > 0)
+            ctx->num_cus = cus;
+    }
     ctx->W = info->width;
     ctx->H = info->height;
     ctx->row_begin = info->row_begin;
@@ -195,8 +200,8 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
     if (!ctx || !key)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: null argument");
     if (!strcmp(key, "atrous_variant")) {
-        if (value < 0 || value > 1)
-            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: atrous_variant must be 0 or 1");
+        if (value < 0 || value > 3)
+            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: atrous_variant must be 0..3");
         ctx->atrous_variant = value;
         return NEB_OK;
     }
@@ -297,6 +302,7 @@ static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
     L.row_end = ctx->row_end;
     L.row0 = row0;
     L.row1 = row1;
+    L.num_cus = ctx->num_cus;
     L.p = ctx->params;
     return L;
 }

@@ -58,9 +58,19 @@ struct BvhNode {
     uint32_t pad1;
 };
 
+// 128-byte BVH4 node produced by collapsing the LBVH (SoA per axis: one float4 per bound and axis).
+// child >= 0: inner node index; child < 0: leaf, code = ~child = (first_triangle << 2) | (count - 1), count <= 4;
+// unused slots carry an inverted (never-hit) box.
+struct Bvh4Node {
+    float4 lox, loy, loz, hix, hiy, hiz;
+    int4 child;
+    int4 pad;
+};
+constexpr int kMaxLeafTris = 4;
+
 struct SceneView {
     const float4* tris;      // 3 x float4 per triangle: {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, geom, prim, -}
-    const BvhNode* nodes;
+    const Bvh4Node* nodes;
     const DevGeom* geoms;
     const DevMat* mats;
     const DevTex* texs;
@@ -84,6 +94,10 @@ struct GiState {
     unsigned long long* d_ray_counter = nullptr;
     neb_gi_hit* d_hits = nullptr;
     bool debug_hits = false;
+    float4* d_records = nullptr; // 7 float4 planes over the resident pixels (GiRecords)
+    unsigned long long last_stats[8] = {};
+    uint32_t* d_block_counts = nullptr; // [2][n_block_counts]: bounce / shadow rays per workgroup
+    size_t n_block_counts = 0;
 };
 
 void gi_destroy(GiState* g)
@@ -271,11 +285,13 @@ __device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
 // ------------------------------------------------------------------------------------------------
 // Traversal
 // ------------------------------------------------------------------------------------------------
-constexpr int kStackDepth = 64;
+constexpr int kLdsStack = 16;     // per-lane entries kept in LDS (4 KB per wave)
+constexpr int kSpillStack = 48;   // deeper entries go to a private (scratch) array; rarely touched
 
 struct Hit {
     float t, u, v;
     uint32_t tri;
+    uint32_t node_visits, tri_tests; // traversal statistics (neb_gi_traversal_stats)
 };
 
 __device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, uint32_t ti, float3 o, float3 d, float tmin,
@@ -301,73 +317,149 @@ __device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, u
     return t > tmin && t < tmax;
 }
 
-__device__ __forceinline__ bool slab(const float* bmin, const float* bmax, float3 o, float3 inv, float tmin, float tmax,
-                                     float& tnear)
+// Entry distance of the ray into box k of a BVH4 node, as an ordered uint key (misses = 0xffffffff).
+// One fma per plane: t = plane * (1/d) - o/d.  fminf/fmaxf drop NaNs (inf - inf for axis-parallel rays), which
+// only makes the interval more conservative; hits themselves are decided by the triangle test.
+__device__ __forceinline__ uint32_t slab_key(float lox, float loy, float loz, float hix, float hiy, float hiz, float3 inv, float3 oinv,
+                                             float tmin, float tmax, uint32_t slot)
 {
-    const float ax = (bmin[0] - o.x) * inv.x, bx = (bmax[0] - o.x) * inv.x;
-    const float ay = (bmin[1] - o.y) * inv.y, by = (bmax[1] - o.y) * inv.y;
-    const float az = (bmin[2] - o.z) * inv.z, bz = (bmax[2] - o.z) * inv.z;
-    // fminf/fmaxf drop NaNs (0 * inf): the interval then stays conservative
+    const float ax = fmaf(lox, inv.x, -oinv.x), bx = fmaf(hix, inv.x, -oinv.x);
+    const float ay = fmaf(loy, inv.y, -oinv.y), by = fmaf(hiy, inv.y, -oinv.y);
+    const float az = fmaf(loz, inv.z, -oinv.z), bz = fmaf(hiz, inv.z, -oinv.z);
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    tnear = t0;
-    return t0 <= t1;
+    // t0 >= tmin >= 0: its bit pattern orders like an unsigned integer; the low 2 bits carry the slot
+    return (t0 <= t1) ? ((__float_as_uint(t0) & ~3u) | slot) : 0xffffffffu;
 }
 
-// Closest-hit (any_hit = false) or first-hit (any_hit = true) traversal.  `stack` is this lane's column of
-// an LDS array [kStackDepth][64].
-__device__ bool traverse(const SceneView& S, float3 o, float3 d, float tmin, float tmax, bool any_hit, int* stack, Hit& hit)
+__device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b)
+{
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+struct TravStack {
+    int* lds;                 // this lane's column of an LDS array [kLdsStack][64]
+    int spill[kSpillStack];
+    int sp = 0;
+    __device__ __forceinline__ void push(int v)
+    {
+        if (sp < kLdsStack)
+            lds[64 * sp] = v;
+        else if (sp < kLdsStack + kSpillStack)
+            spill[sp - kLdsStack] = v;
+        else
+            return; // deeper than 64 pending nodes: drop (cannot happen for a BVH4 over 64-bit Morton keys)
+        sp++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        sp--;
+        return sp < kLdsStack ? lds[64 * sp] : spill[sp - kLdsStack];
+    }
+};
+
+// Closest-hit (ANY_HIT = false) or first-hit (ANY_HIT = true) traversal of the BVH4.
+// A step handles an inner node and then, if the lane lands on a leaf, the leaf in the same iteration
+// (if-if), so lanes in the node phase and lanes in the leaf phase of a wave do not serialise two memory
+// round trips per iteration.  Shadow rays skip the front-to-back ordering of the children.
+constexpr int kTravDone = (int)0x80000000;
+
+template <bool ANY_HIT>
+__device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit)
 {
     hit.t = tmax;
     hit.tri = ~0u;
+    hit.node_visits = hit.tri_tests = 0;
     if (S.n_tris == 0)
         return false;
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     bool found = false;
-    int sp = 0;
+    TravStack st;
+    st.lds = lds_stack;
     int node = S.root;
-    while (true) {
+    while (node != kTravDone) {
         if (node >= 0) {
-            const BvhNode n = S.nodes[node];
-            float t0, t1;
-            const bool h0 = slab(n.c0min, n.c0max, o, inv, tmin, hit.t, t0);
-            const bool h1 = slab(n.c1min, n.c1max, o, inv, tmin, hit.t, t1);
-            if (h0 && h1) {
-                const bool near0 = t0 <= t1;
-                node = near0 ? n.c0 : n.c1;
-                if (sp < kStackDepth) { // a full stack drops the far child rather than run past the LDS column
-                    stack[64 * sp] = near0 ? n.c1 : n.c0;
-                    sp++;
+            hit.node_visits++;
+            const Bvh4Node* n = S.nodes + node;
+            const float4 lox = n->lox, loy = n->loy, loz = n->loz, hix = n->hix, hiy = n->hiy, hiz = n->hiz;
+            const int4 ch = n->child;
+            uint32_t k0 = slab_key(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, inv, oinv, tmin, hit.t, 0u);
+            uint32_t k1 = slab_key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, inv, oinv, tmin, hit.t, 1u);
+            uint32_t k2 = slab_key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, inv, oinv, tmin, hit.t, 2u);
+            uint32_t k3 = slab_key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, inv, oinv, tmin, hit.t, 3u);
+            if (!ANY_HIT) { // sorting network: k0 <= k1 <= k2 <= k3 (nearest first, misses last)
+                cswap(k0, k1);
+                cswap(k2, k3);
+                cswap(k0, k2);
+                cswap(k1, k3);
+                cswap(k1, k2);
+            }
+            auto child_of = [&](uint32_t key) -> int {
+                const uint32_t sl = key & 3u;
+                return sl == 0u ? ch.x : (sl == 1u ? ch.y : (sl == 2u ? ch.z : ch.w));
+            };
+            node = kTravDone;
+            if (!ANY_HIT) {
+                if (k0 != 0xffffffffu) {
+                    if (k3 != 0xffffffffu)
+                        st.push(child_of(k3));
+                    if (k2 != 0xffffffffu)
+                        st.push(child_of(k2));
+                    if (k1 != 0xffffffffu)
+                        st.push(child_of(k1));
+                    node = child_of(k0);
                 }
-                continue;
+            } else { // any order: continue with the first hit child, stack the others
+                if (k3 != 0xffffffffu)
+                    node = ch.w;
+                if (k2 != 0xffffffffu) {
+                    if (node != kTravDone)
+                        st.push(node);
+                    node = ch.z;
+                }
+                if (k1 != 0xffffffffu) {
+                    if (node != kTravDone)
+                        st.push(node);
+                    node = ch.y;
+                }
+                if (k0 != 0xffffffffu) {
+                    if (node != kTravDone)
+                        st.push(node);
+                    node = ch.x;
+                }
             }
-            if (h0) {
-                node = n.c0;
-                continue;
-            }
-            if (h1) {
-                node = n.c1;
-                continue;
-            }
-        } else {
-            const uint32_t ti = (uint32_t)~node;
-            float t, u, v;
-            if (intersect_tri(S.tris, ti, o, d, tmin, hit.t, t, u, v)) {
-                hit.t = t;
-                hit.u = u;
-                hit.v = v;
-                hit.tri = ti;
-                found = true;
-                if (any_hit)
-                    return true;
-            }
+            if (node == kTravDone && st.sp)
+                node = st.pop();
         }
-        if (sp == 0)
-            break;
-        sp--;
-        node = stack[64 * sp];
+        if (node < 0 && node != kTravDone) {
+            const uint32_t code = (uint32_t)~node;
+            const uint32_t first = code >> 2, count = (code & 3u) + 1u;
+            hit.tri_tests += count;
+            for (uint32_t k = 0; k < count; ++k) {
+                float t, u, v;
+                if (intersect_tri(S.tris, first + k, o, d, tmin, hit.t, t, u, v)) {
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit.tri = first + k;
+                    found = true;
+                }
+            }
+            if (ANY_HIT && found)
+                return true;
+            node = st.sp ? st.pop() : kTravDone;
+        }
     }
     return found;
+}
+
+__device__ __forceinline__ bool traverse(const SceneView& S, float3 o, float3 d, float tmin, float tmax, bool any_hit, int* lds_stack,
+                                         Hit& hit)
+{
+    return any_hit ? traverse_t<true>(S, o, d, tmin, tmax, lds_stack, hit) : traverse_t<false>(S, o, d, tmin, tmax, lds_stack, hit);
 }
 
 // SampleLevel(linear, wrap, mip 0) of an RGBA8 UNORM texture (pathtracer.hlsl:359,377,390).
@@ -455,110 +547,213 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t prim, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// GI kernel: one wave per 8x8 pixel tile
+// GI as three wavefront stages per sample (one wave per 8x8 pixel tile, records indexed by pixel):
+//   gi_raygen_trace_kernel : G-buffer -> RNG -> throughput -> cosine ray -> closest-hit traversal
+//   gi_shade_kernel        : miss -> sky; hit -> ReconstructSurfaceData, sun-disk shadow ray + BRDF contribution
+//   gi_shadow_trace_kernel : any-hit traversal of the shadow ray, accumulate; last sample adds into radiance[cur]
+// Splitting keeps the two traversal kernels at 60-66 VGPRs (7-8 waves/SIMD) and the register-hungry shading
+// away from them.
 // ------------------------------------------------------------------------------------------------
+struct GiRecords {
+    float4* ray_o;   // {origin.xyz, tmin}      (bounce ray, then overwritten by the shadow ray)
+    float4* ray_d;   // {direction.xyz, valid}  valid = 1: trace it
+    float4* hit;     // {t (<0 miss), u, v, tri bits}
+    float4* path;    // {throughput.xyz, rng bits}
+    float4* contrib; // {BRDF * sunRadiance * throughput, -}
+    float4* state;   // {V.xyz, rng bits}: survives across the samples of a pixel
+    float4* sum;     // {sum of the samples' radiance, -}
+};
+
 struct GiArgs {
     SceneView S;
     neb_gi_constants c;
+    GiRecords R;
     const uint32_t* albedo;
     const uint32_t* rough_metal; // 2 x fp16
     const uint2* world_pos;      // 4 x fp16
     const uint2* normal;         // 4 x fp16 (.zw = shading normal)
     float4* radiance;
     neb_gi_hit* hits;            // may be null
-    unsigned long long* ray_counter;
+    unsigned long long* ray_counter; // diagnostics: [1..4] traversal steps (only touched when stats != 0)
+    uint32_t* bounce_counts;     // per-workgroup bounce-ray counts
+    uint32_t* shadow_counts;     // per-workgroup shadow-ray counts
     uint32_t W, row_begin, row0, row1, tiles_x;
+    uint32_t sample;             // index of the sample this launch handles
+    uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
 };
 
-__global__ __launch_bounds__(64) void gi_trace_kernel(GiArgs a)
+__device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
 {
-    __shared__ int stack_mem[kStackDepth * 64];
     const uint32_t lane = threadIdx.x;
-    int* stack = stack_mem + lane;
     const uint32_t tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
-    const uint32_t x = tile_x * 8 + (lane & 7), y = a.row0 + tile_y * 8 + (lane >> 3);
-    const bool active = x < a.W && y < a.row1;
+    x = tile_x * 8 + (lane & 7);
+    y = a.row0 + tile_y * 8 + (lane >> 3);
+    i = (size_t)(y - a.row_begin) * a.W + x;
+    return x < a.W && y < a.row1;
+}
+
+// Ray accounting without same-address atomics (one hot word saturates at ~90 atomics/us on MI355X, which cost
+// more than the traversal itself): every workgroup owns one slot of a per-kernel count array; the host sums them.
+__device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine)
+{
+    uint32_t total = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        total += __shfl_down(total, off);
+    if (threadIdx.x == 0 && total)
+        block_counts[blockIdx.x] += total; // slot owned by this workgroup; launches on one stream are ordered
+}
+
+__global__ __launch_bounds__(64) void gi_raygen_trace_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    uint32_t x, y;
+    size_t i;
+    const bool active = gi_pixel(a, x, y, i);
     uint32_t rays = 0;
     if (active) {
-        const size_t i = (size_t)(y - a.row_begin) * a.W + x;
-        uint32_t rng = jenkins((x + y * a.W) ^ jenkins(a.c.frameIndex)); // InitRNG, rand.hlsli:26-30
         const float3 albedo = unpack_r11g11b10(a.albedo[i]);
         const uint2 wp = a.world_pos[i];
         const float3 worldPos = f3(half_bits_to_float(wp.x & 0xffffu), half_bits_to_float(wp.x >> 16), half_bits_to_float(wp.y & 0xffffu));
         const uint32_t nzw = a.normal[i].y;
         const float3 SN = oct_unpack(half_bits_to_float(nzw & 0xffffu), half_bits_to_float(nzw >> 16));
         const float metalness = half_bits_to_float(a.rough_metal[i] >> 16);
-        const float3 cam = f3(a.c.cameraWorldPos[0], a.c.cameraWorldPos[1], a.c.cameraWorldPos[2]);
-        const float3 sky = f3(a.c.skyColor[0], a.c.skyColor[1], a.c.skyColor[2]);
-        const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
-        const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
-        float3 V = cam - worldPos; // :431 -- survives across samples, overwritten at :522 (reference behaviour)
-        float3 sum = f3(0, 0, 0);
-        neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
-        for (uint32_t s = 0; s < a.c.samplesPerPixel; ++s) {
-            (void)rand01(rng); // consumed by NrcCreatePathState (:438)
-            float3 throughput = f3(1, 1, 1);
-            float3 rad = f3(0, 0, 0);
-            const float3 F0 = specular_f0(albedo, metalness);
-            throughput = throughput * (albedo * (1.0f - metalness)); // :474
-            const float pd = 1.0f - specular_probability(saturate1(dot3(normalize3(V), SN)), F0, albedo);
-            if (rand01(rng) < pd)
-                throughput = f3(throughput.x / pd, throughput.y / pd, throughput.z / pd); // :476-479
-            const float u0 = rand01(rng), u1 = rand01(rng);
-            const float3 dir = cosine_hemisphere_aligned(u0, u1, SN);
-            const float3 org = worldPos + SN * 1e-2f; // :138
-            dbg = {-1.0f, ~0u, ~0u, 0u};
-            if (a.c.maxPathVertices > 1) {
-                Hit h;
-                rays++;
-                if (!traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack, h)) {
-                    rad = rad + sky * throughput; // :508
-                } else {
-                    const float4 ids = a.S.tris[3 * h.tri + 2];
-                    const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
-                    dbg.t = h.t;
-                    dbg.geometry = geom;
-                    dbg.primitive = prim;
-                    Surface surf;
-                    if (reconstruct_surface(a.S, prim, geom, h.u, h.v, surf)) {
-                        const float3 hitP = org + dir * h.t;
-                        V = normalize3(-dir); // :522
-                        const float a0 = rand01(rng), a1 = rand01(rng);
-                        const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
-                        const float3 L = normalize3(-sun_dir);
-                        const float3 Bv = normalize3(perpendicular(L));
-                        const float3 T = cross3(Bv, L);
-                        const float3 inc = normalize3(L + (Bv * sinf(angle) + T * cosf(angle)) * a.c.sunTanHalfAngle * dist);
-                        const bool transition = dot3(surf.GN, inc) <= 0.0f;
-                        const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
-                        Hit sh;
-                        rays++;
-                        if (!traverse(a.S, so, inc, 0.001f, kTraceMax, true, stack, sh)) {
-                            const float3 O = evaluate_direct_brdf(surf, V, L) * sun_rad;
-                            rad = rad + O * throughput; // :574
-                            dbg.flags |= 1u;
-                        }
-                    }
-                }
-            }
-            sum = sum + rad;
+        uint32_t rng;
+        float3 V;
+        if (a.sample == 0) {
+            rng = jenkins((x + y * a.W) ^ jenkins(a.c.frameIndex)); // InitRNG, rand.hlsli:26-30
+            V = f3(a.c.cameraWorldPos[0], a.c.cameraWorldPos[1], a.c.cameraWorldPos[2]) - worldPos; // :431
+        } else { // V survives across samples (overwritten at :522), and so does the RNG stream
+            const float4 st = a.R.state[i];
+            V = f3(st.x, st.y, st.z);
+            rng = __float_as_uint(st.w);
         }
+        (void)rand01(rng); // consumed by NrcCreatePathState (:438)
+        const float3 F0 = specular_f0(albedo, metalness);
+        float3 throughput = f3(1, 1, 1) * (albedo * (1.0f - metalness)); // :474
+        const float pd = 1.0f - specular_probability(saturate1(dot3(normalize3(V), SN)), F0, albedo);
+        if (rand01(rng) < pd)
+            throughput = f3(throughput.x / pd, throughput.y / pd, throughput.z / pd); // :476-479
+        const float u0 = rand01(rng), u1 = rand01(rng);
+        const float3 dir = cosine_hemisphere_aligned(u0, u1, SN);
+        const float3 org = worldPos + SN * 1e-2f; // :138
+        const bool bounce = a.c.maxPathVertices > 1; // for (bounce = 1; bounce < nrcMaxPathVertices; ...)
+        a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
+        a.R.ray_o[i] = make_float4(org.x, org.y, org.z, 0.01f);
+        a.R.ray_d[i] = make_float4(dir.x, dir.y, dir.z, bounce ? 1.0f : 0.0f);
+        a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
+        float4 h = make_float4(bounce ? -1.0f : -2.0f, 0.f, 0.f, 0.f); // -2: no bounce at all, nothing is added
+        if (bounce) {
+            Hit hit;
+            rays = 1;
+            if (traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit))
+                h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
+            if (a.stats) { // diagnostics only
+                atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
+                atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
+            }
+        }
+        a.R.hit[i] = h;
+    }
+    count_rays(a.bounce_counts, rays);
+}
+
+__global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
+{
+    uint32_t x, y;
+    size_t i;
+    const bool active = gi_pixel(a, x, y, i);
+    uint32_t rays = 0;
+    if (active) {
+        const float4 h = a.R.hit[i];
+        const float4 pth = a.R.path[i];
+        const float3 throughput = f3(pth.x, pth.y, pth.z);
+        float4 sum = (a.sample == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : a.R.sum[i];
+        float4 shadow_d = make_float4(0.f, 0.f, 0.f, 0.f); // valid = 0: no shadow ray
+        neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
+        if (h.x == -1.0f) { // miss: radiance += skyColor * throughput (:508)
+            sum.x += a.c.skyColor[0] * throughput.x;
+            sum.y += a.c.skyColor[1] * throughput.y;
+            sum.z += a.c.skyColor[2] * throughput.z;
+        } else if (h.x >= 0.0f) {
+            const uint32_t tri = __float_as_uint(h.w);
+            const float4 ids = a.S.tris[3 * tri + 2];
+            const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
+            dbg.t = h.x;
+            dbg.geometry = geom;
+            dbg.primitive = prim;
+            Surface surf;
+            if (reconstruct_surface(a.S, prim, geom, h.y, h.z, surf)) {
+                const float4 ro = a.R.ray_o[i], rd = a.R.ray_d[i];
+                const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
+                const float3 hitP = org + dir * h.x;
+                const float3 V = normalize3(-dir); // :522
+                uint32_t rng = __float_as_uint(pth.w);
+                const float a0 = rand01(rng), a1 = rand01(rng);
+                const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
+                const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
+                const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
+                const float3 L = normalize3(-sun_dir);
+                const float3 Bv = normalize3(perpendicular(L));
+                const float3 T = cross3(Bv, L);
+                const float3 inc = normalize3(L + (Bv * sinf(angle) + T * cosf(angle)) * a.c.sunTanHalfAngle * dist);
+                const bool transition = dot3(surf.GN, inc) <= 0.0f;
+                const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
+                const float3 O = evaluate_direct_brdf(surf, V, L) * sun_rad * throughput; // :573-574
+                a.R.ray_o[i] = make_float4(so.x, so.y, so.z, 0.001f);
+                shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
+                a.R.contrib[i] = make_float4(O.x, O.y, O.z, 0.f);
+                a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
+                rays = 1;
+            }
+        }
+        a.R.ray_d[i] = shadow_d;
+        a.R.sum[i] = sum;
+        if (a.hits)
+            a.hits[i] = dbg;
+    }
+    count_rays(a.shadow_counts, rays);
+}
+
+// (A persistent-wave variant with per-lane ray refill was measured and dropped: lanes of a wave finish after
+// 23 steps on average and the slowest after ~55, so the refill bookkeeping cost more than the idle lanes it
+// recovered: 1.24 ms vs 0.52 ms for the bounce rays at 1080p.)
+__global__ __launch_bounds__(64) void gi_shadow_trace_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    uint32_t x, y;
+    size_t i;
+    if (!gi_pixel(a, x, y, i))
+        return;
+    const float4 rd = a.R.ray_d[i];
+    float4 sum = a.R.sum[i];
+    if (rd.w != 0.0f) {
+        const float4 ro = a.R.ray_o[i];
+        Hit sh;
+        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh);
+        if (a.stats) { // diagnostics only
+            atomicAdd(a.ray_counter + 3, (unsigned long long)sh.node_visits);
+            atomicAdd(a.ray_counter + 4, (unsigned long long)sh.tri_tests);
+        }
+        if (!occluded) { // radiance += BRDF * sunRadiance * throughput (:571-575)
+            const float4 c = a.R.contrib[i];
+            sum.x += c.x;
+            sum.y += c.y;
+            sum.z += c.z;
+            if (a.hits)
+                a.hits[i].flags |= 1u;
+        }
+    }
+    if (a.sample + 1 == a.c.samplesPerPixel) { // stands in for NRC Resolve: radiance[cur] += mean over spp
         const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
         float4 r = a.radiance[i];
         r.x += sum.x * inv_spp;
         r.y += sum.y * inv_spp;
         r.z += sum.z * inv_spp;
         a.radiance[i] = r;
-        if (a.hits)
-            a.hits[i] = dbg;
+    } else {
+        a.R.sum[i] = sum;
     }
-    // one atomic per wave
-    uint32_t total = rays;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        total += __shfl_down(total, off);
-    if (lane == 0 && total)
-        atomicAdd(a.ray_counter, (unsigned long long)total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,7 +773,7 @@ struct GbufArgs {
 
 __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
 {
-    __shared__ int stack_mem[kStackDepth * 64];
+    __shared__ int stack_mem[kLdsStack * 64];
     const uint32_t lane = threadIdx.x;
     int* stack = stack_mem + lane;
     const uint32_t tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
@@ -972,7 +1167,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: upload", e);
     }
     void* ctr = nullptr;
-    if ((e = hipMalloc(&ctr, sizeof(unsigned long long))) != hipSuccess || (e = hipMemset(ctr, 0, sizeof(unsigned long long))) != hipSuccess) {
+    if ((e = hipMalloc(&ctr, 8 * sizeof(unsigned long long))) != hipSuccess || (e = hipMemset(ctr, 0, 8 * sizeof(unsigned long long))) != hipSuccess) {
         gi_destroy(g);
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: counter", e);
     }
@@ -1011,14 +1206,14 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8, false);
     uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8, false);
     const uint32_t n_inner = n > 1 ? n - 1 : 1;
-    BvhNode* d_nodes = (BvhNode*)dalloc((size_t)n_inner * sizeof(BvhNode), true);
+    BvhNode* d_nodes = (BvhNode*)dalloc((size_t)n_inner * sizeof(BvhNode), false);
     int2* d_children = (int2*)dalloc((size_t)n_inner * sizeof(int2), false);
     int* d_parent_inner = (int*)dalloc((size_t)n_inner * 4, false);
     int* d_parent_leaf = (int*)dalloc((size_t)n * 4, false);
     float* d_nmin = (float*)dalloc((size_t)n_inner * 12, false);
     float* d_nmax = (float*)dalloc((size_t)n_inner * 12, false);
     uint32_t* d_visit = (uint32_t*)dalloc((size_t)n_inner * 4, false);
-    void* temps[] = {d_tris12, d_keys, d_keys2, d_children, d_parent_inner, d_parent_leaf, d_nmin, d_nmax, d_visit};
+    void* temps[] = {d_tris12, d_keys, d_keys2, d_nodes, d_children, d_parent_inner, d_parent_leaf, d_nmin, d_nmax, d_visit};
     auto free_temps = [&]() {
         for (void* p : temps)
             if (p)
@@ -1062,15 +1257,140 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     }
     if (e == hipSuccess)
         e = hipStreamSynchronize(stream); // the temporaries are freed below; the build is a one-time setup step
+    // ---- collapse the binary LBVH into BVH4 nodes with leaves of up to kMaxLeafTris triangles ----
+    // (host pass over the device-built hierarchy: topology and boxes are the LBVH's; one-time setup)
+    std::vector<Bvh4Node> wide;
+    int root_code = ~0; // leaf {first 0, count 1}
+    if (e == hipSuccess && n > 1) {
+        std::vector<BvhNode> bin(n - 1);
+        e = hipMemcpy(bin.data(), d_nodes, (size_t)(n - 1) * sizeof(BvhNode), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            // triangle range of every binary inner node (LBVH subtrees cover contiguous sorted ranges)
+            std::vector<uint32_t> first(n - 1), count(n - 1);
+            {
+                std::vector<int> order; // children before parents
+                order.reserve(n - 1);
+                std::vector<int> stk{0};
+                while (!stk.empty()) {
+                    const int i = stk.back();
+                    stk.pop_back();
+                    order.push_back(i);
+                    if (bin[i].c0 >= 0)
+                        stk.push_back(bin[i].c0);
+                    if (bin[i].c1 >= 0)
+                        stk.push_back(bin[i].c1);
+                }
+                for (size_t k = order.size(); k-- > 0;) {
+                    const int i = order[k];
+                    const uint32_t f0 = bin[i].c0 >= 0 ? first[bin[i].c0] : (uint32_t)~bin[i].c0;
+                    const uint32_t n0 = bin[i].c0 >= 0 ? count[bin[i].c0] : 1u;
+                    const uint32_t f1 = bin[i].c1 >= 0 ? first[bin[i].c1] : (uint32_t)~bin[i].c1;
+                    const uint32_t n1 = bin[i].c1 >= 0 ? count[bin[i].c1] : 1u;
+                    first[i] = f0 < f1 ? f0 : f1;
+                    count[i] = n0 + n1;
+                }
+            }
+            struct Ref {
+                int id;        // binary child code: >= 0 inner, < 0 ~triangle
+                float lo[3], hi[3];
+            };
+            auto leaf_code = [&](const Ref& r) -> int {
+                const uint32_t f = r.id >= 0 ? first[r.id] : (uint32_t)~r.id;
+                const uint32_t c = r.id >= 0 ? count[r.id] : 1u;
+                return ~(int)((f << 2) | (c - 1u));
+            };
+            auto is_leaf = [&](const Ref& r) { return r.id < 0 || count[r.id] <= (uint32_t)kMaxLeafTris; };
+            auto area = [](const Ref& r) {
+                const float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
+                return dx * dy + dy * dz + dz * dx;
+            };
+            auto children_of = [&](int i, Ref* out) {
+                out[0].id = bin[i].c0;
+                out[1].id = bin[i].c1;
+                memcpy(out[0].lo, bin[i].c0min, 12);
+                memcpy(out[0].hi, bin[i].c0max, 12);
+                memcpy(out[1].lo, bin[i].c1min, 12);
+                memcpy(out[1].hi, bin[i].c1max, 12);
+            };
+            if (count[0] <= (uint32_t)kMaxLeafTris) {
+                root_code = ~(int)((0u << 2) | (count[0] - 1u));
+            } else {
+                root_code = 0;
+                // work list of (binary node, wide slot index); wide nodes are emitted in DFS order
+                std::vector<std::pair<int, int>> work{{0, 0}};
+                wide.emplace_back();
+                while (!work.empty()) {
+                    const auto [bi, wi] = work.back();
+                    work.pop_back();
+                    Ref c[4];
+                    int nc = 2;
+                    children_of(bi, c);
+                    while (nc < 4) { // open the inner child with the largest surface area
+                        int best = -1;
+                        float best_area = -1.0f;
+                        for (int k = 0; k < nc; ++k)
+                            if (!is_leaf(c[k]) && area(c[k]) > best_area) {
+                                best_area = area(c[k]);
+                                best = k;
+                            }
+                        if (best < 0)
+                            break;
+                        Ref two[2];
+                        children_of(c[best].id, two);
+                        c[best] = two[0];
+                        c[nc++] = two[1];
+                    }
+                    Bvh4Node nd;
+                    float lo[3][4], hi[3][4];
+                    int ch[4];
+                    for (int k = 0; k < 4; ++k) {
+                        if (k < nc) {
+                            for (int q = 0; q < 3; ++q) {
+                                lo[q][k] = c[k].lo[q];
+                                hi[q][k] = c[k].hi[q];
+                            }
+                            if (is_leaf(c[k])) {
+                                ch[k] = leaf_code(c[k]);
+                            } else {
+                                ch[k] = (int)wide.size();
+                                wide.emplace_back();
+                                work.push_back({c[k].id, ch[k]});
+                            }
+                        } else {
+                            for (int q = 0; q < 3; ++q) {
+                                lo[q][k] = INFINITY;
+                                hi[q][k] = -INFINITY;
+                            }
+                            ch[k] = ~0;
+                        }
+                    }
+                    nd.lox = make_float4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+                    nd.loy = make_float4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+                    nd.loz = make_float4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
+                    nd.hix = make_float4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]);
+                    nd.hiy = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
+                    nd.hiz = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
+                    nd.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+                    nd.pad = make_int4(0, 0, 0, 0);
+                    wide[wi] = nd;
+                }
+            }
+        }
+    }
+    Bvh4Node* d_wide = nullptr;
+    if (e == hipSuccess && !wide.empty()) {
+        d_wide = (Bvh4Node*)dalloc(wide.size() * sizeof(Bvh4Node), true);
+        e = d_wide ? hipMemcpy(d_wide, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice) : hipErrorOutOfMemory;
+    }
     if (d_temp)
         (void)hipFree(d_temp);
     free_temps();
     if (e != hipSuccess)
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh", e);
     g->view.tris = d_sorted;
-    g->view.nodes = d_nodes;
-    g->view.root = (n > 1) ? 0 : ~0; // single triangle: the root is leaf 0
-    g->n_nodes = (n > 1) ? n - 1 : 0;
+    g->view.nodes = d_wide;
+    g->view.root = root_code;
+    g->n_nodes = (uint32_t)wide.size();
     std::vector<float>().swap(g->h_tris);
     return NEB_OK;
 }
@@ -1107,9 +1427,22 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         g->allocs.push_back(p);
         g->d_hits = (neb_gi_hit*)p;
     }
+    if (!g->d_records) {
+        void* p = nullptr;
+        GI_HIP(ctx, hipMalloc(&p, npx * sizeof(float4) * 7));
+        g->allocs.push_back(p);
+        g->d_records = (float4*)p;
+    }
     GiArgs a;
     a.S = g->view;
     a.c = *c;
+    a.R.ray_o = g->d_records;
+    a.R.ray_d = g->d_records + npx;
+    a.R.hit = g->d_records + 2 * npx;
+    a.R.path = g->d_records + 3 * npx;
+    a.R.contrib = g->d_records + 4 * npx;
+    a.R.state = g->d_records + 5 * npx;
+    a.R.sum = g->d_records + 6 * npx;
     a.albedo = (const uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
     a.rough_metal = (const uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
     a.world_pos = (const uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
@@ -1122,8 +1455,26 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     a.row0 = row0;
     a.row1 = row1;
     a.tiles_x = (ctx->W + 7) / 8;
+    a.stats = g->debug_hits ? 1u : 0u;
     const uint32_t tiles_y = (row1 - row0 + 7) / 8;
-    hipLaunchKernelGGL(gi_trace_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
+    const dim3 grid(a.tiles_x * tiles_y), block(64);
+    const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
+    if (!g->d_block_counts) {
+        void* p = nullptr;
+        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
+        g->allocs.push_back(p);
+        g->d_block_counts = (uint32_t*)p;
+        g->n_block_counts = n_blocks;
+    }
+    a.bounce_counts = g->d_block_counts;
+    a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    for (uint32_t s = 0; s < c->samplesPerPixel; ++s) {
+        a.sample = s;
+        hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+    }
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
 }
@@ -1139,13 +1490,35 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
 {
     if (!ctx || !ctx->gi)
         return ctx ? gi_fail(ctx, NEB_ERR_STATE, "neb_gi_ray_count: no scene") : NEB_ERR_INVALID_ARG;
-    unsigned long long v = 0;
-    GI_HIP(ctx, hipMemcpyAsync(&v, ctx->gi->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GiState* g = ctx->gi;
+    unsigned long long v[8] = {};
+    std::vector<uint32_t> counts(2 * g->n_block_counts);
+    GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (g->d_block_counts)
+        GI_HIP(ctx, hipMemcpyAsync(counts.data(), g->d_block_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   (hipStream_t)stream));
     GI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-    if (reset)
-        GI_HIP(ctx, hipMemsetAsync(ctx->gi->d_ray_counter, 0, sizeof(v), (hipStream_t)stream));
+    if (reset) {
+        GI_HIP(ctx, hipMemsetAsync(g->d_ray_counter, 0, sizeof(v), (hipStream_t)stream));
+        if (g->d_block_counts)
+            GI_HIP(ctx, hipMemsetAsync(g->d_block_counts, 0, counts.size() * sizeof(uint32_t), (hipStream_t)stream));
+    }
+    unsigned long long total = 0;
+    for (uint32_t c : counts)
+        total += c;
+    v[0] = total;
     if (rays)
-        *rays = v;
+        *rays = total;
+    memcpy(g->last_stats, v, sizeof(v));
+    return NEB_OK;
+}
+
+int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5])
+{
+    if (!ctx || !ctx->gi || !out)
+        return NEB_ERR_INVALID_ARG;
+    for (int k = 0; k < 5; ++k)
+        out[k] = ctx->gi->last_stats[k];
     return NEB_OK;
 }
 

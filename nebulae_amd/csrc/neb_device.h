@@ -1,4 +1,7 @@
 // neb_device.h -- device-side helpers shared by the gfx950 kernels.
+// Every fused multiply-add is written out (fmaf): the SVGF kernels are compiled with floating-point
+// contraction off so that a pixel's result cannot depend on which unrolled copy of the code (tile slot,
+// staging slot) produced it -- the multi-GPU path promises N-strip == 1-strip bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,7 +25,7 @@ __device__ __forceinline__ uint32_t float_to_half_bits(float f)
 // svgf_common.hlsli:32-35 (ITU-R BT.709)
 __device__ __forceinline__ float luminance(float r, float g, float b)
 {
-    return r * 0.2126f + g * 0.7152f + b * 0.0722f;
+    return fmaf(b, 0.0722f, fmaf(g, 0.7152f, r * 0.2126f));
 }
 
 // Texture2D<float> view of R24_UNORM_X8_TYPELESS (SVGFDenoiser.h:162): c / (2^24 - 1).
@@ -45,7 +48,7 @@ __device__ __forceinline__ float3 oct16_unpack_zw(uint32_t packed)
         vx = (1.0f - fabsf(ey)) * sx;
         vy = (1.0f - fabsf(ex)) * sy;
     }
-    float inv = __frsqrt_rn(vx * vx + vy * vy + vz * vz);
+    float inv = __frsqrt_rn(fmaf(vz, vz, fmaf(vy, vy, vx * vx)));
     return make_float3(vx * inv, vy * inv, vz * inv);
 }
 

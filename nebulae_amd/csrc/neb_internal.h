@@ -19,6 +19,7 @@ struct SvgfLaunch {
     uint32_t row_begin;    // first resident image row: plane address of (x, y) is (y - row_begin) * W + x
     uint32_t row_end;      // one past the last resident row
     uint32_t row0, row1;   // image rows to process
+    int num_cus;           // persistent-grid sizing
     neb_svgf_params p;
 };
 
@@ -38,6 +39,7 @@ int gi_set_debug_hits(neb_ctx* ctx, int on);
 
 struct neb_ctx {
     int device = 0;
+    int num_cus = 256; // hipDeviceProp_t::multiProcessorCount (persistent-grid sizing)
     uint32_t W = 0, H = 0, row_begin = 0, row_end = 0, levels = 4;
     void* planes[NEB_PLANE_COUNT][2] = {};
     int cur = 0, hist = 1;

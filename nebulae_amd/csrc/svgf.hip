@@ -9,6 +9,10 @@
 // image-row segments whatever the step, staged once into LDS with depth and normals already
 // decoded, and each lane filters a column of R lattice rows so every staged texel is
 // read from LDS once per R outputs.  See DESIGN.md "Kernels".
+#pragma clang fp contract(off) // fused operations are explicit fmaf: see neb_device.h
+
+#include <algorithm>
+
 #include "neb_device.h"
 #include "neb_internal.h"
 
@@ -52,21 +56,21 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     // SVGF_DWeight: exp(-dz^2 / (2 sigma^2))   (svgf_common.hlsli:11-15)
     const float wDepth = fast_exp2(dz * dz * a.neg_inv_two_sigma2_log2e);
     // SVGF_NWeight: saturate(dot)               (svgf_common.hlsli:4-7)
-    const float wNormal = __saturatef(Nc.x * Nh.x + Nc.y * Nh.y + Nc.z * Nh.z);
+    const float wNormal = __saturatef(fmaf(Nc.z, Nh.z, fmaf(Nc.y, Nh.y, Nc.x * Nh.x)));
     const float w = wDepth * wNormal;
-    const float alpha = 1.0f + w * (a.alpha - 1.0f); // lerp(1, alpha, w)  (:51)
+    const float alpha = fmaf(w, a.alpha - 1.0f, 1.0f); // lerp(1, alpha, w)  (:51)
 
     const float Y = luminance(Cc.x, Cc.y, Cc.z);
     const float Mh0 = half_bits_to_float(mh & 0xffffu), Mh1 = half_bits_to_float(mh >> 16);
-    const float M1 = Y + alpha * (Mh0 - Y);
+    const float M1 = fmaf(alpha, Mh0 - Y, Y);
     const float Y2 = Y * Y;
-    const float M2 = Y2 + alpha * (Mh1 - Y2);
-    const float var = fmaxf(M2 - M1 * M1, a.varianceEps);
+    const float M2 = fmaf(alpha, Mh1 - Y2, Y2);
+    const float var = fmaxf(fmaf(-M1, M1, M2), a.varianceEps);
 
     float4 out;
-    out.x = Cc.x + alpha * (Ch.x - Cc.x);
-    out.y = Cc.y + alpha * (Ch.y - Cc.y);
-    out.z = Cc.z + alpha * (Ch.z - Cc.z);
+    out.x = fmaf(alpha, Ch.x - Cc.x, Cc.x);
+    out.y = fmaf(alpha, Ch.y - Cc.y, Cc.y);
+    out.z = fmaf(alpha, Ch.z - Cc.z, Cc.z);
     out.w = Cc.w;
     a.rad_cur[i] = out;
     a.mom_cur[i] = float_to_half_bits(M1) | (float_to_half_bits(M2) << 16);
@@ -130,12 +134,24 @@ __host__ __device__ constexpr float atrous_k(int d)
     return (d < 0 ? -d : d) == 0 ? 0.0625f : ((d < 0 ? -d : d) == 1 ? 0.25f : 0.375f);
 }
 
-// exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) evaluated as one
-// exp2: exponent = phiNormal*log2(d) - |dz|*cz - |dl|*cl (d == 0 -> log2 = -inf -> weight 0).
-__device__ __forceinline__ float edge_weight(float d, float adz, float adl, float cz, float cl, float phiN)
+// log2(K[abs(dx)] * K[abs(dy)]): the kernel weight folded into the exponent of the edge-stopping exp2
+__host__ __device__ constexpr float atrous_log2k(int dx, int dy)
 {
-    const float e = fmaf(phiN, fast_log2(fmaxf(d, 0.0f)), -(adz * cz)) - adl * cl;
-    return fast_exp2(e);
+    // log2(1/16) = -4, log2(1/4) = -2, log2(3/8) = log2(3) - 3
+    const float lx = (dx < 0 ? -dx : dx) == 0 ? -4.0f : ((dx < 0 ? -dx : dx) == 1 ? -2.0f : -1.4150374992788437f);
+    const float ly = (dy < 0 ? -dy : dy) == 0 ? -4.0f : ((dy < 0 ? -dy : dy) == 1 ? -2.0f : -1.4150374992788437f);
+    return lx + ly;
+}
+
+// exact c / (2^24 - 1): q = c*r, then one Newton step on the remainder (differs from the correctly rounded
+// quotient on 24 of the 2^24 codes, by one ulp)
+__device__ __forceinline__ float depth_unorm24_fast(uint32_t d)
+{
+    const float c = (float)(d & 0xffffffu);
+    const float r = 1.0f / 16777215.0f;
+    const float q = c * r;
+    const float rem = fmaf(-q, 16777215.0f, c);
+    return fmaf(rem, r, q);
 }
 
 __device__ __forceinline__ float lum_scale(float var_f, float phiColor)
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
     const float4 c0 = a.src[i];
     const float lum0 = luminance(c0.x, c0.y, c0.z);
     const float cl = lum_scale(half_bits_to_float(a.variance[i]), a.phiColor);
-    const float z0 = depth_unorm24(a.depth[i]);
+    const float z0 = depth_unorm24_fast(a.depth[i]);
     const float3 n0 = oct16_unpack_zw(a.normal[i].y);
     float sr = 0.f, sg = 0.f, sb = 0.f, sw = 0.f;
 #pragma unroll
@@ -167,15 +183,17 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
         for (int dx = -2; dx <= 2; ++dx) {
             const int qx = min(max(x + dx * a.step, 0), a.W - 1);
             const float4 c = a.src[rowoff + qx];
-            const float z = depth_unorm24(a.depth[rowoff + qx]);
+            const float z = depth_unorm24_fast(a.depth[rowoff + qx]);
             const float3 n = oct16_unpack_zw(a.normal[rowoff + qx].y);
             const float lum = luminance(c.x, c.y, c.z);
-            const float d = n0.x * n.x + n0.y * n.y + n0.z * n.z;
-            const float w = (atrous_k(dx) * atrous_k(dy)) *
-                            edge_weight(d, fabsf(z0 - z), fabsf(lum0 - lum), a.cz, cl, a.phiNormal);
-            sr += w * c.x;
-            sg += w * c.y;
-            sb += w * c.z;
+            const float d = fmaxf(fmaf(n0.z, n.z, fmaf(n0.y, n.y, n0.x * n.x)), 0.0f);
+            float e = fmaf(a.phiNormal, fast_log2(d), atrous_log2k(dx, dy));
+            e = fmaf(-fabsf(z0 - z), a.cz, e);
+            e = fmaf(-fabsf(lum0 - lum), cl, e);
+            const float w = fast_exp2(e);
+            sr = fmaf(w, c.x, sr);
+            sg = fmaf(w, c.y, sg);
+            sb = fmaf(w, c.z, sb);
             sw += w;
         }
     }
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
     a.dst[i] = make_float4(sr * inv, sg * inv, sb * inv, c0.w);
 }
 
-// Variant 1: LDS row-lattice tile.
+// Variant 1: LDS row-lattice tile, persistent workgroups with register prefetch.
 //   Workgroup = 256 lanes = 4 waves.  Output tile = BW (64) consecutive columns x BH (= 4R)
 //   rows of the lattice {r + S*j}.  Taps of a lattice row are lattice rows j-2..j+2, so the
 //   tile needs only BH+4 image rows (each a contiguous, coalesced segment of BW+4S texels)
@@ -192,129 +210,196 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
 //   keeps {r,g,b,z} and {nx,ny,nz,lum} as two float4 LDS planes (ds_read_b128, lane-contiguous,
 //   conflict-free).  Wave w filters lattice rows [w*R, w*R+R): a lane walks its column's R+4
 //   staged rows once and feeds each staged texel to every output row it is a tap of.
+//   Each workgroup walks several tiles: the global loads of the NEXT tile are issued into
+//   registers before the current tile is filtered, so their latency hides under ~1.6k VALU
+//   instructions per wave instead of stalling an empty SIMD (the first version spent 36 % of
+//   wave time in s_waitcnt).
 template <int S, int R>
-__global__ __launch_bounds__(256, 4) void svgf_atrous_lds_kernel(AtrousArgs a)
+struct AtrousTile {
+    static constexpr int BW = 64, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4, TOTAL = ROWS * COLS;
+    static constexpr int NLOAD = (TOTAL + 255) / 256;
+};
+
+template <int S, int R>
+__global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(AtrousArgs a)
 {
-    constexpr int BW = 64, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4;
+    using T = AtrousTile<S, R>;
+    constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD;
     extern __shared__ float4 lds[];
     float4* __restrict__ A = lds;               // {r, g, b, z}
     float4* __restrict__ B = lds + ROWS * COLS; // {nx, ny, nz, lum}
 
-    // XCD-aware tile order: workgroups b, b+8, ... share an XCD (and its L2), so give each XCD a
-    // contiguous run of tiles (neighbouring tiles share halo columns/rows).  Speed only.
-    const uint32_t chunk = gridDim.x >> 3;
-    const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-    if (t >= a.nblocks)
-        return;
-    const int tx_tile = (int)(t % (uint32_t)a.tiles_x);
-    const int rest = (int)(t / (uint32_t)a.tiles_x);
-    const int r = rest % S;     // residue class of the lattice rows
-    const int jt = rest / S;    // tile index along the lattice
-    // first lattice index of the residue class inside [row0, row1)
-    const int jmin = (a.row0 - r + S - 1) / S > 0 ? (a.row0 - r + S - 1) / S : 0;
-    const int jbase = jmin + jt * BH;
-    const int x0 = tx_tile * BW;
-    if (r + S * jbase >= a.row1)
-        return; // whole tile below the row range (uniform for the workgroup)
-
     const float4* __restrict__ src = a.src;
     const uint32_t* __restrict__ depth = a.depth;
     const uint32_t* __restrict__ normal32 = reinterpret_cast<const uint32_t*>(a.normal);
-
-    // ---- stage (BH+4) x (BW+4S) texels, clamped to the image (svgf_atrous.hlsl:65) ----
-    constexpr int TOTAL = ROWS * COLS;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < TOTAL; i += 256) {
-        const int lr = i / COLS, lc = i - lr * COLS;
-        // clamp to the image (the reference's edge rule), then to the resident rows: a partial tile
-        // also stages rows that no valid output taps; on a row strip those may lie outside the
-        // allocation, so they are redirected to a resident row (their values are never used)
-        int y = min(max(r + S * (jbase + lr - 2), 0), a.H - 1);
-        y = min(max(y, a.row_begin), a.row_end - 1);
-        const int x = min(max(x0 - 2 * S + lc, 0), a.W - 1);
-        const size_t q = (size_t)(y - a.row_begin) * a.W + x;
-        const float4 c = src[q];
-        const uint32_t d = depth[q];
-        const uint32_t nzw = normal32[2 * q + 1];
-        const float3 n = oct16_unpack_zw(nzw);
-        A[i] = make_float4(c.x, c.y, c.z, depth_unorm24(d));
-        B[i] = make_float4(n.x, n.y, n.z, luminance(c.x, c.y, c.z));
-    }
-    __syncthreads();
-
-    // ---- filter ----
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int xo = x0 + lane;
-    float z0[R], n0x[R], n0y[R], n0z[R], lum0[R], cl[R], alpha0[R];
-    float sr[R], sg[R], sb[R], sw[R];
-    bool valid[R];
+
+    // Tile walk, XCD-aware: workgroups b, b+8, ... share an XCD (and its L2); each XCD takes a contiguous
+    // run of tiles, and the workgroups of an XCD interleave inside that run.  Speed only.
+    const uint32_t per_xcd = (a.nblocks + 7u) >> 3;
+    const uint32_t xcd = blockIdx.x & 7u, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    const uint32_t t_end = min((xcd + 1u) * per_xcd, a.nblocks);
+
+    // staged-texel coordinates of this lane inside a tile: the same for every tile
+    int lrow[NLOAD], lcol[NLOAD];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int lr = wv * R + k + 2;
-        const float4 cA = A[lr * COLS + lane + 2 * S];
-        const float4 cB = B[lr * COLS + lane + 2 * S];
-        z0[k] = cA.w;
-        n0x[k] = cB.x;
-        n0y[k] = cB.y;
-        n0z[k] = cB.z;
-        lum0[k] = cB.w;
-        const int yo = r + S * (jbase + wv * R + k);
-        valid[k] = (xo < a.Wd) && (yo < a.row1);
-        float var_f = 0.f;
-        alpha0[k] = 0.f;
-        if (valid[k]) {
-            const size_t i = (size_t)(yo - a.row_begin) * a.W + xo;
-            var_f = half_bits_to_float(a.variance[i]);
-            alpha0[k] = reinterpret_cast<const float*>(src)[4 * i + 3];
-        }
-        cl[k] = lum_scale(var_f, a.phiColor);
-        sr[k] = sg[k] = sb[k] = sw[k] = 0.f;
+    for (int k = 0; k < NLOAD; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        lrow[k] = i / COLS;
+        lcol[k] = i - lrow[k] * COLS;
     }
-    const float cz = a.cz, phiN = a.phiNormal;
+    float4 pc[NLOAD];
+    uint32_t pd[NLOAD], pn[NLOAD];
+
+    auto tile_origin = [&](uint32_t t, int& r, int& jbase, int& x0) -> bool {
+        const int tx_tile = (int)(t % (uint32_t)a.tiles_x);
+        const int rest = (int)(t / (uint32_t)a.tiles_x);
+        r = rest % S;               // residue class of the lattice rows
+        const int jt = rest / S;    // tile index along the lattice
+        const int jmin = (a.row0 - r + S - 1) / S > 0 ? (a.row0 - r + S - 1) / S : 0; // first lattice index inside [row0,row1)
+        jbase = jmin + jt * BH;
+        x0 = tx_tile * BW;
+        return r + S * jbase < a.row1; // false: whole tile below the row range
+    };
+    auto issue_load = [&](int k, int r, int jbase, int x0) {
+        if (threadIdx.x + 256 * k < TOTAL) {
+            // clamp to the image (the reference's edge rule, svgf_atrous.hlsl:65), then to the resident rows:
+            // a partial tile also stages rows that no valid output taps; on a row strip those may lie
+            // outside the allocation, so they are redirected to a resident row (their values are never used)
+            int y = min(max(r + S * (jbase + lrow[k] - 2), 0), a.H - 1);
+            y = min(max(y, a.row_begin), a.row_end - 1);
+            const int x = min(max(x0 - 2 * S + lcol[k], 0), a.W - 1);
+            const size_t q = (size_t)(y - a.row_begin) * a.W + x;
+            pc[k] = src[q];
+            pd[k] = depth[q];
+            pn[k] = normal32[2 * q + 1];
+        }
+    };
+    auto issue_loads = [&](int r, int jbase, int x0) {
 #pragma unroll
-    for (int ir = 0; ir < R + 4; ++ir) {
-        const int lrow = (wv * R + ir) * COLS + lane + 2 * S;
+        for (int k = 0; k < NLOAD; ++k)
+            issue_load(k, r, jbase, x0);
+    };
+
+    uint32_t t = xcd * per_xcd + wg_in_xcd;
+    int r = 0, jbase = 0, x0 = 0;
+    bool have = false;
+    while (t < t_end && !(have = tile_origin(t, r, jbase, x0)))
+        t += wgs_per_xcd;
+    if (have)
+        issue_loads(r, jbase, x0);
+
+    while (have) {
+        // ---- decode the prefetched texels into LDS ----
 #pragma unroll
-        for (int dx = -2; dx <= 2; ++dx) {
-            const float4 tA = A[lrow + dx * S];
-            const float4 tB = B[lrow + dx * S];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int dy = ir - k - 2;
-                if (dy < -2 || dy > 2)
-                    continue;
-                const float d = n0x[k] * tB.x + n0y[k] * tB.y + n0z[k] * tB.z;
-                const float w = (atrous_k(dx) * atrous_k(dy)) *
-                                edge_weight(d, fabsf(z0[k] - tA.w), fabsf(lum0[k] - tB.w), cz, cl[k], phiN);
-                sr[k] = fmaf(w, tA.x, sr[k]);
-                sg[k] = fmaf(w, tA.y, sg[k]);
-                sb[k] = fmaf(w, tA.z, sb[k]);
-                sw[k] += w;
+        for (int k = 0; k < NLOAD; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < TOTAL) {
+                const float3 n = oct16_unpack_zw(pn[k]);
+                A[i] = make_float4(pc[k].x, pc[k].y, pc[k].z, depth_unorm24_fast(pd[k]));
+                B[i] = make_float4(n.x, n.y, n.z, luminance(pc[k].x, pc[k].y, pc[k].z));
             }
         }
-        // Pin the partial sums here: they only feed the predicated store below, so LLVM would
-        // otherwise sink ALL the arithmetic under that branch and keep every staged texel live
-        // (spilling ~1.3 KB per lane).  The sched_barrier keeps one row's ds_reads per region.
+        __syncthreads();
+
+        // ---- next tile: issue its loads now, consume them after this tile is filtered ----
+        const int cr = r, cjbase = jbase, cx0 = x0;
+        bool have_next = false;
+        t += wgs_per_xcd;
+        while (t < t_end && !(have_next = tile_origin(t, r, jbase, x0)))
+            t += wgs_per_xcd;
+        // The next tile's loads are spread over the row iterations of the filter below (one batch per row) so
+        // that, chip-wide, memory traffic and arithmetic overlap instead of alternating in bursts; batches
+        // beyond the R+4 row iterations go out first.
+        if (have_next) {
 #pragma unroll
-        for (int k = 0; k < R; ++k)
-            asm volatile("" : "+v"(sr[k]), "+v"(sg[k]), "+v"(sb[k]), "+v"(sw[k]));
-        __builtin_amdgcn_sched_barrier(0);
-    }
+            for (int k = R + 4; k < NLOAD; ++k)
+                issue_load(k, r, jbase, x0);
+        }
+
+        // ---- filter the current tile ----
+        const int xo = cx0 + lane;
+        float z0[R], n0x[R], n0y[R], n0z[R], lum0[R], cl[R], alpha0[R];
+        float sr[R], sg[R], sb[R], sw[R];
+        bool valid[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        if (!valid[k])
-            continue;
-        const int yo = r + S * (jbase + wv * R + k);
-        const float inv = fast_rcp(fmaxf(sw[k], 1e-4f)); // :84
-        a.dst[(size_t)(yo - a.row_begin) * a.W + xo] = make_float4(sr[k] * inv, sg[k] * inv, sb[k] * inv, alpha0[k]);
+        for (int k = 0; k < R; ++k) {
+            const int lr = wv * R + k + 2;
+            const float4 cA = A[lr * COLS + lane + 2 * S];
+            const float4 cB = B[lr * COLS + lane + 2 * S];
+            z0[k] = cA.w;
+            n0x[k] = cB.x;
+            n0y[k] = cB.y;
+            n0z[k] = cB.z;
+            lum0[k] = cB.w;
+            const int yo = cr + S * (cjbase + wv * R + k);
+            valid[k] = (xo < a.Wd) && (yo < a.row1);
+            float var_f = 0.f;
+            alpha0[k] = 0.f;
+            if (valid[k]) {
+                const size_t i = (size_t)(yo - a.row_begin) * a.W + xo;
+                var_f = half_bits_to_float(a.variance[i]);
+                alpha0[k] = reinterpret_cast<const float*>(src)[4 * i + 3];
+            }
+            cl[k] = lum_scale(var_f, a.phiColor);
+            sr[k] = sg[k] = sb[k] = sw[k] = 0.f;
+        }
+        const float cz = a.cz, phiN = a.phiNormal;
+#pragma unroll
+        for (int ir = 0; ir < R + 4; ++ir) {
+            if (ir < NLOAD && have_next)
+                issue_load(ir, r, jbase, x0);
+            const int lrow_base = (wv * R + ir) * COLS + lane + 2 * S;
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const float4 tA = A[lrow_base + dx * S];
+                const float4 tB = B[lrow_base + dx * S];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int dy = ir - k - 2;
+                    if (dy < -2 || dy > 2)
+                        continue;
+                    // w = Kx*Ky * exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) as ONE exp2:
+                    // exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d == 0 -> -inf -> weight 0)
+                    const float lk = atrous_log2k(dx, dy);
+                    const float d = fmaxf(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)), 0.0f);
+                    float e = fmaf(phiN, fast_log2(d), lk);
+                    e = fmaf(-fabsf(z0[k] - tA.w), cz, e);
+                    e = fmaf(-fabsf(lum0[k] - tB.w), cl[k], e);
+                    const float w = fast_exp2(e);
+                    sr[k] = fmaf(w, tA.x, sr[k]);
+                    sg[k] = fmaf(w, tA.y, sg[k]);
+                    sb[k] = fmaf(w, tA.z, sb[k]);
+                    sw[k] += w;
+                }
+            }
+            // Pin the partial sums here: they only feed the predicated store below, so LLVM would
+            // otherwise sink ALL the arithmetic under that branch and keep every staged texel live
+            // (spilling ~1.3 KB per lane).  The sched_barrier keeps one row's ds_reads per region.
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                asm volatile("" : "+v"(sr[k]), "+v"(sg[k]), "+v"(sb[k]), "+v"(sw[k]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (!valid[k])
+                continue;
+            const int yo = cr + S * (cjbase + wv * R + k);
+            const float inv = fast_rcp(fmaxf(sw[k], 1e-4f)); // :84
+            a.dst[(size_t)(yo - a.row_begin) * a.W + xo] = make_float4(sr[k] * inv, sg[k] * inv, sb[k] * inv, alpha0[k]);
+        }
+        have = have_next;
+        if (have)
+            __syncthreads(); // everyone is done reading LDS before the next tile overwrites it
     }
 }
 
 template <int S, int R>
-static hipError_t launch_lds(AtrousArgs a, hipStream_t s)
+static hipError_t launch_lds(AtrousArgs a, int num_cus, hipStream_t s)
 {
-    constexpr int BW = 64, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4;
-    constexpr size_t lds_bytes = (size_t)ROWS * COLS * 2 * sizeof(float4);
+    using T = AtrousTile<S, R>;
+    constexpr size_t lds_bytes = (size_t)T::TOTAL * 2 * sizeof(float4);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&svgf_atrous_lds_kernel<S, R>),
@@ -323,11 +408,16 @@ static hipError_t launch_lds(AtrousArgs a, hipStream_t s)
             return e;
         attr_set = true;
     }
-    a.tiles_x = (a.Wd + BW - 1) / BW;
+    a.tiles_x = (a.Wd + T::BW - 1) / T::BW;
     const int max_lattice_rows = (a.row1 - a.row0 + S - 1) / S; // per residue class, upper bound
-    a.tiles_j = (max_lattice_rows + BH - 1) / BH;
+    a.tiles_j = (max_lattice_rows + T::BH - 1) / T::BH;
     a.nblocks = (uint32_t)a.tiles_x * (uint32_t)S * (uint32_t)a.tiles_j;
-    const uint32_t grid = ((a.nblocks + 7u) / 8u) * 8u;
+    // persistent grid: as many workgroups as fit (LDS-limited, at most 3 per CU by the launch bounds)
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(R <= 2 ? 5 : 3, (160u * 1024u) / lds_bytes);
+    uint32_t grid = (uint32_t)num_cus * (per_cu ? per_cu : 1u);
+    if (grid > a.nblocks)
+        grid = a.nblocks;
+    grid = ((grid + 7u) / 8u) * 8u;
     hipLaunchKernelGGL((svgf_atrous_lds_kernel<S, R>), dim3(grid), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
@@ -335,6 +425,7 @@ static hipError_t launch_lds(AtrousArgs a, hipStream_t s)
 hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
                          const uint16_t* variance, const uint32_t* depth, const uint2* normal, hipStream_t s)
 {
+    const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
     const uint32_t Wd = (L.W / 8u) * 8u, Hd = (L.H / 8u) * 8u; // SVGFDenoiser.cpp:185
     const uint32_t row1 = L.row1 < Hd ? L.row1 : Hd;
     if (L.row0 >= row1 || Wd == 0)
@@ -358,14 +449,16 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
     a.cz = kLog2e / (L.p.phiDepth * (float)step);
     a.phiColor = L.p.phiColor;
     a.phiNormal = L.p.phiNormal;
-    if (variant == 1) {
+    // variant 1 (default): R = 4 rows per lane for steps <= 4, R = 2 (smaller LDS tile, 5 waves/SIMD) for steps >= 8,
+    // as measured; 2 / 3 force R = 2 / R = 4 everywhere (A/B arms)
+    if (variant >= 1) {
         switch (step) {
-        case 1: return launch_lds<1, 4>(a, s);
-        case 2: return launch_lds<2, 4>(a, s);
-        case 4: return launch_lds<4, 4>(a, s);
-        case 8: return launch_lds<8, 4>(a, s);
-        case 16: return launch_lds<16, 4>(a, s);
-        case 32: return launch_lds<32, 4>(a, s);
+        case 1: return (variant == 2) ? launch_lds<1, 2>(a, num_cus, s) : launch_lds<1, 4>(a, num_cus, s);
+        case 2: return (variant == 2) ? launch_lds<2, 2>(a, num_cus, s) : launch_lds<2, 4>(a, num_cus, s);
+        case 4: return (variant == 2) ? launch_lds<4, 2>(a, num_cus, s) : launch_lds<4, 4>(a, num_cus, s);
+        case 8: return (variant == 3) ? launch_lds<8, 4>(a, num_cus, s) : launch_lds<8, 2>(a, num_cus, s);
+        case 16: return (variant == 3) ? launch_lds<16, 4>(a, num_cus, s) : launch_lds<16, 2>(a, num_cus, s);
+        case 32: return (variant == 3) ? launch_lds<32, 4>(a, num_cus, s) : launch_lds<32, 2>(a, num_cus, s);
         default: break; // wider steps do not fit the LDS tile: direct kernel
         }
     }

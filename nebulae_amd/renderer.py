@@ -150,6 +150,13 @@ class DeferredRenderer:
                     "neb_gi_ray_count")
         return v.value
 
+    def traversal_stats(self):
+        """{rays, node visits and triangle tests of the bounce rays (+ shadow rays while debug hits are on)} as of the
+        last ray_count() call."""
+        v = (C.c_uint64 * 5)()
+        self._check(self._lib.neb_gi_traversal_stats(self._ctx, v), "neb_gi_traversal_stats")
+        return dict(zip(("rays", "bounce_nodes", "bounce_tris", "shadow_nodes", "shadow_tris"), [int(x) for x in v]))
+
     def set_debug_hits(self, on=True):
         self.svgf.set_option("gi_debug_hits", int(on))
 

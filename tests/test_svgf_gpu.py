@@ -40,7 +40,7 @@ def feed(d, o, f, g, rad):
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=lambda p: p.split("/")[-1])
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 2, 3])
 def test_frames_match_golden(path, variant):
     z, W, H, L, frames, shift = load_golden(path)
     d = make(W, H, L)
