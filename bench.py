@@ -3,8 +3,8 @@
 
 One "step" = one frame of the hot path on device-resident inputs, in the order of
 Renderer::RenderSceneDeferred (/root/reference/src/Renderer.cpp:123-133): radiance[cur] <- the
-direct-light term (device-to-device copy of a resident plane; stands in for the PBR pass that
-overwrites it), the GI dispatch (one-bounce indirect diffuse, adds into radiance[cur]), SVGF temporal
+direct-light term (device-to-device copy of the plane neb_pbr_direct produced once for the static
+view; stands in for the per-frame PBR pass that overwrites it), the GI dispatch (one-bounce indirect diffuse, adds into radiance[cur]), SVGF temporal
 accumulation and the a-trous wavelet levels.  Workload at N=1: BASELINE.json configs[2] --
 1920x1080, 1 spp, 5 a-trous levels on "sponza-standin" (the Sponza geometry blobs are stripped from
 the reference checkout; nebulae_amd/scene.py:atrium_standin matches Sponza.gltf's statistics).
@@ -133,8 +133,11 @@ def main():
     for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: the other slot holds the same G-buffer
         r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
     rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
-    direct = torch.zeros_like(rad_view[0])
-    direct[..., 3] = 1.0
+    r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
+    torch.cuda.synchronize()
+    direct = rad_view[r.svgf.get_current_resource_index()].clone()
+    if do_gi:
+        r.ray_count(reset=True)
     noisy_dev = None
     if not do_gi:
         g = synth.synth_gbuffer(GW, GH)

@@ -50,7 +50,8 @@ typedef enum neb_plane {
     NEB_PLANE_ALBEDO = 6,      /* R11G11B10_FLOAT     4 B/px, 1 slot (G-buffer, GI input)         */
     NEB_PLANE_ROUGH_METAL = 7, /* R16G16_FLOAT        4 B/px, 1 slot                              */
     NEB_PLANE_WORLDPOS = 8,    /* R16G16B16A16_FLOAT  8 B/px, 1 slot                              */
-    NEB_PLANE_COUNT = 9
+    NEB_PLANE_LDR = 9,         /* R8G8B8A8_UNORM      4 B/px, 1 slot (tonemapped back buffer, row f3) */
+    NEB_PLANE_COUNT = 10
 } neb_plane;
 
 /* Slot selectors for the 2-slot (ping-pong) planes. */
@@ -208,6 +209,13 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
 int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5]);
 /* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);
+/* "next" row f1: DeferredRenderer::SubmitCommandsPBRLighting (src/DeferredRenderer.cpp:326-394) driving
+ * assets/shaders/deferred_pbr.hlsl:39-115: Cook-Torrance sun light x one any-hit shadow ray per pixel; OVERWRITES
+ * radiance[cur] (alpha = 1).  Uses cameraWorldPos, sunLight*, sunTanHalfAngle and frameIndex of the constants. */
+int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* constants, neb_stream stream);
+/* "next" row f3: DeferredRenderer::SubmitCommandsHDRTonemapping (src/DeferredRenderer.cpp:616-660),
+ * assets/shaders/tonemapping.hlsl:3-53: ACES fit of radiance[cur] into the R8G8B8A8_UNORM LDR plane (alpha = luma). */
+int neb_tonemap(neb_ctx* ctx, neb_stream stream);
 /* "next" row f2: primary-visibility G-buffer producer with the encodings of
  * assets/shaders/deferred_gbuffers.hlsl:71-103 (writes ALBEDO, ROUGH_METAL, WORLDPOS, normal[cur], depth[cur]). */
 int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* camera, neb_stream stream);

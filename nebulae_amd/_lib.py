@@ -10,7 +10,7 @@ from . import build as _build
 
 NEB_OK = 0
 PLANE_RADIANCE, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOMENTS, PLANE_VARIANCE, PLANE_SCRATCH = 0, 1, 2, 3, 4, 5
-PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS = 6, 7, 8
+PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS, PLANE_LDR = 6, 7, 8, 9
 SLOT_CURRENT, SLOT_HISTORY = -1, -2
 
 
@@ -69,6 +69,8 @@ def _gi_sigs():
         "neb_gi_ray_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
         "neb_gi_traversal_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
         "neb_gi_download_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+        "neb_pbr_direct": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_void_p]),
+        "neb_tonemap": (C.c_int, [C.c_void_p, C.c_void_p]),
         "neb_gbuffer_raycast": (C.c_int, [C.c_void_p, C.POINTER(S.CameraDesc), C.c_void_p]),
     }
 

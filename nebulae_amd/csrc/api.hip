@@ -16,6 +16,7 @@ const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT] = {
     {4, 1},  // ALBEDO       R11G11B10_FLOAT
     {4, 1},  // ROUGH_METAL  R16G16_FLOAT
     {8, 1},  // WORLDPOS     R16G16B16A16_FLOAT
+    {4, 1},  // LDR          R8G8B8A8_UNORM
 };
 } // namespace neb
 

@@ -79,6 +79,7 @@ struct SceneView {
     const float* uvs;        // 2 per vertex
     const float* tangents;   // 4 per vertex
     const uint32_t* texels;  // RGBA8
+    const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
     uint32_t n_tris;
     int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
 };
@@ -496,19 +497,44 @@ __device__ __forceinline__ float3 xform_dir(const float* m, float3 p) // (p,0) *
 }
 
 // ReconstructSurfaceData (pathtracer.hlsl:299-395)
-__device__ bool reconstruct_surface(const SceneView& S, uint32_t prim, uint32_t geom, float bu, float bv, Surface& out)
+// Per-triangle shading record (128 B, one cache line) so that a hit costs one line instead of ~10 scattered
+// ones (3 indices, 3 x normal/uv/tangent in three SoA pools):
+//   r0 {n0.xyz, uv0.x} r1 {n1.xyz, uv0.y} r2 {n2.xyz, uv1.x} r3..r5 tangent0..2 r6 {uv1.y, uv2.x, uv2.y, -} r7 spare
+struct TriShade {
+    float3 n0, n1, n2;
+    float2 uv0, uv1, uv2;
+    float4 t0, t1, t2;
+};
+__device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t tri)
+{
+    const float4* r = S.shade + 8 * (size_t)tri;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r6 = r[6];
+    TriShade t;
+    t.n0 = f3(r0.x, r0.y, r0.z);
+    t.n1 = f3(r1.x, r1.y, r1.z);
+    t.n2 = f3(r2.x, r2.y, r2.z);
+    t.uv0 = make_float2(r0.w, r1.w);
+    t.uv1 = make_float2(r2.w, r6.x);
+    t.uv2 = make_float2(r6.y, r6.z);
+    t.t0 = r[3];
+    t.t1 = r[4];
+    t.t2 = r[5];
+    return t;
+}
+
+// ReconstructSurfaceData (pathtracer.hlsl:299-395); `tri` is the sorted triangle index of the hit.
+__device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, uint32_t geom, float bu, float bv, Surface& out)
 {
     const DevGeom g = S.geoms[geom];
     const float b0 = 1.0f - (bu + bv), b1 = bu, b2 = bv;
     if (!g.valid)
         return false; // :313-318
-    const uint32_t i0 = g.vertexBase + S.indices[g.firstIndex + 3 * prim], i1 = g.vertexBase + S.indices[g.firstIndex + 3 * prim + 1],
-                   i2 = g.vertexBase + S.indices[g.firstIndex + 3 * prim + 2];
-    const float3 n0 = load3(S.normals, i0), n1 = load3(S.normals, i1), n2 = load3(S.normals, i2);
+    const TriShade ts = load_tri_shade(S, tri);
+    const float3 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
     const float3 gn = normalize3(f3(n0.x * b0 + n1.x * b1 + n2.x * b2, n0.y * b0 + n1.y * b1 + n2.y * b2, n0.z * b0 + n1.z * b1 + n2.z * b2));
     out.GN = normalize3(xform_dir(g.m, gn)); // :340
-    const float u = S.uvs[2 * i0] * b0 + S.uvs[2 * i1] * b1 + S.uvs[2 * i2] * b2;
-    const float v = S.uvs[2 * i0 + 1] * b0 + S.uvs[2 * i1 + 1] * b1 + S.uvs[2 * i2 + 1] * b2;
+    const float u = ts.uv0.x * b0 + ts.uv1.x * b1 + ts.uv2.x * b2;
+    const float v = ts.uv0.y * b0 + ts.uv1.y * b1 + ts.uv2.y * b2;
     if (g.material < 0)
         return false; // :349
     const DevMat m = S.mats[g.material];
@@ -522,9 +548,10 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t prim, uint32_t 
         out.SN = out.GN;
     } else {
         float tg[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            tg[k] = S.tangents[4 * i0 + k] * b0 + S.tangents[4 * i1 + k] * b1 + S.tangents[4 * i2 + k] * b2;
+        tg[0] = ts.t0.x * b0 + ts.t1.x * b1 + ts.t2.x * b2;
+        tg[1] = ts.t0.y * b0 + ts.t1.y * b1 + ts.t2.y * b2;
+        tg[2] = ts.t0.z * b0 + ts.t1.z * b1 + ts.t2.z * b2;
+        tg[3] = ts.t0.w * b0 + ts.t1.w * b1 + ts.t2.w * b2;
         const float l4 = sqrtf(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2] + tg[3] * tg[3]); // normalize(float4), :371
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -544,6 +571,36 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t prim, uint32_t 
         out.metalness = t.z; // .b
     }
     return true;
+}
+
+// one thread per sorted triangle: gather its vertices' attributes from the SoA pools into the 128-B record
+__global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
+{
+    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= n)
+        return;
+    const float4 ids = S.tris[3 * ti + 2];
+    const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
+    const DevGeom g = S.geoms[geom];
+    float4 r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.valid) {
+        const uint32_t i0 = g.vertexBase + S.indices[g.firstIndex + 3 * prim], i1 = g.vertexBase + S.indices[g.firstIndex + 3 * prim + 1],
+                       i2 = g.vertexBase + S.indices[g.firstIndex + 3 * prim + 2];
+        const float3 n0 = load3(S.normals, i0), n1 = load3(S.normals, i1), n2 = load3(S.normals, i2);
+        r[0] = make_float4(n0.x, n0.y, n0.z, S.uvs[2 * i0]);
+        r[1] = make_float4(n1.x, n1.y, n1.z, S.uvs[2 * i0 + 1]);
+        r[2] = make_float4(n2.x, n2.y, n2.z, S.uvs[2 * i1]);
+        r[3] = make_float4(S.tangents[4 * i0], S.tangents[4 * i0 + 1], S.tangents[4 * i0 + 2], S.tangents[4 * i0 + 3]);
+        r[4] = make_float4(S.tangents[4 * i1], S.tangents[4 * i1 + 1], S.tangents[4 * i1 + 2], S.tangents[4 * i1 + 3]);
+        r[5] = make_float4(S.tangents[4 * i2], S.tangents[4 * i2 + 1], S.tangents[4 * i2 + 2], S.tangents[4 * i2 + 3]);
+        r[6] = make_float4(S.uvs[2 * i1 + 1], S.uvs[2 * i2], S.uvs[2 * i2 + 1], 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        out[8 * (size_t)ti + k] = r[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,7 +740,7 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
             dbg.geometry = geom;
             dbg.primitive = prim;
             Surface surf;
-            if (reconstruct_surface(a.S, prim, geom, h.y, h.z, surf)) {
+            if (reconstruct_surface(a.S, tri, geom, h.y, h.z, surf)) {
                 const float4 ro = a.R.ray_o[i], rd = a.R.ray_d[i];
                 const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
                 const float3 hitP = org + dir * h.x;
@@ -803,20 +860,19 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
     uint32_t ds = 0x00ffffffu;
     if (hit) {
         const float4 ids = a.S.tris[3 * h.tri + 2];
-        const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
+        const uint32_t geom = __float_as_uint(ids.y);
         const DevGeom g = a.S.geoms[geom];
         const float b1 = h.u, b2 = h.v, b0 = 1.0f - (b1 + b2);
         rm0 = 1.0f; // deferred_gbuffers.hlsl:91
         float3 GN = f3(0, 0, 1), SN = f3(0, 0, 1);
         if (g.valid) {
-            const uint32_t i0 = g.vertexBase + a.S.indices[g.firstIndex + 3 * prim], i1 = g.vertexBase + a.S.indices[g.firstIndex + 3 * prim + 1],
-                           i2 = g.vertexBase + a.S.indices[g.firstIndex + 3 * prim + 2];
-            const float3 n0 = load3(a.S.normals, i0), n1 = load3(a.S.normals, i1), n2 = load3(a.S.normals, i2);
+            const TriShade ts = load_tri_shade(a.S, h.tri);
+            const float3 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
             const float3 w0 = normalize3(xform_dir(g.m, n0)), w1 = normalize3(xform_dir(g.m, n1)), w2 = normalize3(xform_dir(g.m, n2));
             GN = normalize3(w0 * b0 + w1 * b1 + w2 * b2);
             SN = GN;
-            const float u = a.S.uvs[2 * i0] * b0 + a.S.uvs[2 * i1] * b1 + a.S.uvs[2 * i2] * b2;
-            const float v = a.S.uvs[2 * i0 + 1] * b0 + a.S.uvs[2 * i1 + 1] * b1 + a.S.uvs[2 * i2 + 1] * b2;
+            const float u = ts.uv0.x * b0 + ts.uv1.x * b1 + ts.uv2.x * b2;
+            const float v = ts.uv0.y * b0 + ts.uv1.y * b1 + ts.uv2.y * b2;
             if (g.material >= 0) {
                 const DevMat m = a.S.mats[g.material];
                 if (m.tex[0] >= 0) {
@@ -824,12 +880,10 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
                     alb = f3(t.x, t.y, t.z);
                 }
                 if (m.tex[1] >= 0) {
-                    const float* tp = a.S.tangents;
-                    const float3 tg0 = f3(tp[4 * i0], tp[4 * i0 + 1], tp[4 * i0 + 2]), tg1 = f3(tp[4 * i1], tp[4 * i1 + 1], tp[4 * i1 + 2]),
-                                 tg2 = f3(tp[4 * i2], tp[4 * i2 + 1], tp[4 * i2 + 2]);
-                    const float3 bt0 = normalize3(cross3(normalize3(n0), tg0) * tp[4 * i0 + 3]);
-                    const float3 bt1 = normalize3(cross3(normalize3(n1), tg1) * tp[4 * i1 + 3]);
-                    const float3 bt2 = normalize3(cross3(normalize3(n2), tg2) * tp[4 * i2 + 3]);
+                    const float3 tg0 = f3(ts.t0.x, ts.t0.y, ts.t0.z), tg1 = f3(ts.t1.x, ts.t1.y, ts.t1.z), tg2 = f3(ts.t2.x, ts.t2.y, ts.t2.z);
+                    const float3 bt0 = normalize3(cross3(normalize3(n0), tg0) * ts.t0.w);
+                    const float3 bt1 = normalize3(cross3(normalize3(n1), tg1) * ts.t1.w);
+                    const float3 bt2 = normalize3(cross3(normalize3(n2), tg2) * ts.t2.w);
                     const float3 T = normalize3(tg0 * b0 + tg1 * b1 + tg2 * b2);
                     const float3 B = normalize3(bt0 * b0 + bt1 * b1 + bt2 * b2);
                     const float4 t = sample_texture(a.S, m.tex[1], u, v);
@@ -853,6 +907,84 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
     a.normal[i] = make_uint2(float_to_half_bits(egn.x) | (float_to_half_bits(egn.y) << 16),
                              float_to_half_bits(esn.x) | (float_to_half_bits(esn.y) << 16));
     a.depth[i] = ds;
+}
+
+// ------------------------------------------------------------------------------------------------
+// "next" rows f1 (direct sun light, deferred_pbr.hlsl:39-115) and f3 (ACES tonemap, tonemapping.hlsl:3-53)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pbr_direct_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    uint32_t x, y;
+    size_t i;
+    const bool active = gi_pixel(a, x, y, i);
+    uint32_t rays = 0;
+    if (active) {
+        const float3 albedo = unpack_r11g11b10(a.albedo[i]);
+        const uint2 wp = a.world_pos[i];
+        const float3 worldPos = f3(half_bits_to_float(wp.x & 0xffffu), half_bits_to_float(wp.x >> 16), half_bits_to_float(wp.y & 0xffffu));
+        const uint32_t nzw = a.normal[i].y;
+        const float3 SN = oct_unpack(half_bits_to_float(nzw & 0xffffu), half_bits_to_float(nzw >> 16));
+        const uint32_t rm = a.rough_metal[i];
+        const float rough = half_bits_to_float(rm & 0xffffu), metal = half_bits_to_float(rm >> 16);
+        const float3 eye = f3(a.c.cameraWorldPos[0], a.c.cameraWorldPos[1], a.c.cameraWorldPos[2]);
+        const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
+        const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
+        const float3 V = normalize3(eye - worldPos);
+        const float VdotN = fminf(fmaxf(dot3(V, SN), 0.00001f), 1.0f);
+        const float3 L = normalize3(-sun_dir);
+        const float3 Hv = normalize3(L + V);
+        const float LdotN = fminf(fmaxf(dot3(L, SN), 0.00001f), 1.0f);
+        const float VdotH = fminf(fmaxf(dot3(V, Hv), 0.00001f), 1.0f);
+        const float NdotH = fminf(fmaxf(dot3(SN, Hv), 0.00001f), 1.0f);
+        const float3 F0 = specular_f0(albedo, metal);
+        const float3 F = fresnel_schlick(F0, VdotH);
+        const float3 Kd = f3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
+        const float denom = 1.0f / (4.0f * VdotN * LdotN); // Brdf_Specular_CookTorrance, brdf.hlsli:100-111
+        const float alpha = rough * rough, a2 = alpha * alpha;
+        const float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+        const float ndf = a2 / (kPi * dd * dd);
+        const float k = alpha * 0.5f;
+        const float gsf = (VdotN * (1.0f / (VdotN * (1.0f - k) + k))) * (LdotN * (1.0f / (LdotN * (1.0f - k) + k)));
+        const float cs = ndf * gsf;
+        const float3 O = Kd * (albedo * kPiInv) + f3(cs * F.x * denom, cs * F.y * denom, cs * F.z * denom);
+        // InitRNG(tid.xy, gid.xy, frame): the shader passes the GROUP id as the resolution (:82)
+        uint32_t rng = jenkins((x + y * (x / 8u)) ^ jenkins(a.c.frameIndex));
+        const float a0 = rand01(rng), a1 = rand01(rng);
+        const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
+        const float3 Bv = normalize3(perpendicular(L));
+        const float3 T = cross3(Bv, L);
+        const float3 inc = normalize3(L + (Bv * sinf(angle) + T * cosf(angle)) * a.c.sunTanHalfAngle * dist);
+        Hit h;
+        rays = 1;
+        const bool occluded = traverse(a.S, worldPos + SN * 1e-2f, inc, 0.0f, 3.402823466e+38f, true, stack_mem + threadIdx.x, h);
+        const float vis = occluded ? 0.0f : 1.0f;
+        a.radiance[i] = make_float4(O.x * LdotN * sun_rad.x * vis, O.y * LdotN * sun_rad.y * vis, O.z * LdotN * sun_rad.z * vis, 1.0f);
+    }
+    count_rays(a.shadow_counts, rays);
+}
+
+__global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__ radiance, uint32_t* __restrict__ ldr, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 c = radiance[i];
+    // ACESInputMat, RRTAndODTFit, ACESOutputMat (tonemapping.hlsl:3-41)
+    float v[3] = {0.59719f * c.x + 0.35458f * c.y + 0.04823f * c.z, 0.07600f * c.x + 0.90834f * c.y + 0.01566f * c.z,
+                  0.02840f * c.x + 0.13383f * c.y + 0.83777f * c.z};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float aa = v[r] * (v[r] + 0.0245786f) - 0.000090537f;
+        const float bb = v[r] * (0.983729f * v[r] + 0.4329510f) + 0.238081f;
+        v[r] = aa / bb;
+    }
+    const float o0 = saturate1(1.60475f * v[0] + -0.53108f * v[1] + -0.07367f * v[2]);
+    const float o1 = saturate1(-0.10208f * v[0] + 1.10813f * v[1] + -0.00605f * v[2]);
+    const float o2 = saturate1(-0.00327f * v[0] + -0.07276f * v[1] + 1.07602f * v[2]);
+    const float luma = saturate1(o0 * 0.2126f + o1 * 0.7152f + o2 * 0.0722f);
+    ldr[i] = (uint32_t)(o0 * 255.0f + 0.5f) | ((uint32_t)(o1 * 255.0f + 0.5f) << 8) | ((uint32_t)(o2 * 255.0f + 0.5f) << 16) |
+             ((uint32_t)(luma * 255.0f + 0.5f) << 24);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1255,6 +1387,18 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             e = hipGetLastError();
         }
     }
+    float4* d_shade = nullptr;
+    if (e == hipSuccess) {
+        d_shade = (float4*)dalloc((size_t)n * 128, true);
+        if (!d_shade) {
+            e = hipErrorOutOfMemory;
+        } else {
+            SceneView sv = g->view;
+            sv.tris = d_sorted;
+            hipLaunchKernelGGL(pack_shade_records_kernel, dim3(nb), dim3(256), 0, stream, sv, n, d_shade);
+            e = hipGetLastError();
+        }
+    }
     if (e == hipSuccess)
         e = hipStreamSynchronize(stream); // the temporaries are freed below; the build is a one-time setup step
     // ---- collapse the binary LBVH into BVH4 nodes with leaves of up to kMaxLeafTris triangles ----
@@ -1388,6 +1532,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     if (e != hipSuccess)
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh", e);
     g->view.tris = d_sorted;
+    g->view.shade = d_shade;
     g->view.nodes = d_wide;
     g->view.root = root_code;
     g->n_nodes = (uint32_t)wide.size();
@@ -1476,6 +1621,56 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
     }
     GI_HIP(ctx, hipGetLastError());
+    return NEB_OK;
+}
+
+int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
+{
+    if (!ctx || !c)
+        return ctx ? gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_pbr_direct: null constants") : NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (!g || !g->built)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_pbr_direct: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
+    GiArgs a{};
+    a.S = g->view;
+    a.c = *c;
+    a.albedo = (const uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
+    a.rough_metal = (const uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
+    a.world_pos = (const uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
+    a.normal = (const uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur];
+    a.radiance = (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur];
+    a.W = ctx->W;
+    a.row_begin = ctx->row_begin;
+    a.row0 = ctx->row_begin;
+    a.row1 = ctx->row_end;
+    a.tiles_x = (ctx->W + 7) / 8; // Dispatch((W+7)/8, (H+7)/8): DeferredRenderer.cpp:382
+    const uint32_t tiles_y = (a.row1 - a.row0 + 7) / 8;
+    const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
+    if (!g->d_block_counts) {
+        void* p = nullptr;
+        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
+        g->allocs.push_back(p);
+        g->d_block_counts = (uint32_t*)p;
+        g->n_block_counts = n_blocks;
+    }
+    a.bounce_counts = g->d_block_counts;
+    a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    hipLaunchKernelGGL(pbr_direct_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
+    GI_HIP(ctx, hipGetLastError());
+    return NEB_OK;
+}
+
+int neb_tonemap(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    const size_t n = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
+    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], (uint32_t*)ctx->planes[NEB_PLANE_LDR][0], n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return gi_fail(ctx, NEB_ERR_HIP, "neb_tonemap", e);
     return NEB_OK;
 }
 

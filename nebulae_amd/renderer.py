@@ -125,6 +125,15 @@ class DeferredRenderer:
         self._check(self._lib.neb_gbuffer_raycast(self._ctx, C.byref(self.info.camera), C.c_void_p(self.info.stream)),
                     "neb_gbuffer_raycast")
 
+    def submit_commands_pbr_lighting(self):
+        """SubmitCommandsPBRLighting (src/DeferredRenderer.cpp:326-394): direct sun light, overwrites radiance[cur]."""
+        c = self.global_constants()
+        self._check(self._lib.neb_pbr_direct(self._ctx, C.byref(c), C.c_void_p(self.info.stream)), "neb_pbr_direct")
+
+    def submit_commands_hdr_tonemapping(self):
+        """SubmitCommandsHDRTonemapping (src/DeferredRenderer.cpp:616-660): radiance[cur] -> LDR plane (RGBA8)."""
+        self._check(self._lib.neb_tonemap(self._ctx, C.c_void_p(self.info.stream)), "neb_tonemap")
+
     def submit_commands_gi_pathtrace(self, rows=None):
         c = self.global_constants()
         if rows is None:

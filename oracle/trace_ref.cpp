@@ -427,6 +427,15 @@ inline bool slab(const Node& n, V3 o, V3 inv, float tmin, float tmax, float& tne
 
 } // namespace
 
+static unsigned long long g_node_visits = 0, g_tri_tests = 0; // diagnostics (not thread-exact; fine for averages)
+extern "C" void trace_ref_stats(unsigned long long* nodes, unsigned long long* tris, int reset)
+{
+    *nodes = g_node_visits;
+    *tris = g_tri_tests;
+    if (reset)
+        g_node_visits = g_tri_tests = 0;
+}
+
 static bool trace(const trace_ref_scene* s, const std::vector<uint32_t>& right, V3 o, V3 d, float tmin, float tmax,
                   bool any_hit, Hit& hit)
 {
@@ -445,7 +454,11 @@ static bool trace(const trace_ref_scene* s, const std::vector<uint32_t>& right, 
         float tn;
         if (!slab(n, o, inv, tmin, hit.t, tn))
             continue;
+#pragma omp atomic
+        g_node_visits++;
         if (n.count) {
+#pragma omp atomic
+            g_tri_tests += n.count;
             for (uint32_t i = 0; i < n.count; ++i) {
                 float t, u, v;
                 if (intersect_tri(s->tris[n.left + i], o, d, tmin, hit.t, t, u, v)) {
@@ -846,5 +859,90 @@ extern "C" void trace_ref_gbuffer(const trace_ref_scene* s, uint32_t W, uint32_t
                 normal[4 * i + k] = svgf_ref_f32_to_f16(en[k]);
             depth_stencil[i] = ds;
         }
+    }
+}
+
+// ---- deferred_pbr.hlsl:39-115 ----
+extern "C" uint64_t trace_ref_pbr_direct(const trace_ref_scene* s, uint32_t W, uint32_t H, const trace_ref_constants* c,
+                                         const uint32_t* albedo_p, const uint16_t* rough_metal, const uint16_t* world_pos,
+                                         const uint16_t* normal, float* radiance, int threads)
+{
+    const std::vector<uint32_t> right = right_children(s);
+    const V3 eye = v3(c->cameraWorldPos[0], c->cameraWorldPos[1], c->cameraWorldPos[2]);
+    const V3 sun_dir = v3(c->sunLightDirection[0], c->sunLightDirection[1], c->sunLightDirection[2]);
+    const V3 sun_rad = v3(c->sunLightRadiance[0], c->sunLightRadiance[1], c->sunLightRadiance[2]);
+    uint64_t rays = 0;
+    auto clampf = [](float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); };
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : rays)
+    for (int yy = 0; yy < (int)H; ++yy) {
+        for (uint32_t x = 0; x < W; ++x) {
+            const uint32_t y = (uint32_t)yy;
+            const size_t i = (size_t)y * W + x;
+            float alb[3];
+            trace_ref_unpack_r11g11b10(albedo_p[i], alb);
+            const V3 albedo = v3(alb[0], alb[1], alb[2]);
+            const V3 worldPos = v3(h2f(world_pos[4 * i]), h2f(world_pos[4 * i + 1]), h2f(world_pos[4 * i + 2]));
+            const V3 SN = oct_unpack(h2f(normal[4 * i + 2]), h2f(normal[4 * i + 3]));
+            const float rough = h2f(rough_metal[2 * i]), metal = h2f(rough_metal[2 * i + 1]);
+            const V3 V = normalize(eye - worldPos);
+            const float VdotN = clampf(dot(V, SN), 0.00001f, 1.0f);
+            const V3 L = normalize(-sun_dir);
+            const V3 Hv = normalize(L + V);
+            const float LdotN = clampf(dot(L, SN), 0.00001f, 1.0f);
+            const float VdotH = clampf(dot(V, Hv), 0.00001f, 1.0f);
+            const float NdotH = clampf(dot(SN, Hv), 0.00001f, 1.0f);
+            const V3 F0 = specular_f0(albedo, metal);
+            const V3 F = fresnel_schlick(F0, VdotH);
+            const V3 Kd = {1.0f - F.x, 1.0f - F.y, 1.0f - F.z};
+            // Brdf_Specular_CookTorrance (brdf.hlsli:100-111)
+            const float denom = 1.0f / (4.0f * VdotN * LdotN);
+            const float alpha = rough * rough, a2 = alpha * alpha;
+            const float dd = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+            const float ndf = a2 / (PI * dd * dd);
+            const float k = alpha * 0.5f;
+            const float gsf = (VdotN * (1.0f / (VdotN * (1.0f - k) + k))) * (LdotN * (1.0f / (LdotN * (1.0f - k) + k)));
+            const float cs = ndf * gsf;
+            const V3 O = Kd * (albedo * PI_INV) + v3(cs * F.x * denom, cs * F.y * denom, cs * F.z * denom);
+            // InitRNG(tid.xy, gid.xy, frame): the GROUP id is passed as the resolution (:82)
+            uint32_t rng = init_rng(x, y, x / 8u, c->frameIndex);
+            const float a0 = rand01(rng), a1 = rand01(rng);
+            const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
+            const V3 Bv = normalize(perpendicular(L));
+            const V3 T = cross(Bv, L);
+            const V3 inc = normalize(L + (Bv * sinf(angle) + T * cosf(angle)) * c->sunTanHalfAngle * dist);
+            Hit h;
+            rays++;
+            const bool occluded = trace(s, right, worldPos + SN * 1e-2f, inc, 0.0f, 3.402823466e+38f, true, h);
+            const float vis = occluded ? 0.0f : 1.0f;
+            radiance[4 * i + 0] = O.x * LdotN * sun_rad.x * vis;
+            radiance[4 * i + 1] = O.y * LdotN * sun_rad.y * vis;
+            radiance[4 * i + 2] = O.z * LdotN * sun_rad.z * vis;
+            radiance[4 * i + 3] = 1.0f;
+        }
+    }
+    return rays;
+}
+
+// ---- tonemapping.hlsl:3-53 ----
+extern "C" void trace_ref_tonemap(uint32_t W, uint32_t H, const float* radiance, uint8_t* rgba8)
+{
+    static const float in_m[3][3] = {{0.59719f, 0.35458f, 0.04823f}, {0.07600f, 0.90834f, 0.01566f}, {0.02840f, 0.13383f, 0.83777f}};
+    static const float out_m[3][3] = {{1.60475f, -0.53108f, -0.07367f}, {-0.10208f, 1.10813f, -0.00605f}, {-0.00327f, -0.07276f, 1.07602f}};
+    for (size_t i = 0; i < (size_t)W * H; ++i) {
+        const float* c = radiance + 4 * i;
+        float v[3], o[3];
+        for (int r = 0; r < 3; ++r)
+            v[r] = in_m[r][0] * c[0] + in_m[r][1] * c[1] + in_m[r][2] * c[2];
+        for (int r = 0; r < 3; ++r) {
+            const float a = v[r] * (v[r] + 0.0245786f) - 0.000090537f;
+            const float b = v[r] * (0.983729f * v[r] + 0.4329510f) + 0.238081f;
+            v[r] = a / b;
+        }
+        for (int r = 0; r < 3; ++r)
+            o[r] = saturate(out_m[r][0] * v[0] + out_m[r][1] * v[1] + out_m[r][2] * v[2]);
+        const float luma = o[0] * 0.2126f + o[1] * 0.7152f + o[2] * 0.0722f;
+        const float q[4] = {o[0], o[1], o[2], saturate(luma)};
+        for (int r = 0; r < 4; ++r)
+            rgba8[4 * i + r] = (uint8_t)(q[r] * 255.0f + 0.5f); // UNORM8 round-to-nearest
     }
 }

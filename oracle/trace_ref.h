@@ -100,6 +100,15 @@ void trace_ref_gbuffer(const trace_ref_scene* s, uint32_t W, uint32_t H, const t
                        uint32_t* albedo_r11g11b10, uint16_t* rough_metal, uint16_t* world_pos, uint16_t* normal,
                        uint32_t* depth_stencil, int threads);
 
+/* "next" row f1: direct sun light, assets/shaders/deferred_pbr.hlsl:39-115 -- OVERWRITES radiance (alpha = 1).
+ * RNG seeded with the group id as "resolution" exactly as the shader does (:82). */
+uint64_t trace_ref_pbr_direct(const trace_ref_scene* s, uint32_t W, uint32_t H, const trace_ref_constants* c,
+                              const uint32_t* albedo_r11g11b10, const uint16_t* rough_metal, const uint16_t* world_pos,
+                              const uint16_t* normal, float* radiance, int threads);
+
+/* "next" row f3: ACES fit of assets/shaders/tonemapping.hlsl:3-53 into R8G8B8A8_UNORM (alpha = luma). */
+void trace_ref_tonemap(uint32_t W, uint32_t H, const float* radiance, uint8_t* rgba8);
+
 /* Format helpers exported for tests. */
 uint32_t trace_ref_pack_r11g11b10(const float* rgb);
 void trace_ref_unpack_r11g11b10(uint32_t v, float* rgb);

@@ -174,3 +174,28 @@ class OracleTracer:
             self.close()
         except Exception:
             pass
+
+
+def oracle_pbr_direct(tracer, gb, consts):
+    """trace_ref_pbr_direct: direct sun light (row f1); returns (radiance[H,W,4], rays)."""
+    H, W = gb["albedo"].shape
+    L = tracer.L
+    L.trace_ref_pbr_direct.restype = C.c_uint64
+    from nebulae_amd import scene as S
+    L.trace_ref_pbr_direct.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(S.GIConstants), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int]
+    rad = np.zeros((H, W, 4), np.float32)
+    rays = L.trace_ref_pbr_direct(tracer.p, W, H, C.byref(consts), gb["albedo"].ctypes.data, gb["rough_metal"].ctypes.data,
+                                  gb["world_pos"].ctypes.data, gb["normal"].ctypes.data, rad.ctypes.data, tracer.threads)
+    return rad, int(rays)
+
+
+def oracle_tonemap(radiance):
+    H, W, _ = radiance.shape
+    L = lib()
+    L.trace_ref_tonemap.restype = None
+    L.trace_ref_tonemap.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    out = np.zeros((H, W, 4), np.uint8)
+    rad = np.ascontiguousarray(radiance, np.float32)
+    L.trace_ref_tonemap(W, H, rad.ctypes.data, out.ctypes.data)
+    return out

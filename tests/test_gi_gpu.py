@@ -142,3 +142,36 @@ def test_trace_before_scene_is_an_error():
     with pytest.raises(NebError):
         r.submit_commands_gi_pathtrace()
     r.destroy()
+
+
+def test_direct_light_and_tonemap_match_oracle():
+    """Rows f1 + f3: PBR direct light (overwrites radiance, one any-hit ray per pixel) and the ACES tonemap."""
+    from nebulae_amd.svgf import PLANE_LDR
+    from oracle_lib import oracle_pbr_direct, oracle_tonemap
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=9))
+    upload_gbuffer(r, gb)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.full((H, W, 4), 7.0, np.float32))
+    r.ray_count(reset=True)
+    r.submit_commands_pbr_lighting()
+    got = r.svgf.download(PLANE_RADIANCE)
+    want, orays = oracle_pbr_direct(o, gb, r.global_constants())
+    assert r.ray_count() == orays == W * H
+    lit_same = (got[..., 0] > 0) == (want[..., 0] > 0)
+    assert lit_same.mean() >= 1.0 - 3e-4                       # shadow-ray visibility agrees except at triangle edges
+    assert np.array_equal(got[..., 3], np.ones((H, W), np.float32))
+    assert rel_l2(got[lit_same][:, :3], want[lit_same][:, :3]) <= 2e-5
+    # GI on top of the direct term, then tonemap
+    r.submit_commands_gi_pathtrace()
+    hdr = r.svgf.download(PLANE_RADIANCE)
+    r.submit_commands_hdr_tonemapping()
+    ldr = r.svgf.download(PLANE_LDR).view(np.uint8).reshape(H, W, 4)
+    ref = oracle_tonemap(hdr)
+    assert np.abs(ldr.astype(np.int16) - ref.astype(np.int16)).max() <= 1  # UNORM8 rounding of ~1e-7-different floats
+    assert (ldr == ref).mean() >= 0.999
+    r.destroy()
