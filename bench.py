@@ -48,6 +48,23 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(width, height, levels):
+    """HBM bytes per a-trous launch from the newest committed PMC summary (tools/traffic_from_pmc.py): PMC counters need
+    their own rocprofv3 passes, so bench.py reports the value measured on this workload, or None if there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("width") == width and d.get("height") == height:
+            per = [v["total"] for k, v in d["kernels"].items() if "svgf_atrous_lds_kernel" in k]
+            if len(per) == levels:
+                best = (sum(per) / len(per), os.path.basename(f))
+    return best
+
+
 def host_cores():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return max(1, min(n, 16))  # a 1-GPU box shares its host: 16 cores is this job's CPU share
@@ -102,9 +119,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if os.environ.get("NEB_BENCH_SHARE_DEVICE"):  # rehearsal of the N > 1 path on a 1-GPU box: every rank on cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("NEB_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
     from nebulae_amd import scene as S
     from nebulae_amd import strips, synth
@@ -179,7 +199,8 @@ def main():
     dt = time.perf_counter() - t0
     rays_timed = r.ray_count(reset=True) if do_gi else 0
     assert all(ran_svgf), "SVGF was skipped inside the timed region"
-    stats = torch.tensor([dt, float(rays_timed)], device="cuda", dtype=torch.float64)
+    stats = torch.tensor([dt, float(rays_timed)], dtype=torch.float64,
+                         device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -206,6 +227,7 @@ def main():
         own_px = (own1 - own0) * GW                       # pixels a rank owns (= one 1080p frame)
         fps_equiv = args.steps / dt * world               # 1080p-frame equivalents per second, whole job
         achieved = ATROUS_BYTES_PX * own_px / t_atrous / 1e9
+        traffic = measured_traffic(GW, GH, L) if world == 1 else None
         out = {
             "metric": "denoised frames/s (1920x1080-frame equivalents: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
                       "denoised frames/s (1920x1080-frame equivalents: SVGF temporal + a-trous only)",
@@ -223,7 +245,8 @@ def main():
             "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": t_temporal * 1e6, "atrous_levels": [t * 1e6 for t in per_level]},
             "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None},
+                         "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
+                         "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None},
             "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s"},
         }

@@ -102,13 +102,26 @@ class StripRenderer(DeferredRenderer):
         """Swap the boundary rows of `level`'s source plane with the neighbouring strips."""
         import torch.distributed as dist
         (sp, ss), _ = self.svgf.atrous_level_planes(level)
+        plan = self.part.level_exchange(self.rank, level)
+        if not plan:
+            return
+        send = [self._plane_rows(sp, ss, s0, s1) for _, (s0, s1), _ in plan]
+        recv = [self._plane_rows(sp, ss, r0, r1) for _, _, (r0, r1) in plan]
+        staged = send[0].is_cuda and dist.get_backend(self.group) == "gloo"
+        if staged:  # rehearsal on a box without RCCL peers: gloo moves host memory only, so stage the rows through it
+            import torch
+            torch.cuda.current_stream().synchronize()
+            send = [t.cpu() for t in send]
+            host = [torch.empty(t.shape, dtype=t.dtype) for t in recv]
         ops = []
-        for peer, (s0, s1), (r0, r1) in self.part.level_exchange(self.rank, level):
-            ops.append(dist.P2POp(dist.isend, self._plane_rows(sp, ss, s0, s1), peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, self._plane_rows(sp, ss, r0, r1), peer, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        for k, (peer, _, _) in enumerate(plan):
+            ops.append(dist.P2POp(dist.isend, send[k], peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, host[k] if staged else recv[k], peer, group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if staged:
+            for dst, src in zip(recv, host):
+                dst.copy_(src)
 
     def submit_commands_svgf_denoising(self, events=None):
         if self.dynamic_scene_this_frame:  # src/DeferredRenderer.cpp:595
