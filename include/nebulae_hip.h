@@ -168,7 +168,8 @@ typedef struct neb_texture_desc {
 typedef struct neb_gi_constants {
     uint32_t frameIndex;
     uint32_t samplesPerPixel;
-    uint32_t maxPathVertices; /* nrcMaxPathVertices; 2 = one bounce (the supported value) */
+    uint32_t maxPathVertices; /* nrcMaxPathVertices, <= 8 (MaxPathtracingRecursionDepth, DeferredRenderer.h:118); 2 = one bounce, the
+                                 north-star configuration; > 2 follows the shader's bounce loop with the NRC stubs (row f4) */
     float cameraWorldPos[3];
     float skyColor[3];
     float sunLightDirection[3];

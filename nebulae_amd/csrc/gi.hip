@@ -612,8 +612,10 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
 // away from them.
 // ------------------------------------------------------------------------------------------------
 struct GiRecords {
-    float4* ray_o;   // {origin.xyz, tmin}      (bounce ray, then overwritten by the shadow ray)
-    float4* ray_d;   // {direction.xyz, valid}  valid = 1: trace it
+    float4* ray_o;   // {origin.xyz, tmin}      bounce ray of the path
+    float4* ray_d;   // {direction.xyz, alive}  alive = 1: the path continues with this ray
+    float4* sray_o;  // {origin.xyz, tmin}      sun shadow ray of the current vertex
+    float4* sray_d;  // {direction.xyz, valid}  valid = 1: trace it
     float4* hit;     // {t (<0 miss), u, v, tri bits}
     float4* path;    // {throughput.xyz, rng bits}
     float4* contrib; // {BRDF * sunRadiance * throughput, -}
@@ -636,6 +638,7 @@ struct GiArgs {
     uint32_t* shadow_counts;     // per-workgroup shadow-ray counts
     uint32_t W, row_begin, row0, row1, tiles_x;
     uint32_t sample;             // index of the sample this launch handles
+    uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
     uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
 };
 
@@ -715,6 +718,29 @@ __global__ __launch_bounds__(64) void gi_raygen_trace_kernel(GiArgs a)
     count_rays(a.bounce_counts, rays);
 }
 
+// Closest-hit traversal of the bounce rays of path vertices >= 2 (vertex 1 is fused into ray generation).
+__global__ __launch_bounds__(64) void gi_bounce_trace_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    uint32_t x, y;
+    size_t i;
+    const bool active = gi_pixel(a, x, y, i);
+    uint32_t rays = 0;
+    if (active) {
+        const float4 rd = a.R.ray_d[i];
+        if (rd.w != 0.0f) {
+            const float4 ro = a.R.ray_o[i];
+            Hit hit;
+            rays = 1;
+            float4 h = make_float4(-1.0f, 0.f, 0.f, 0.f);
+            if (traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, false, stack_mem + threadIdx.x, hit))
+                h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
+            a.R.hit[i] = h;
+        }
+    }
+    count_rays(a.bounce_counts, rays);
+}
+
 __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
 {
     uint32_t x, y;
@@ -724,15 +750,18 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
     if (active) {
         const float4 h = a.R.hit[i];
         const float4 pth = a.R.path[i];
-        const float3 throughput = f3(pth.x, pth.y, pth.z);
-        float4 sum = (a.sample == 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : a.R.sum[i];
+        const float4 rd = a.R.ray_d[i];
+        float3 throughput = f3(pth.x, pth.y, pth.z);
+        float4 sum = (a.sample == 0 && a.bounce == 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : a.R.sum[i];
         float4 shadow_d = make_float4(0.f, 0.f, 0.f, 0.f); // valid = 0: no shadow ray
+        float4 next_d = make_float4(0.f, 0.f, 0.f, 0.f);   // alive = 0: the path ends here
         neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
-        if (h.x == -1.0f) { // miss: radiance += skyColor * throughput (:508)
+        const bool alive = rd.w != 0.0f; // (vertex 1 with maxPathVertices <= 1: hit.x == -2, nothing is added)
+        if (alive && h.x == -1.0f) { // miss: radiance += skyColor * throughput (:508)
             sum.x += a.c.skyColor[0] * throughput.x;
             sum.y += a.c.skyColor[1] * throughput.y;
             sum.z += a.c.skyColor[2] * throughput.z;
-        } else if (h.x >= 0.0f) {
+        } else if (alive && h.x >= 0.0f) {
             const uint32_t tri = __float_as_uint(h.w);
             const float4 ids = a.S.tris[3 * tri + 2];
             const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
@@ -741,7 +770,7 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
             dbg.primitive = prim;
             Surface surf;
             if (reconstruct_surface(a.S, tri, geom, h.y, h.z, surf)) {
-                const float4 ro = a.R.ray_o[i], rd = a.R.ray_d[i];
+                const float4 ro = a.R.ray_o[i];
                 const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
                 const float3 hitP = org + dir * h.x;
                 const float3 V = normalize3(-dir); // :522
@@ -757,16 +786,35 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
                 const bool transition = dot3(surf.GN, inc) <= 0.0f;
                 const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
                 const float3 O = evaluate_direct_brdf(surf, V, L) * sun_rad * throughput; // :573-574
-                a.R.ray_o[i] = make_float4(so.x, so.y, so.z, 0.001f);
+                a.R.sray_o[i] = make_float4(so.x, so.y, so.z, 0.001f);
                 shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
                 a.R.contrib[i] = make_float4(O.x, O.y, O.z, 0.f);
-                a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
                 rays = 1;
+                if (a.bounce + 1 < a.c.maxPathVertices) { // not the last vertex (:579-583): sample the next bounce
+                    // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
+                    // so the Rand(rng) of :614 returns the same number as the first of them.
+                    uint32_t rng_copy = rng;
+                    const float3 SNn = normalize3(surf.SN);
+                    const float e0 = rand01(rng_copy), e1 = rand01(rng_copy);
+                    const float3 Ld = cosine_hemisphere_aligned(e0, e1, SNn);
+                    const float pdiff = 1.0f - specular_probability(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
+                    const float3 no = hitP + surf.GN * 1e-2f; // :607
+                    throughput = throughput * (surf.albedo * (1.0f - surf.metalness)); // :613
+                    if (rand01(rng) < pdiff)
+                        throughput = f3(throughput.x / pdiff, throughput.y / pdiff, throughput.z / pdiff); // :614-618
+                    a.R.ray_o[i] = make_float4(no.x, no.y, no.z, 0.001f);
+                    next_d = make_float4(Ld.x, Ld.y, Ld.z, 1.0f);
+                    a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
+                } else {
+                    a.R.path[i] = make_float4(pth.x, pth.y, pth.z, __uint_as_float(rng));
+                }
+                a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
             }
         }
-        a.R.ray_d[i] = shadow_d;
+        a.R.ray_d[i] = next_d;
+        a.R.sray_d[i] = shadow_d;
         a.R.sum[i] = sum;
-        if (a.hits)
+        if (a.hits && a.bounce == 1)
             a.hits[i] = dbg;
     }
     count_rays(a.shadow_counts, rays);
@@ -782,10 +830,10 @@ __global__ __launch_bounds__(64) void gi_shadow_trace_kernel(GiArgs a)
     size_t i;
     if (!gi_pixel(a, x, y, i))
         return;
-    const float4 rd = a.R.ray_d[i];
+    const float4 rd = a.R.sray_d[i];
     float4 sum = a.R.sum[i];
     if (rd.w != 0.0f) {
-        const float4 ro = a.R.ray_o[i];
+        const float4 ro = a.R.sray_o[i];
         Hit sh;
         const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh);
         if (a.stats) { // diagnostics only
@@ -797,11 +845,12 @@ __global__ __launch_bounds__(64) void gi_shadow_trace_kernel(GiArgs a)
             sum.x += c.x;
             sum.y += c.y;
             sum.z += c.z;
-            if (a.hits)
+            if (a.hits && a.bounce == 1)
                 a.hits[i].flags |= 1u;
         }
     }
-    if (a.sample + 1 == a.c.samplesPerPixel) { // stands in for NRC Resolve: radiance[cur] += mean over spp
+    const bool last_vertex = a.bounce + 1 >= a.c.maxPathVertices;
+    if (a.sample + 1 == a.c.samplesPerPixel && last_vertex) { // stands in for NRC Resolve: radiance[cur] += mean over spp
         const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
         float4 r = a.radiance[i];
         r.x += sum.x * inv_spp;
@@ -1560,8 +1609,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
     if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
         return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_gi_trace: rows not resident");
-    if (c->samplesPerPixel == 0 || c->maxPathVertices > 2)
-        return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: samplesPerPixel must be >= 1 and maxPathVertices <= 2 (one bounce)");
+    if (c->samplesPerPixel == 0 || c->maxPathVertices > 8)
+        return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: samplesPerPixel must be >= 1 and maxPathVertices <= 8 (MaxPathtracingRecursionDepth)");
     if (row0 == row1)
         return NEB_OK;
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
@@ -1574,7 +1623,7 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     }
     if (!g->d_records) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, npx * sizeof(float4) * 7));
+        GI_HIP(ctx, hipMalloc(&p, npx * sizeof(float4) * 9));
         g->allocs.push_back(p);
         g->d_records = (float4*)p;
     }
@@ -1588,6 +1637,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     a.R.contrib = g->d_records + 4 * npx;
     a.R.state = g->d_records + 5 * npx;
     a.R.sum = g->d_records + 6 * npx;
+    a.R.sray_o = g->d_records + 7 * npx;
+    a.R.sray_d = g->d_records + 8 * npx;
     a.albedo = (const uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
     a.rough_metal = (const uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
     a.world_pos = (const uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
@@ -1614,11 +1665,18 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    const uint32_t n_vertices = c->maxPathVertices > 1 ? c->maxPathVertices - 1 : 1; // path vertices traced per sample
     for (uint32_t s = 0; s < c->samplesPerPixel; ++s) {
         a.sample = s;
-        hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+        for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
+            a.bounce = b;
+            if (b == 1)
+                hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+        }
     }
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;

@@ -712,37 +712,56 @@ extern "C" uint64_t trace_ref_gi(const trace_ref_scene* s, uint32_t W, uint32_t 
                 V3 dir = cosine_hemisphere_aligned(u0, u1, SN);
                 V3 org = worldPos + SN * 1e-2f;
                 dbg = {-1.0f, ~0u, ~0u, 0};
-                if (c->maxPathVertices > 1) { // for (bounce = 1; bounce < nrcMaxPathVertices; ...)
+                float tmin = 0.01f; // primary vertex: :140; later bounces 0.001 (:609)
+                for (uint32_t bounce = 1; bounce < c->maxPathVertices; ++bounce) { // :495
                     Hit h;
                     rays++;
-                    if (!trace(s, right, org, dir, 0.01f, TRACING_MAX_DISTANCE, false, h)) {
+                    if (!trace(s, right, org, dir, tmin, TRACING_MAX_DISTANCE, false, h)) {
                         rad = rad + sky * throughput; // :508
-                    } else {
-                        const Tri& tr = s->tris[h.tri];
+                        break;
+                    }
+                    const Tri& tr = s->tris[h.tri];
+                    if (bounce == 1) {
                         dbg.t = h.t;
                         dbg.geometry = tr.geom;
                         dbg.primitive = tr.prim;
-                        Surface surf;
-                        if (reconstruct_surface(s, tr.prim, tr.geom, h.u, h.v, surf)) {
-                            V3 hitP = org + dir * h.t;
-                            V = normalize(-dir); // :522
-                            float a0 = rand01(rng), a1 = rand01(rng);
-                            float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
-                            V3 L = normalize(-sun_dir);
-                            V3 Bv = normalize(perpendicular(L));
-                            V3 T = cross(Bv, L);
-                            V3 inc = normalize(L + (Bv * sinf(angle) + T * cosf(angle)) * c->sunTanHalfAngle * dist);
-                            bool transition = dot(surf.GN, inc) <= 0.0f;
-                            V3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
-                            Hit sh;
-                            rays++;
-                            if (!trace(s, right, so, inc, 0.001f, TRACING_MAX_DISTANCE, true, sh)) {
-                                V3 O = evaluate_direct_brdf(surf, V, L) * sun_rad;
-                                rad = rad + O * throughput; // :574 (no N.L term, BRDF at the disk centre L)
-                                dbg.flags |= 1u;
-                            }
-                        }
                     }
+                    Surface surf;
+                    if (!reconstruct_surface(s, tr.prim, tr.geom, h.u, h.v, surf))
+                        break; // :514-518
+                    V3 hitP = org + dir * h.t;
+                    V = normalize(-dir); // :522
+                    float a0 = rand01(rng), a1 = rand01(rng);
+                    float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
+                    V3 L = normalize(-sun_dir);
+                    V3 Bv = normalize(perpendicular(L));
+                    V3 T = cross(Bv, L);
+                    V3 inc = normalize(L + (Bv * sinf(angle) + T * cosf(angle)) * c->sunTanHalfAngle * dist);
+                    bool transition = dot(surf.GN, inc) <= 0.0f;
+                    V3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
+                    Hit sh;
+                    rays++;
+                    if (!trace(s, right, so, inc, 0.001f, TRACING_MAX_DISTANCE, true, sh)) {
+                        V3 O = evaluate_direct_brdf(surf, V, L) * sun_rad;
+                        rad = rad + O * throughput; // :574 (no N.L term, BRDF at the disk centre L)
+                        if (bounce == 1)
+                            dbg.flags |= 1u;
+                    }
+                    if (bounce == c->maxPathVertices - 1)
+                        break; // :579-583
+                    // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its Rand2 draws do not advance the path's
+                    // stream, so the Rand(rng) of :614 below returns the same number as the first of them.
+                    uint32_t rng_copy = rng;
+                    V3 SNn = normalize(surf.SN);
+                    float e0 = rand01(rng_copy), e1 = rand01(rng_copy);
+                    V3 Ld = cosine_hemisphere_aligned(e0, e1, SNn);
+                    float pdiff = 1.0f - specular_probability(saturate(dot(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
+                    org = hitP + surf.GN * 1e-2f; // :607
+                    dir = Ld;
+                    tmin = 0.001f;
+                    throughput = throughput * diffuse_reflectance(surf.albedo, surf.metalness); // :613
+                    if (rand01(rng) < pdiff)
+                        throughput = v3(throughput.x / pdiff, throughput.y / pdiff, throughput.z / pdiff); // :614-618
                 }
                 sum = sum + rad;
             }

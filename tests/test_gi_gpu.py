@@ -128,7 +128,7 @@ def test_edge_cases_empty_scene_single_triangle_and_missing_attributes():
     assert (hits["t"] > 0).any() and np.array_equal(hits["t"] > 0, ohits["t"] > 0)
     assert rel_l2(got[..., :3], want[..., :3]) <= 1e-5
     # (c) constants outside the supported range are rejected, not silently clamped
-    r.gi_ui.max_path_vertices = 8
+    r.gi_ui.max_path_vertices = 9
     with pytest.raises(NebError):
         r.submit_commands_gi_pathtrace()
     r.destroy()
@@ -174,4 +174,38 @@ def test_direct_light_and_tonemap_match_oracle():
     ref = oracle_tonemap(hdr)
     assert np.abs(ldr.astype(np.int16) - ref.astype(np.int16)).max() <= 1  # UNORM8 rounding of ~1e-7-different floats
     assert (ldr == ref).mean() >= 0.999
+    r.destroy()
+
+
+@pytest.mark.parametrize("max_vertices,spp", [(3, 1), (5, 2), (8, 1), (1, 1)])
+def test_multi_bounce_matches_oracle(max_vertices, spp):
+    """Row f4: the shader's bounce loop (pathtracer.hlsl:495-621) with the NRC stubs, up to 8 path vertices, including the
+    by-value rng of EvaluateIndirectBRDF.  maxPathVertices = 1 traces nothing and adds nothing."""
+    make, cam, W, H = scenes()["cornell"]
+    sc = make()
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.gi_ui.gi_samples_per_pixel = spp
+    r.gi_ui.max_path_vertices = max_vertices
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=3))
+    upload_gbuffer(r, gb)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    r.set_debug_hits(True)
+    r.ray_count(reset=True)
+    r.submit_commands_gi_pathtrace()
+    got = r.svgf.download(PLANE_RADIANCE)
+    hits = r.download_hits()
+    rays = r.ray_count()
+    want, ohits, orays = o.gi(gb, r.global_constants())
+    if max_vertices == 1:
+        assert rays == orays == 0 and float(np.abs(got).max()) == 0.0
+    else:
+        same = (hits["geometry"] == ohits["geometry"]) & (hits["primitive"] == ohits["primitive"])
+        assert same.mean() >= 1.0 - 2e-4
+        assert abs(rays - orays) <= max(8, 1e-3 * orays)
+        assert rel_l2(got[..., :3], want[..., :3]) <= 5e-3      # a path that forks at a triangle edge changes its pixel entirely
+        assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 3e-3
+        assert np.median(np.abs(got[..., :3] - want[..., :3])) <= 1e-6
     r.destroy()
