@@ -99,7 +99,8 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
 /* Implementation knobs with no reference counterpart (A/B arms for profiling):
  *   "atrous_variant": 1 = LDS row-lattice kernel (default; 4 rows per lane for steps <= 4, 2 for wider steps),
  *                     2 / 3 = LDS kernel with 2 / 4 rows per lane everywhere, 0 = direct-load kernel;
- *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene). */
+ *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene);
+ *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
 /* ---- resource sharing: the ~25 getters of SVGFDenoiser.h:24-70 collapse into one call.
@@ -203,6 +204,10 @@ int neb_gi_scene_info(const neb_ctx* ctx, uint32_t* n_triangles, uint32_t* n_nod
  * normal[cur].  _rows: image rows [row0,row1) only (multi-GPU strips). */
 int neb_gi_trace(neb_ctx* ctx, const neb_gi_constants* constants, neb_stream stream);
 int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* constants, uint32_t row0, uint32_t row1, neb_stream stream);
+/* The reference's separate resolve step (nrc Resolve(commandList, GetRadianceOutput()), DeferredRenderer.cpp:586):
+ * radiance[cur].rgb += the indirect term of the last neb_gi_trace that ran with "gi_defer_resolve" = 1.  Lets the GI
+ * stages of frame f+1 overlap the SVGF passes of frame f on another stream (they share no plane until this call). */
+int neb_gi_resolve(neb_ctx* ctx, neb_stream stream);
 /* Rays traced (bounce + shadow) by all GI dispatches since the last reset.  Synchronises `stream`. */
 int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream);
 /* Diagnostics: counters as of the last neb_gi_ray_count call: {rays, bounce node visits, bounce triangle tests,

@@ -206,6 +206,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
         ctx->atrous_variant = value;
         return NEB_OK;
     }
+    if (!strcmp(key, "gi_defer_resolve")) {
+        if (gi_set_defer_resolve(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_defer_resolve needs a scene (neb_gi_set_scene)");
+        return NEB_OK;
+    }
     if (!strcmp(key, "gi_debug_hits")) {
         if (gi_set_debug_hits(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_debug_hits needs a scene (neb_gi_set_scene)");

@@ -97,6 +97,8 @@ struct GiState {
     bool debug_hits = false;
     float4* d_records = nullptr; // 7 float4 planes over the resident pixels (GiRecords)
     unsigned long long last_stats[8] = {};
+    bool defer_resolve = false;
+    uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
     uint32_t* d_block_counts = nullptr; // [2][n_block_counts]: bounce / shadow rays per workgroup
     size_t n_block_counts = 0;
 };
@@ -640,6 +642,7 @@ struct GiArgs {
     uint32_t sample;             // index of the sample this launch handles
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
     uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
+    uint32_t defer_resolve;      // 1: leave the frame's sum in R.sum; neb_gi_resolve adds it into radiance[cur] later
 };
 
 __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(64) void gi_shadow_trace_kernel(GiArgs a)
         }
     }
     const bool last_vertex = a.bounce + 1 >= a.c.maxPathVertices;
-    if (a.sample + 1 == a.c.samplesPerPixel && last_vertex) { // stands in for NRC Resolve: radiance[cur] += mean over spp
+    if (a.sample + 1 == a.c.samplesPerPixel && last_vertex && !a.defer_resolve) { // stands in for NRC Resolve: radiance[cur] += mean over spp
         const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
         float4 r = a.radiance[i];
         r.x += sum.x * inv_spp;
@@ -956,6 +959,23 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
     a.normal[i] = make_uint2(float_to_half_bits(egn.x) | (float_to_half_bits(egn.y) << 16),
                              float_to_half_bits(esn.x) | (float_to_half_bits(esn.y) << 16));
     a.depth[i] = ds;
+}
+
+// The reference adds the indirect term into radiance[cur] in a separate step (nrc Resolve, DeferredRenderer.cpp:586).
+// neb_gi_resolve is that step when the trace ran with "gi_defer_resolve": it lets a caller overlap the GI stages of
+// frame f+1 (which touch only the G-buffer and the GI records) with the SVGF passes of frame f on another stream.
+__global__ __launch_bounds__(256) void gi_resolve_kernel(float4* __restrict__ radiance, const float4* __restrict__ sum, size_t first, size_t n,
+                                                         float inv_spp)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n)
+        return;
+    const float4 s = sum[first + k];
+    float4 r = radiance[first + k];
+    r.x += s.x * inv_spp;
+    r.y += s.y * inv_spp;
+    r.z += s.z * inv_spp;
+    radiance[first + k] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1652,6 +1672,10 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     a.row1 = row1;
     a.tiles_x = (ctx->W + 7) / 8;
     a.stats = g->debug_hits ? 1u : 0u;
+    a.defer_resolve = g->defer_resolve ? 1u : 0u;
+    g->pending_spp = c->samplesPerPixel;
+    g->pending_row0 = row0;
+    g->pending_row1 = row1;
     const uint32_t tiles_y = (row1 - row0 + 7) / 8;
     const dim3 grid(a.tiles_x * tiles_y), block(64);
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
@@ -1678,6 +1702,23 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
         }
     }
+    GI_HIP(ctx, hipGetLastError());
+    return NEB_OK;
+}
+
+int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (!g || !g->d_records || !g->defer_resolve)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
+    if (g->pending_row1 <= g->pending_row0)
+        return NEB_OK;
+    const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
+    const size_t first = (size_t)(g->pending_row0 - ctx->row_begin) * ctx->W, n = (size_t)(g->pending_row1 - g->pending_row0) * ctx->W;
+    hipLaunchKernelGGL(gi_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], g->d_records + 6 * npx, first, n, 1.0f / (float)g->pending_spp);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
 }
@@ -1835,6 +1876,13 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
 } // extern "C"
 
 namespace neb {
+int gi_set_defer_resolve(neb_ctx* ctx, int on)
+{
+    if (!ctx->gi)
+        return NEB_ERR_STATE;
+    ctx->gi->defer_resolve = on != 0;
+    return NEB_OK;
+}
 int gi_set_debug_hits(neb_ctx* ctx, int on)
 {
     if (!ctx->gi)

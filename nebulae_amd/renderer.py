@@ -134,13 +134,21 @@ class DeferredRenderer:
         """SubmitCommandsHDRTonemapping (src/DeferredRenderer.cpp:616-660): radiance[cur] -> LDR plane (RGBA8)."""
         self._check(self._lib.neb_tonemap(self._ctx, C.c_void_p(self.info.stream)), "neb_tonemap")
 
-    def submit_commands_gi_pathtrace(self, rows=None):
+    def submit_commands_gi_pathtrace(self, rows=None, stream=None):
         c = self.global_constants()
+        st = C.c_void_p(self.info.stream if stream is None else stream)
         if rows is None:
-            rc = self._lib.neb_gi_trace(self._ctx, C.byref(c), C.c_void_p(self.info.stream))
+            rc = self._lib.neb_gi_trace(self._ctx, C.byref(c), st)
         else:
-            rc = self._lib.neb_gi_trace_rows(self._ctx, C.byref(c), rows[0], rows[1], C.c_void_p(self.info.stream))
+            rc = self._lib.neb_gi_trace_rows(self._ctx, C.byref(c), rows[0], rows[1], st)
         self._check(rc, "neb_gi_trace")
+
+    def set_defer_resolve(self, on=True):
+        """Split the GI dispatch as the reference does (QueryAndTrain ... then Resolve, DeferredRenderer.cpp:560,586)."""
+        self.svgf.set_option("gi_defer_resolve", int(on))
+
+    def submit_commands_gi_resolve(self, stream=None):
+        self._check(self._lib.neb_gi_resolve(self._ctx, C.c_void_p(self.info.stream if stream is None else stream)), "neb_gi_resolve")
 
     def submit_commands_svgf_denoising(self):
         if self.dynamic_scene_this_frame:  # :595

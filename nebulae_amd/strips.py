@@ -95,8 +95,8 @@ class StripRenderer(DeferredRenderer):
         base = self.svgf.row_begin
         return self._views[key][row0 - base:row1 - base]
 
-    def submit_commands_gi_pathtrace(self, rows=None):
-        super().submit_commands_gi_pathtrace(rows=self.part.owned(self.rank) if rows is None else rows)
+    def submit_commands_gi_pathtrace(self, rows=None, stream=None):
+        super().submit_commands_gi_pathtrace(rows=self.part.owned(self.rank) if rows is None else rows, stream=stream)
 
     def exchange_halo(self, level):
         """Swap the boundary rows of `level`'s source plane with the neighbouring strips."""

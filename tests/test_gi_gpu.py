@@ -209,3 +209,52 @@ def test_multi_bounce_matches_oracle(max_vertices, spp):
         assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 3e-3
         assert np.median(np.abs(got[..., :3] - want[..., :3])) <= 1e-6
     r.destroy()
+
+
+def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact():
+    """neb_gi_trace with "gi_defer_resolve" + neb_gi_resolve == the fused dispatch, and running the GI stages of frame
+    f+1 on a side stream while frame f is denoised gives the same frames bit for bit."""
+    import torch
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    outs = []
+    for mode in ("fused", "pipelined"):
+        r = DeferredRenderer()
+        r.init(W, H, atrous_levels=4)
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=main.cuda_stream))
+        r.submit_commands_gbuffer()
+        torch.cuda.synchronize()
+        from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL
+        for pl in (PLANE_NORMAL, PLANE_DEPTH):
+            r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
+        rad = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
+        direct = torch.full_like(rad[0], 0.125)
+        if mode == "pipelined":
+            r.set_defer_resolve(True)
+        resolved = None
+        for f in range(2, 9):
+            r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=main.cuda_stream))
+            cur = r.svgf.get_current_resource_index()
+            if mode == "pipelined":
+                if resolved is not None:
+                    side.wait_event(resolved)
+                r.submit_commands_gi_pathtrace(stream=side.cuda_stream)
+                rad[cur].copy_(direct, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+                main.wait_event(done)
+                r.submit_commands_gi_resolve()
+                resolved = torch.cuda.Event()
+                resolved.record(main)
+            else:
+                rad[cur].copy_(direct, non_blocking=True)
+                r.submit_commands_gi_pathtrace()
+            r.submit_commands_svgf_denoising()
+            r.end_frame()
+        torch.cuda.synchronize()
+        outs.append(r.svgf.download(PLANE_RADIANCE))
+        r.destroy()
+    assert float(np.abs(outs[0][..., :3]).max()) > 0.2
+    assert np.array_equal(outs[0], outs[1])
