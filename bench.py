@@ -173,7 +173,7 @@ def main():
     overlap = do_gi and args.overlap
     side = torch.cuda.Stream() if overlap else None
     resolved = [None]
-    if do_gi:
+    if overlap:
         r.set_defer_resolve(True)
 
     def step(timed_events=None):
@@ -183,16 +183,19 @@ def main():
         cur = r.svgf.get_current_resource_index()
         pipelined = overlap and timed_events is None
         gi_stream = side if pipelined else stream
+        if not overlap:  # PBR pass stand-in (overwrites radiance[cur]); the fused GI dispatch then adds into it
+            rad_view[cur].copy_(direct if do_gi else noisy_dev[f % 4], non_blocking=True)
+        if timed_events is not None:
+            timed_events["gi0"].record(stream)
         if do_gi:
             if pipelined and resolved[0] is not None:
                 side.wait_event(resolved[0])  # the previous frame's resolve has consumed the GI records
-            if timed_events is not None:
-                timed_events["gi0"].record(stream)
             r.submit_commands_gi_pathtrace(stream=gi_stream.cuda_stream)
-            if timed_events is not None:
-                timed_events["gi1"].record(stream)
-        rad_view[cur].copy_(direct if do_gi else noisy_dev[f % 4], non_blocking=True)  # PBR pass stand-in (overwrites)
-        if do_gi:
+        if timed_events is not None:
+            timed_events["gi1"].record(stream)
+        if overlap:
+            rad_view[cur].copy_(direct, non_blocking=True)
+        if overlap:
             if pipelined:
                 done = torch.cuda.Event()
                 done.record(side)
