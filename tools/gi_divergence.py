@@ -1,0 +1,30 @@
+"""Diagnostics: how much of a wave's traversal is idle lanes, and what would direction binning recover?
+Per-ray loop iterations come from the debug hit records; waves are then re-formed on the host."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from nebulae_amd import scene as S
+from nebulae_amd.renderer import DeferredRenderer, RenderInfo
+W, H = 1920, 1080
+sc, cam = S.atrium_standin(), S.sponza_camera()
+r = DeferredRenderer(); r.init(W, H, atrous_levels=5)
+r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+r.submit_commands_gbuffer(); r.set_debug_hits(True); r.submit_commands_gi_pathtrace()
+hits = r.download_hits()
+it = (hits["flags"] >> 8).astype(np.int64)
+def wave_cost(order_it):
+    w = order_it[: (order_it.size // 64) * 64].reshape(-1, 64)
+    return w.max(axis=1).sum(), w.sum() / 64.0
+# (a) as launched: 8x8 tiles
+t = it[: (H // 8) * 8, : (W // 8) * 8].reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1)
+mx, mean = wave_cost(t)
+print("8x8 tiles: sum of wave maxima %.3e vs sum of lane means %.3e -> lane utilisation %.2f" % (mx, mean, mean / mx))
+# (b) oracle-best: sort rays globally by their own iteration count (upper bound of any reordering)
+mx2, _ = wave_cost(np.sort(it.reshape(-1)))
+print("perfect sort by cost: utilisation %.2f (gain x%.2f)" % (mean / mx2, mx / mx2))
+# (c) binning by iteration count inside 32x32 blocks (what an in-block reorder could at best do)
+b = it[: (H // 32) * 32, : (W // 32) * 32].reshape(H // 32, 32, W // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 1024)
+mx3 = np.sort(b, axis=1).reshape(-1, 64).max(axis=1).sum()
+mx3_base = b.reshape(-1, 16, 64)
+print("sorted inside 32x32 blocks: gain x%.2f" % (wave_cost(t)[0] / (mx3 * (t.size / b.size))))
+print("iterations per ray: mean %.1f p50 %d p90 %d p99 %d max %d" % (it.mean(), np.percentile(it, 50), np.percentile(it, 90), np.percentile(it, 99), it.max()))
