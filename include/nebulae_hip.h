@@ -184,7 +184,7 @@ typedef struct neb_gi_hit {
     float t;            /* < 0: miss */
     uint32_t geometry;  /* GeometryIndex() */
     uint32_t primitive; /* PrimitiveIndex() */
-    uint32_t flags;     /* bit 0: sun shadow ray unoccluded */
+    uint32_t flags;     /* bit 0: sun shadow ray unoccluded; bits 8..31: traversal iterations of the bounce ray (diagnostics) */
 } neb_gi_hit;
 
 typedef struct neb_camera {

@@ -206,11 +206,6 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
         ctx->atrous_variant = value;
         return NEB_OK;
     }
-    if (!strcmp(key, "gi_rays_per_lane")) {
-        if (gi_set_rays_per_lane(ctx, value) != NEB_OK)
-            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_rays_per_lane needs a scene and 1 <= value <= 64");
-        return NEB_OK;
-    }
     if (!strcmp(key, "gi_defer_resolve")) {
         if (gi_set_defer_resolve(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_defer_resolve needs a scene (neb_gi_set_scene)");

@@ -98,7 +98,6 @@ struct GiState {
     float4* d_records = nullptr; // 7 float4 planes over the resident pixels (GiRecords)
     unsigned long long last_stats[8] = {};
     bool defer_resolve = false;
-    uint32_t rays_per_lane = 1; // > 1: gi_trace_multi_kernel
     uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
     uint32_t* d_block_counts = nullptr; // [2][n_block_counts]: bounce / shadow rays per workgroup
     size_t n_block_counts = 0;
@@ -644,7 +643,6 @@ struct GiArgs {
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
     uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
     uint32_t defer_resolve;      // 1: leave the frame's sum in R.sum; neb_gi_resolve adds it into radiance[cur] later
-    uint32_t raygen_only;        // 1: gi_raygen_trace_kernel only writes the ray record (a multi-ray tracer follows)
 };
 
 __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
@@ -708,9 +706,9 @@ __global__ __launch_bounds__(64) void gi_raygen_trace_kernel(GiArgs a)
         a.R.ray_d[i] = make_float4(dir.x, dir.y, dir.z, bounce ? 1.0f : 0.0f);
         a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
         float4 h = make_float4(bounce ? -1.0f : -2.0f, 0.f, 0.f, 0.f); // -2: no bounce at all, nothing is added
-        rays = bounce ? 1u : 0u;
-        if (bounce && !a.raygen_only) {
+        if (bounce) {
             Hit hit;
+            rays = 1;
             if (traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit))
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only
@@ -823,7 +821,7 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
         a.R.sum[i] = sum;
         if (a.hits && a.bounce == 1) {
             if (a.stats)
-                dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray
+                dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py)
             a.hits[i] = dbg;
         }
     }
@@ -966,183 +964,6 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
     a.normal[i] = make_uint2(float_to_half_bits(egn.x) | (float_to_half_bits(egn.y) << 16),
                              float_to_half_bits(esn.x) | (float_to_half_bits(esn.y) << 16));
     a.depth[i] = ds;
-}
-
-// K rays per lane, back to back ("gi_rays_per_lane" > 1).  Rays of one wave need very different numbers of
-// traversal iterations (mean 19, wave maximum ~34 on sponza-standin): with one ray per lane 45 % of the lane-iterations
-// are idle.  Here a lane that finishes its ray immediately starts its next one (its pixel in the wave's next 8x8
-// tile) without leaving the loop -- no ballots, queues or atomics -- so a wave's cost is the maximum over lanes of a
-// SUM of K ray costs, whose relative spread is ~1/sqrt(K) of a single ray's.
-template <bool ANY_HIT>
-__global__ __launch_bounds__(64) void gi_trace_multi_kernel(GiArgs a, uint32_t n_tiles, uint32_t K)
-{
-    __shared__ int stack_mem[kLdsStack * 64];
-    const uint32_t lane = threadIdx.x;
-    TravStack st;
-    st.lds = stack_mem + lane;
-    uint32_t tile = blockIdx.x * K;
-    const uint32_t tile_end = min(tile + K, n_tiles);
-    size_t pix = 0;
-    float3 o = f3(0, 0, 0), d = f3(0, 0, 1), inv = f3(0, 0, 0), oinv = f3(0, 0, 0);
-    float tmin = 0.f;
-    Hit hit;
-    hit.t = 0.f;
-    hit.u = hit.v = 0.f;
-    hit.tri = ~0u;
-    hit.node_visits = hit.tri_tests = 0;
-    bool found = false;
-    int node = kTravDone;
-    uint32_t rays = 0;
-
-    auto finish = [&](bool had_ray) {
-        if (ANY_HIT) {
-            float4 sum = a.R.sum[pix];
-            if (had_ray && !found) { // unoccluded: radiance += BRDF * sunRadiance * throughput (:571-575)
-                const float4 c = a.R.contrib[pix];
-                sum.x += c.x;
-                sum.y += c.y;
-                sum.z += c.z;
-                if (a.hits && a.bounce == 1)
-                    a.hits[pix].flags |= 1u;
-            }
-            const bool last_vertex = a.bounce + 1 >= a.c.maxPathVertices;
-            if (a.sample + 1 == a.c.samplesPerPixel && last_vertex && !a.defer_resolve) {
-                const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
-                float4 r = a.radiance[pix];
-                r.x += sum.x * inv_spp;
-                r.y += sum.y * inv_spp;
-                r.z += sum.z * inv_spp;
-                a.radiance[pix] = r;
-            } else {
-                a.R.sum[pix] = sum;
-            }
-        } else if (had_ray) {
-            a.R.hit[pix] = found ? make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri)) : make_float4(-1.0f, 0.f, 0.f, 0.f);
-        }
-    };
-    // Ray records are prefetched one ray ahead: when a lane finishes a ray mid-loop, switching to the next one must
-    // not make the whole wave wait for a memory round trip (in-order issue: 64 x (K-1) such stalls per wave otherwise).
-    float4 nro = make_float4(0.f, 0.f, 0.f, 0.f), nrd = make_float4(0.f, 0.f, 0.f, 0.f);
-    size_t npix = 0;
-    bool nhave = false;
-    auto prefetch = [&]() {
-        nhave = false;
-        while (tile < tile_end) {
-            const uint32_t x = (tile % a.tiles_x) * 8u + (lane & 7u), y = a.row0 + (tile / a.tiles_x) * 8u + (lane >> 3);
-            tile++;
-            if (x >= a.W || y >= a.row1)
-                continue;
-            npix = (size_t)(y - a.row_begin) * a.W + x;
-            nrd = ANY_HIT ? a.R.sray_d[npix] : a.R.ray_d[npix];
-            nro = ANY_HIT ? a.R.sray_o[npix] : a.R.ray_o[npix];
-            nhave = true;
-            return;
-        }
-    };
-    // makes the prefetched ray current (and prefetches the one after); false when the lane has no pixel left
-    auto fetch = [&]() -> bool {
-        while (nhave) {
-            pix = npix;
-            const float4 ro = nro, rd = nrd;
-            prefetch();
-            found = false;
-            if (rd.w != 0.0f && a.S.n_tris != 0) {
-                o = f3(ro.x, ro.y, ro.z);
-                d = f3(rd.x, rd.y, rd.z);
-                inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-                tmin = ro.w;
-                hit.t = kTraceMax;
-                hit.tri = ~0u;
-                st.sp = 0;
-                node = a.S.root;
-                rays++;
-                return true;
-            }
-            finish(rd.w != 0.0f); // no ray for this pixel (or an empty scene: every ray misses)
-        }
-        return false;
-    };
-    prefetch();
-
-    if (fetch()) {
-        for (;;) {
-            if (node >= 0) {
-                const Bvh4Node* n = a.S.nodes + node;
-                const float4 lox = n->lox, loy = n->loy, loz = n->loz, hix = n->hix, hiy = n->hiy, hiz = n->hiz;
-                const int4 ch = n->child;
-                uint32_t k0 = slab_key(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, inv, oinv, tmin, hit.t, 0u);
-                uint32_t k1 = slab_key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, inv, oinv, tmin, hit.t, 1u);
-                uint32_t k2 = slab_key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, inv, oinv, tmin, hit.t, 2u);
-                uint32_t k3 = slab_key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, inv, oinv, tmin, hit.t, 3u);
-                if (!ANY_HIT) {
-                    cswap(k0, k1);
-                    cswap(k2, k3);
-                    cswap(k0, k2);
-                    cswap(k1, k3);
-                    cswap(k1, k2);
-                }
-                auto child_of = [&](uint32_t key) -> int {
-                    const uint32_t sl = key & 3u;
-                    return sl == 0u ? ch.x : (sl == 1u ? ch.y : (sl == 2u ? ch.z : ch.w));
-                };
-                node = kTravDone;
-                if (!ANY_HIT) {
-                    if (k0 != 0xffffffffu) {
-                        if (k3 != 0xffffffffu)
-                            st.push(child_of(k3));
-                        if (k2 != 0xffffffffu)
-                            st.push(child_of(k2));
-                        if (k1 != 0xffffffffu)
-                            st.push(child_of(k1));
-                        node = child_of(k0);
-                    }
-                } else {
-                    if (k3 != 0xffffffffu)
-                        node = ch.w;
-                    if (k2 != 0xffffffffu) {
-                        if (node != kTravDone)
-                            st.push(node);
-                        node = ch.z;
-                    }
-                    if (k1 != 0xffffffffu) {
-                        if (node != kTravDone)
-                            st.push(node);
-                        node = ch.y;
-                    }
-                    if (k0 != 0xffffffffu) {
-                        if (node != kTravDone)
-                            st.push(node);
-                        node = ch.x;
-                    }
-                }
-                if (node == kTravDone && st.sp)
-                    node = st.pop();
-            }
-            if (node < 0 && node != kTravDone) {
-                const uint32_t code = (uint32_t)~node;
-                const uint32_t first = code >> 2, count = (code & 3u) + 1u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    float t, u, v;
-                    if (intersect_tri(a.S.tris, first + k, o, d, tmin, hit.t, t, u, v)) {
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        hit.tri = first + k;
-                        found = true;
-                    }
-                }
-                node = (ANY_HIT && found) ? kTravDone : (st.sp ? st.pop() : kTravDone);
-            }
-            if (node == kTravDone) {
-                finish(true);
-                if (!fetch())
-                    break;
-            }
-        }
-    }
-    if (!ANY_HIT && a.bounce > 1) // vertex-1 rays are counted by the ray generator
-        count_rays(a.bounce_counts, rays);
 }
 
 // The reference adds the indirect term into radiance[cur] in a separate step (nrc Resolve, DeferredRenderer.cpp:586).
@@ -1878,21 +1699,12 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         a.sample = s;
         for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
             a.bounce = b;
-            const uint32_t K = g->rays_per_lane;
-            const uint32_t n_tiles = a.tiles_x * tiles_y;
-            const dim3 mgrid((n_tiles + K - 1) / K);
-            a.raygen_only = K > 1 ? 1u : 0u;
             if (b == 1)
                 hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
-            if (K > 1)
-                hipLaunchKernelGGL(gi_trace_multi_kernel<false>, mgrid, block, 0, (hipStream_t)stream, a, n_tiles, K);
-            else if (b > 1)
+            else
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
-            if (K > 1)
-                hipLaunchKernelGGL(gi_trace_multi_kernel<true>, mgrid, block, 0, (hipStream_t)stream, a, n_tiles, K);
-            else
-                hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
         }
     }
     GI_HIP(ctx, hipGetLastError());
@@ -2069,13 +1881,6 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
 } // extern "C"
 
 namespace neb {
-int gi_set_rays_per_lane(neb_ctx* ctx, int k)
-{
-    if (!ctx->gi || k < 1 || k > 64)
-        return NEB_ERR_STATE;
-    ctx->gi->rays_per_lane = (uint32_t)k;
-    return NEB_OK;
-}
 int gi_set_defer_resolve(neb_ctx* ctx, int on)
 {
     if (!ctx->gi)

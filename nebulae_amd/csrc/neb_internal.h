@@ -35,7 +35,6 @@ struct GiState;               // gi.hip: scene tables, LBVH, counters
 void gi_destroy(GiState* g);
 int gi_set_debug_hits(neb_ctx* ctx, int on);
 int gi_set_defer_resolve(neb_ctx* ctx, int on);
-int gi_set_rays_per_lane(neb_ctx* ctx, int k);
 
 } // namespace neb
 
