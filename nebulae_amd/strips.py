@@ -87,6 +87,8 @@ class StripRenderer(DeferredRenderer):
         res0, res1 = part.resident(rank)
         self.init(part.W, part.H, atrous_levels=part.L, device=device, row_begin=res0, row_end=res1 if part.N > 1 else 0)
         self._views = {}
+        import os
+        self._staging = os.environ.get("NEB_STRIPS_STAGING") or None  # None | "host" | "device"
 
     def _plane_rows(self, plane, slot, row0, row1):
         key = (plane, slot)
@@ -105,23 +107,33 @@ class StripRenderer(DeferredRenderer):
         plan = self.part.level_exchange(self.rank, level)
         if not plan:
             return
+        import torch
         send = [self._plane_rows(sp, ss, s0, s1) for _, (s0, s1), _ in plan]
         recv = [self._plane_rows(sp, ss, r0, r1) for _, _, (r0, r1) in plan]
-        staged = send[0].is_cuda and dist.get_backend(self.group) == "gloo"
-        if staged:  # rehearsal on a box without RCCL peers: gloo moves host memory only, so stage the rows through it
-            import torch
+        # staging modes: None = zero copy (rows go straight out of / into the plane: the default on RCCL);
+        # "host" = through host memory (gloo rehearsal on a box without RCCL peers);
+        # "device" = through torch-allocated device buffers (NEB_STRIPS_STAGING=device: for RCCL builds that insist on
+        # memory from the framework's allocator; the planes are hipMalloc'ed by the context and only viewed by torch)
+        mode = self._staging
+        if mode is None and send[0].is_cuda and dist.get_backend(self.group) == "gloo":
+            mode = "host"
+        dst = recv
+        if mode == "host":
             torch.cuda.current_stream().synchronize()
             send = [t.cpu() for t in send]
-            host = [torch.empty(t.shape, dtype=t.dtype) for t in recv]
+            dst = [torch.empty(t.shape, dtype=t.dtype) for t in recv]
+        elif mode == "device":
+            send = [t.clone() for t in send]
+            dst = [torch.empty_like(t) for t in recv]
         ops = []
         for k, (peer, _, _) in enumerate(plan):
             ops.append(dist.P2POp(dist.isend, send[k], peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, host[k] if staged else recv[k], peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, dst[k], peer, group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        if staged:
-            for dst, src in zip(recv, host):
-                dst.copy_(src)
+        if mode is not None:
+            for d, s_ in zip(recv, dst):
+                d.copy_(s_)
 
     def submit_commands_svgf_denoising(self, events=None):
         if self.dynamic_scene_this_frame:  # src/DeferredRenderer.cpp:595
