@@ -43,7 +43,7 @@ struct DevMat {
     float rough, metal;
 };
 struct DevTex {
-    uint32_t offset; // in texels, into the RGBA8 pool
+    uint32_t offset; // in footprint entries (16 B), into the texel pool
     uint32_t w, h, pad;
 };
 // 64-byte BVH2 node: both children's boxes live in the parent, so one node fetch decides both.
@@ -78,7 +78,7 @@ struct SceneView {
     const float* normals;    // 3 per vertex
     const float* uvs;        // 2 per vertex
     const float* tangents;   // 4 per vertex
-    const uint32_t* texels;  // RGBA8
+    const uint32_t* texels;  // RGBA8 bilinear footprint table: 4 texels (16 B) per texel position, see sample_texture
     const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
     uint32_t n_tris;
     int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
@@ -478,9 +478,10 @@ __device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
         x0 += W;
     if (y0 < 0)
         y0 += H;
-    const int x1 = (x0 + 1) % W, y1 = (y0 + 1) % H;
-    const uint32_t* px = S.texels + t.offset;
-    const uint32_t p00 = px[y0 * W + x0], p10 = px[y0 * W + x1], p01 = px[y1 * W + x0], p11 = px[y1 * W + x1];
+    // bilinear footprint table: entry (x0, y0) holds the four texels {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} with the
+    // wrap already applied, so a filtered fetch is ONE 16-byte load instead of four scattered dwords
+    const uint4 fp = reinterpret_cast<const uint4*>(S.texels)[(size_t)t.offset + (size_t)y0 * W + x0];
+    const uint32_t p00 = fp.x, p10 = fp.y, p01 = fp.z, p11 = fp.w;
     float r[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1354,12 +1355,25 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
             delete g;
             return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_set_scene: empty texture");
         }
-        dtexs[i].offset = (uint32_t)texels.size();
+        dtexs[i].offset = (uint32_t)(texels.size() / 4); // in footprint entries (uint4)
         dtexs[i].w = texs[i].width;
         dtexs[i].h = texs[i].height;
         dtexs[i].pad = 0;
         const uint32_t* px = (const uint32_t*)texs[i].rgba8;
-        texels.insert(texels.end(), px, px + (size_t)texs[i].width * texs[i].height);
+        const uint32_t tw = texs[i].width, th = texs[i].height;
+        const size_t base = texels.size();
+        texels.resize(base + (size_t)tw * th * 4);
+        for (uint32_t y = 0; y < th; ++y) {
+            const uint32_t y1 = (y + 1) % th;
+            for (uint32_t x = 0; x < tw; ++x) {
+                const uint32_t x1 = (x + 1) % tw;
+                uint32_t* q = &texels[base + ((size_t)y * tw + x) * 4];
+                q[0] = px[(size_t)y * tw + x];
+                q[1] = px[(size_t)y * tw + x1];
+                q[2] = px[(size_t)y1 * tw + x];
+                q[3] = px[(size_t)y1 * tw + x1];
+            }
+        }
     }
     g->n_tris = (uint32_t)(g->h_tris.size() / 12);
     memcpy(g->scene_min, smin, sizeof(smin));
