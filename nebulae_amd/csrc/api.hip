@@ -132,6 +132,7 @@ int neb_resize(neb_ctx* ctx, uint32_t width, uint32_t height)
     NEB_HIP(ctx, hipSetDevice(ctx->device));
     NEB_HIP(ctx, hipDeviceSynchronize());
     free_planes(ctx);
+    gi_on_resize(ctx->gi);
     ctx->W = width;
     ctx->H = height;
     ctx->row_begin = 0;

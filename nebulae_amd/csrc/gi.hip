@@ -103,6 +103,28 @@ struct GiState {
     size_t n_block_counts = 0;
 };
 
+// neb_resize: the per-pixel GI buffers (records, debug hits, per-workgroup counters) belong to the old resolution
+void gi_on_resize(GiState* g)
+{
+    if (!g)
+        return;
+    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts};
+    for (void* p : stale) {
+        if (!p)
+            continue;
+        for (size_t k = 0; k < g->allocs.size(); ++k)
+            if (g->allocs[k] == p) {
+                g->allocs.erase(g->allocs.begin() + (long)k);
+                break;
+            }
+        (void)hipFree(p);
+    }
+    g->d_records = nullptr;
+    g->d_hits = nullptr;
+    g->d_block_counts = nullptr;
+    g->n_block_counts = 0;
+}
+
 void gi_destroy(GiState* g)
 {
     if (!g)

@@ -33,6 +33,7 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
 
 struct GiState;               // gi.hip: scene tables, LBVH, counters
 void gi_destroy(GiState* g);
+void gi_on_resize(GiState* g);
 int gi_set_debug_hits(neb_ctx* ctx, int on);
 int gi_set_defer_resolve(neb_ctx* ctx, int on);
 

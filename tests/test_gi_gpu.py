@@ -258,3 +258,32 @@ def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact():
         r.destroy()
     assert float(np.abs(outs[0][..., :3]).max()) > 0.2
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_resize_recreates_planes_and_gi_buffers():
+    """SVGFDenoiser::Resize re-creates (zeroes) the resources (src/SVGFDenoiser.cpp:28-37); after it a frame at the new
+    size must equal the same frame on a fresh context."""
+    sc = S.cornell_standin(textured=True)
+    cam = S.orbit_camera()
+    a = DeferredRenderer()
+    a.init(96, 64, atrous_levels=3)
+    a.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    a.submit_commands_gbuffer()
+    a.submit_commands_gi_pathtrace()
+    a.svgf.resize(160, 120)
+    a.width, a.height = 160, 120
+    b = DeferredRenderer()
+    b.init(160, 120, atrous_levels=3)
+    b.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))  # same dynamic-scene / reset-history state as `a`
+    for r in (a, b):
+        for f in (4, 5, 6):
+            r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f))
+            r.submit_commands_gbuffer()
+            r.submit_commands_pbr_lighting()
+            r.submit_commands_gi_pathtrace()
+            r.submit_commands_svgf_denoising()
+    ga, gb_ = a.svgf.download(PLANE_RADIANCE), b.svgf.download(PLANE_RADIANCE)
+    assert ga.shape == (120, 160, 4) and float(np.abs(ga[..., :3]).max()) > 0
+    assert np.array_equal(ga, gb_)
+    a.destroy()
+    b.destroy()
