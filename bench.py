@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--triangles", type=int, default=262267)
     ap.add_argument("--cpu-frames", type=int, default=3, help="SVGF frames of the CPU oracle to time (0 = skip the CPU leg)")
     ap.add_argument("--svgf-only", action="store_true", help="skip the GI dispatch (synthetic noisy radiance instead)")
+    ap.add_argument("--sort-rays", type=int, default=-1, help="GI ray sorting mask: bit 0 shadow rays, bit 1 bounce rays (-1 = library default)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the GI stages of frame f+1 on a side stream while frame f is denoised (measured: +1 %%, off by default)")
     return ap.parse_args()
@@ -155,6 +156,8 @@ def main():
     for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: the other slot holds the same G-buffer
         r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
     rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
+    if args.sort_rays >= 0:
+        r.svgf.set_option("gi_sort_rays", args.sort_rays)
     r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
     torch.cuda.synchronize()
     direct = rad_view[r.svgf.get_current_resource_index()].clone()

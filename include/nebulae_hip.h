@@ -100,6 +100,8 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "atrous_variant": 1 = LDS row-lattice kernel (default; 4 rows per lane for steps <= 4, 2 for wider steps),
  *                     2 / 3 = LDS kernel with 2 / 4 rows per lane everywhere, 0 = direct-load kernel;
  *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene);
+ *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (default on),
+ *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
  *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 

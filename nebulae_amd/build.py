@@ -28,7 +28,8 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    extra = os.environ.get("NEB_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds only (e.g. -DNEB_SORT_BITS=16)
+    cmd = [_hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

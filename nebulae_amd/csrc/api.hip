@@ -207,6 +207,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
         ctx->atrous_variant = value;
         return NEB_OK;
     }
+    if (!strcmp(key, "gi_sort_rays")) {
+        if (gi_set_sort_rays(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sort_rays needs a scene and a mask 0..3 (bit 0 shadow rays, bit 1 bounce rays)");
+        return NEB_OK;
+    }
     if (!strcmp(key, "gi_defer_resolve")) {
         if (gi_set_defer_resolve(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_defer_resolve needs a scene (neb_gi_set_scene)");

@@ -98,6 +98,11 @@ struct GiState {
     float4* d_records = nullptr; // 7 float4 planes over the resident pixels (GiRecords)
     unsigned long long last_stats[8] = {};
     bool defer_resolve = false;
+    bool sort_shadow = true;  // "gi_sort_rays" bit 0
+    bool sort_bounce = false; // "gi_sort_rays" bit 1
+    uint32_t* d_sort = nullptr;      // 4 x npx uint32: keys, vals, keys_out, vals_out
+    void* d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
     uint32_t* d_block_counts = nullptr; // [2][n_block_counts]: bounce / shadow rays per workgroup
     size_t n_block_counts = 0;
@@ -108,7 +113,7 @@ void gi_on_resize(GiState* g)
 {
     if (!g)
         return;
-    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts};
+    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts, g->d_sort, g->d_sort_temp};
     for (void* p : stale) {
         if (!p)
             continue;
@@ -123,6 +128,8 @@ void gi_on_resize(GiState* g)
     g->d_hits = nullptr;
     g->d_block_counts = nullptr;
     g->n_block_counts = 0;
+    g->d_sort = nullptr;
+    g->d_sort_temp = nullptr;
 }
 
 void gi_destroy(GiState* g)
@@ -636,6 +643,37 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
 // Splitting keeps the two traversal kernels at 60-66 VGPRs (7-8 waves/SIMD) and the register-hungry shading
 // away from them.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t morton30(float3 p, const float* smin, const float* sinv)
+{
+    const uint32_t qx = (uint32_t)fminf(fmaxf((p.x - smin[0]) * sinv[0] * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf((p.y - smin[1]) * sinv[1] * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf((p.z - smin[2]) * sinv[2] * 1024.0f, 0.0f), 1023.0f);
+    return (expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz);
+}
+
+// Radix-sort key width for ray ordering: the top kSortBits bits of the 30-bit Morton code of the ray origin
+// (each 8 bits are one onesweep pass over the keys).
+#ifndef NEB_SORT_BITS
+#define NEB_SORT_BITS 24
+#endif
+constexpr int kSortBits = NEB_SORT_BITS;
+
+__device__ __forceinline__ uint32_t bounce_sort_key(float3 o, float3 d, const float* smin, const float* sinv)
+{
+    const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+    const uint32_t key = (oct << (kSortBits - 3)) | (morton30(o, smin, sinv) >> (30 - (kSortBits - 3)));
+    return min(key, (1u << kSortBits) - 2u);
+}
+
 struct GiRecords {
     float4* ray_o;   // {origin.xyz, tmin}      bounce ray of the path
     float4* ray_d;   // {direction.xyz, alive}  alive = 1: the path continues with this ray
@@ -666,6 +704,14 @@ struct GiArgs {
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
     uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
     uint32_t defer_resolve;      // 1: leave the frame's sum in R.sum; neb_gi_resolve adds it into radiance[cur] later
+    uint32_t* sort_keys;         // shadow-ray sorting ("gi_sort_shadow_rays"): Morton key of the ray origin per pixel, or null
+    uint32_t* sort_vals;         // pixel index per key
+    const uint32_t* sort_order;  // pixel indices in key order (after the radix sort), or null: pixel order
+    uint32_t* bsort_keys;        // same for the bounce rays ("gi_sort_rays" bit 1): key = direction octant | origin Morton code
+    uint32_t* bsort_vals;
+    uint32_t raygen_only;        // 1: gi_raygen_trace_kernel only writes the ray record and its key (a sorted trace follows)
+    float smin[3], sinv[3];      // scene box for the Morton keys
+    uint32_t first_px, n_px;     // dispatched pixel range [first_px, first_px + n_px) of the resident planes
 };
 
 __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
@@ -729,9 +775,13 @@ __global__ __launch_bounds__(64) void gi_raygen_trace_kernel(GiArgs a)
         a.R.ray_d[i] = make_float4(dir.x, dir.y, dir.z, bounce ? 1.0f : 0.0f);
         a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
         float4 h = make_float4(bounce ? -1.0f : -2.0f, 0.f, 0.f, 0.f); // -2: no bounce at all, nothing is added
-        if (bounce) {
+        rays = bounce ? 1u : 0u;
+        if (a.bsort_keys) {
+            a.bsort_keys[i] = bounce ? bounce_sort_key(org, dir, a.smin, a.sinv) : (1u << kSortBits) - 1u;
+            a.bsort_vals[i] = (uint32_t)i;
+        }
+        if (bounce && !a.raygen_only) {
             Hit hit;
-            rays = 1;
             if (traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit))
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only
@@ -750,8 +800,16 @@ __global__ __launch_bounds__(64) void gi_bounce_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
     uint32_t x, y;
-    size_t i;
-    const bool active = gi_pixel(a, x, y, i);
+    size_t i = 0;
+    bool active;
+    if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
+        const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+        active = j < a.n_px;
+        if (active)
+            i = a.sort_order[j];
+    } else {
+        active = gi_pixel(a, x, y, i);
+    }
     uint32_t rays = 0;
     if (active) {
         const float4 rd = a.R.ray_d[i];
@@ -765,7 +823,8 @@ __global__ __launch_bounds__(64) void gi_bounce_trace_kernel(GiArgs a)
             a.R.hit[i] = h;
         }
     }
-    count_rays(a.bounce_counts, rays);
+    if (a.bounce > 1) // vertex-1 rays are counted by the ray generator
+        count_rays(a.bounce_counts, rays);
 }
 
 __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
@@ -842,6 +901,24 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
         a.R.ray_d[i] = next_d;
         a.R.sray_d[i] = shadow_d;
         a.R.sum[i] = sum;
+        if (a.sort_keys) { // shadow rays are all (nearly) parallel: grouping them by origin makes a wave's rays walk the same nodes
+            uint32_t key = (1u << kSortBits) - 1u; // pixels without a shadow ray sort last
+            if (shadow_d.w != 0.0f) {
+                const float4 so4 = a.R.sray_o[i];
+                key = min(morton30(f3(so4.x, so4.y, so4.z), a.smin, a.sinv) >> (30 - kSortBits), (1u << kSortBits) - 2u);
+            }
+            a.sort_keys[i] = key;
+            a.sort_vals[i] = (uint32_t)i;
+        }
+        if (a.bsort_keys) { // next bounce ray: direction octant, then origin
+            uint32_t key = (1u << kSortBits) - 1u;
+            if (next_d.w != 0.0f) {
+                const float4 no4 = a.R.ray_o[i];
+                key = bounce_sort_key(f3(no4.x, no4.y, no4.z), f3(next_d.x, next_d.y, next_d.z), a.smin, a.sinv);
+            }
+            a.bsort_keys[i] = key;
+            a.bsort_vals[i] = (uint32_t)i;
+        }
         if (a.hits && a.bounce == 1) {
             if (a.stats)
                 dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py)
@@ -859,8 +936,14 @@ __global__ __launch_bounds__(64) void gi_shadow_trace_kernel(GiArgs a)
     __shared__ int stack_mem[kLdsStack * 64];
     uint32_t x, y;
     size_t i;
-    if (!gi_pixel(a, x, y, i))
+    if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
+        const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+        if (j >= a.n_px)
+            return;
+        i = a.sort_order[j];
+    } else if (!gi_pixel(a, x, y, i)) {
         return;
+    }
     const float4 rd = a.R.sray_d[i];
     float4 sum = a.R.sum[i];
     if (rd.w != 0.0f) {
@@ -1087,15 +1170,6 @@ __global__ __launch_bounds__(256) void tonemap_kernel(const float4* __restrict__
 // ------------------------------------------------------------------------------------------------
 // LBVH build (Karras 2012): Morton keys -> radix sort -> hierarchy -> bottom-up refit
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
-{
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-
 __global__ void lbvh_morton_kernel(const float* __restrict__ tris12, uint32_t n, float3 smin, float3 sinv, uint64_t* keys)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1713,6 +1787,40 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     a.row1 = row1;
     a.tiles_x = (ctx->W + 7) / 8;
     a.stats = g->debug_hits ? 1u : 0u;
+    a.sort_keys = a.sort_vals = nullptr;
+    a.sort_order = nullptr;
+    a.first_px = (uint32_t)((size_t)(row0 - ctx->row_begin) * ctx->W);
+    a.n_px = (uint32_t)((size_t)(row1 - row0) * ctx->W);
+    for (int q = 0; q < 3; ++q) {
+        a.smin[q] = g->scene_min[q];
+        a.sinv[q] = 1.0f / fmaxf(g->scene_max[q] - g->scene_min[q], 1e-20f);
+    }
+    a.bsort_keys = a.bsort_vals = nullptr;
+    a.raygen_only = 0;
+    if (g->sort_shadow || g->sort_bounce) {
+        if (!g->d_sort) {
+            void* p = nullptr;
+            GI_HIP(ctx, hipMalloc(&p, 8 * npx * sizeof(uint32_t))); // {keys, vals, keys_out, vals_out} x {shadow, bounce}
+            g->allocs.push_back(p);
+            g->d_sort = (uint32_t*)p;
+            size_t bytes = 0;
+            GI_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, g->d_sort, g->d_sort + 2 * npx, g->d_sort + npx, g->d_sort + 3 * npx,
+                                                             (int)npx, 0, kSortBits, (hipStream_t)stream));
+            GI_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
+            g->allocs.push_back(p);
+            g->d_sort_temp = p;
+            g->sort_temp_bytes = bytes;
+        }
+        if (g->sort_shadow) {
+            a.sort_keys = g->d_sort;
+            a.sort_vals = g->d_sort + npx;
+        }
+        if (g->sort_bounce) {
+            a.bsort_keys = g->d_sort + 4 * npx;
+            a.bsort_vals = g->d_sort + 5 * npx;
+            a.raygen_only = 1;
+        }
+    }
     a.defer_resolve = g->defer_resolve ? 1u : 0u;
     g->pending_spp = c->samplesPerPixel;
     g->pending_row0 = row0;
@@ -1737,10 +1845,29 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             a.bounce = b;
             if (b == 1)
                 hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
-            else
+            if (g->sort_bounce) {
+                size_t bytes = g->sort_temp_bytes;
+                uint32_t* bs = g->d_sort + 4 * npx;
+                GI_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(g->d_sort_temp, bytes, bs + a.first_px, bs + 2 * npx + a.first_px, bs + npx + a.first_px,
+                                                                 bs + 3 * npx + a.first_px, (int)a.n_px, 0, kSortBits, (hipStream_t)stream));
+                GiArgs b1 = a;
+                b1.sort_order = bs + 3 * npx + a.first_px;
+                hipLaunchKernelGGL(gi_bounce_trace_kernel, dim3((a.n_px + 63) / 64), block, 0, (hipStream_t)stream, b1);
+            } else if (b > 1) {
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+            }
             hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
-            hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+            if (g->sort_shadow) {
+                size_t bytes = g->sort_temp_bytes;
+                GI_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(g->d_sort_temp, bytes, g->d_sort + a.first_px, g->d_sort + 2 * npx + a.first_px,
+                                                                 g->d_sort + npx + a.first_px, g->d_sort + 3 * npx + a.first_px, (int)a.n_px, 0, kSortBits,
+                                                                 (hipStream_t)stream));
+                GiArgs b2 = a;
+                b2.sort_order = g->d_sort + 3 * npx + a.first_px;
+                hipLaunchKernelGGL(gi_shadow_trace_kernel, dim3((a.n_px + 63) / 64), block, 0, (hipStream_t)stream, b2);
+            } else {
+                hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+            }
         }
     }
     GI_HIP(ctx, hipGetLastError());
@@ -1917,6 +2044,14 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
 } // extern "C"
 
 namespace neb {
+int gi_set_sort_rays(neb_ctx* ctx, int mask)
+{
+    if (!ctx->gi || mask < 0 || mask > 3)
+        return NEB_ERR_STATE;
+    ctx->gi->sort_shadow = (mask & 1) != 0;
+    ctx->gi->sort_bounce = (mask & 2) != 0;
+    return NEB_OK;
+}
 int gi_set_defer_resolve(neb_ctx* ctx, int on)
 {
     if (!ctx->gi)

@@ -36,6 +36,7 @@ void gi_destroy(GiState* g);
 void gi_on_resize(GiState* g);
 int gi_set_debug_hits(neb_ctx* ctx, int on);
 int gi_set_defer_resolve(neb_ctx* ctx, int on);
+int gi_set_sort_rays(neb_ctx* ctx, int mask);
 
 } // namespace neb
 

@@ -35,8 +35,8 @@ def scenes():
 
 
 @pytest.mark.parametrize("name", ["cornell", "cornell_factors", "atrium_small"])
-@pytest.mark.parametrize("spp", [1, 3])
-def test_gi_matches_oracle(name, spp):
+@pytest.mark.parametrize("spp,sort_rays", [(1, 0), (3, 1), (1, 3), (2, 2)])
+def test_gi_matches_oracle(name, spp, sort_rays):
     make, cam, W, H = scenes()[name]
     sc = make()
     o = OracleTracer(sc)
@@ -51,6 +51,7 @@ def test_gi_matches_oracle(name, spp):
     base[..., 3] = 1.0
     r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, base)
     r.set_debug_hits(True)
+    r.svgf.set_option("gi_sort_rays", sort_rays)
     r.ray_count(reset=True)
     r.submit_commands_gi_pathtrace()
     got = r.svgf.download(PLANE_RADIANCE)
@@ -177,8 +178,9 @@ def test_direct_light_and_tonemap_match_oracle():
     r.destroy()
 
 
+@pytest.mark.parametrize("sort_rays", [1, 3])
 @pytest.mark.parametrize("max_vertices,spp", [(3, 1), (5, 2), (8, 1), (1, 1)])
-def test_multi_bounce_matches_oracle(max_vertices, spp):
+def test_multi_bounce_matches_oracle(max_vertices, spp, sort_rays):
     """Row f4: the shader's bounce loop (pathtracer.hlsl:495-621) with the NRC stubs, up to 8 path vertices, including the
     by-value rng of EvaluateIndirectBRDF.  maxPathVertices = 1 traces nothing and adds nothing."""
     make, cam, W, H = scenes()["cornell"]
@@ -193,6 +195,7 @@ def test_multi_bounce_matches_oracle(max_vertices, spp):
     upload_gbuffer(r, gb)
     r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
     r.set_debug_hits(True)
+    r.svgf.set_option("gi_sort_rays", sort_rays)
     r.ray_count(reset=True)
     r.submit_commands_gi_pathtrace()
     got = r.svgf.download(PLANE_RADIANCE)
