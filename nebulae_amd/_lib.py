@@ -88,9 +88,11 @@ def load(build_if_missing=True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB_PATH
-    if build_if_missing and _build.needs_build():
-        _build.build()
+    path = os.environ.get("NEB_LIB_PATH")  # tuning only: A/B another build of the same sources (still the HIP library)
+    if not path:
+        path = _build.LIB_PATH
+        if build_if_missing and _build.needs_build():
+            _build.build()
     if not os.path.exists(path):
         raise NebError(f"{path} is missing and could not be built; nebulae_amd has no CPU fallback")
     lib = C.CDLL(path)

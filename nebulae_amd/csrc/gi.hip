@@ -66,7 +66,13 @@ struct Bvh4Node {
     int4 child;
     int4 pad;
 };
-constexpr int kMaxLeafTris = 4;
+#ifndef NEB_TRACE_WAVES
+#define NEB_TRACE_WAVES 8 // waves per SIMD the traversal kernels are register-budgeted for
+#endif
+#ifndef NEB_MAX_LEAF_TRIS
+#define NEB_MAX_LEAF_TRIS 2 // 1..4 (the leaf code keeps count - 1 in two bits); measured 1/2/3/4: 1407 / 1390 / 1403 / 1500 us of GI per 1080p frame
+#endif
+constexpr int kMaxLeafTris = NEB_MAX_LEAF_TRIS;
 
 struct SceneView {
     const float4* tris;      // 3 x float4 per triangle: {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, geom, prim, -}
@@ -326,10 +332,9 @@ struct Hit {
     uint32_t node_visits, tri_tests; // traversal statistics (neb_gi_traversal_stats)
 };
 
-__device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, uint32_t ti, float3 o, float3 d, float tmin,
-                                              float tmax, float& t, float& u, float& v)
+__device__ __forceinline__ bool intersect_tri_regs(float4 a, float4 b, float4 c, float3 o, float3 d, float tmin, float tmax, float& t,
+                                                   float& u, float& v)
 {
-    const float4 a = tris[3 * ti], b = tris[3 * ti + 1], c = tris[3 * ti + 2];
     const float3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
     // Moeller-Trumbore, same operation order as oracle/trace_ref.cpp
     const float3 p = cross3(d, e2);
@@ -347,6 +352,12 @@ __device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, u
         return false;
     t = dot3(e2, q) * inv;
     return t > tmin && t < tmax;
+}
+
+__device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, uint32_t ti, float3 o, float3 d, float tmin,
+                                              float tmax, float& t, float& u, float& v)
+{
+    return intersect_tri_regs(tris[3 * ti], tris[3 * ti + 1], tris[3 * ti + 2], o, d, tmin, tmax, t, u, v);
 }
 
 // Entry distance of the ray into box k of a BVH4 node, as an ordered uint key (misses = 0xffffffff).
@@ -371,10 +382,13 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b)
     b = hi;
 }
 
+// The stack pointer and the LDS column are plain scalars and the spill array is its own object: when all three
+// sat in one struct the dynamically indexed array kept the whole struct (stack pointer included) in scratch memory,
+// and every push / pop paid a scratch round trip behind an s_waitcnt vmcnt(0).
 struct TravStack {
-    int* lds;                 // this lane's column of an LDS array [kLdsStack][64]
-    int spill[kSpillStack];
-    int sp = 0;
+    int* lds;   // this lane's column of an LDS array [kLdsStack][64]
+    int* spill; // private array of kSpillStack entries
+    int sp;
     __device__ __forceinline__ void push(int v)
     {
         if (sp < kLdsStack)
@@ -409,8 +423,8 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     bool found = false;
-    TravStack st;
-    st.lds = lds_stack;
+    int spill_mem[kSpillStack];
+    TravStack st{lds_stack, spill_mem, 0};
     int node = S.root;
     while (node != kTravDone) {
         if (node >= 0) {
@@ -470,7 +484,19 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
             const uint32_t code = (uint32_t)~node;
             const uint32_t first = code >> 2, count = (code & 3u) + 1u;
             hit.tri_tests += count;
-            for (uint32_t k = 0; k < count; ++k) {
+            if constexpr (kMaxLeafTris <= 2) { // both triangles are fetched before the first test: one round trip per leaf
+                const uint32_t second = first + count - 1u;
+                const float4 a0 = S.tris[3 * first], b0 = S.tris[3 * first + 1], c0 = S.tris[3 * first + 2];
+                const float4 a1 = S.tris[3 * second], b1 = S.tris[3 * second + 1], c1 = S.tris[3 * second + 2];
+                float t, u, v;
+                if (intersect_tri_regs(a0, b0, c0, o, d, tmin, hit.t, t, u, v)) {
+                    hit.t = t, hit.u = u, hit.v = v, hit.tri = first, found = true;
+                }
+                if (count > 1u && intersect_tri_regs(a1, b1, c1, o, d, tmin, hit.t, t, u, v)) {
+                    hit.t = t, hit.u = u, hit.v = v, hit.tri = second, found = true;
+                }
+            } else {
+              for (uint32_t k = 0; k < count; ++k) {
                 float t, u, v;
                 if (intersect_tri(S.tris, first + k, o, d, tmin, hit.t, t, u, v)) {
                     hit.t = t;
@@ -479,6 +505,7 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
                     hit.tri = first + k;
                     found = true;
                 }
+              }
             }
             if (ANY_HIT && found)
                 return true;
@@ -736,7 +763,7 @@ __device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine
         block_counts[blockIdx.x] += total; // slot owned by this workgroup; launches on one stream are ordered
 }
 
-__global__ __launch_bounds__(64) void gi_raygen_trace_kernel(GiArgs a)
+__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
     uint32_t x, y;
@@ -796,7 +823,7 @@ __global__ __launch_bounds__(64) void gi_raygen_trace_kernel(GiArgs a)
 }
 
 // Closest-hit traversal of the bounce rays of path vertices >= 2 (vertex 1 is fused into ray generation).
-__global__ __launch_bounds__(64) void gi_bounce_trace_kernel(GiArgs a)
+__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_bounce_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
     uint32_t x, y;
@@ -931,7 +958,7 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
 // (A persistent-wave variant with per-lane ray refill was measured and dropped: lanes of a wave finish after
 // 23 steps on average and the slowest after ~55, so the refill bookkeeping cost more than the idle lanes it
 // recovered: 1.24 ms vs 0.52 ms for the bounce rays at 1080p.)
-__global__ __launch_bounds__(64) void gi_shadow_trace_kernel(GiArgs a)
+__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
     uint32_t x, y;
