@@ -323,8 +323,11 @@ __device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
 // ------------------------------------------------------------------------------------------------
 // Traversal
 // ------------------------------------------------------------------------------------------------
-constexpr int kLdsStack = 16;     // per-lane entries kept in LDS (4 KB per wave)
-constexpr int kSpillStack = 48;   // deeper entries go to a private (scratch) array; rarely touched
+#ifndef NEB_LDS_STACK
+#define NEB_LDS_STACK 16
+#endif
+constexpr int kLdsStack = NEB_LDS_STACK; // per-lane entries kept in LDS (4 KB per wave at 16)
+constexpr int kSpillStack = 64 - kLdsStack; // deeper entries go to a private (scratch) array; rarely touched
 
 struct Hit {
     float t, u, v;
@@ -332,11 +335,12 @@ struct Hit {
     uint32_t node_visits, tri_tests; // traversal statistics (neb_gi_traversal_stats)
 };
 
+// Moeller-Trumbore in the operation order of oracle/trace_ref.cpp.  The early returns stay: a leaf step usually runs
+// with few lanes active, whole waves leave at the first rejection, and a branch-free version measured 9 % slower.
 __device__ __forceinline__ bool intersect_tri_regs(float4 a, float4 b, float4 c, float3 o, float3 d, float tmin, float tmax, float& t,
                                                    float& u, float& v)
 {
     const float3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
-    // Moeller-Trumbore, same operation order as oracle/trace_ref.cpp
     const float3 p = cross3(d, e2);
     const float det = dot3(e1, p);
     if (det == 0.0f)
@@ -426,6 +430,7 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     int spill_mem[kSpillStack];
     TravStack st{lds_stack, spill_mem, 0};
     int node = S.root;
+    constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
         if (node >= 0) {
             hit.node_visits++;
@@ -436,42 +441,43 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
             uint32_t k1 = slab_key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, inv, oinv, tmin, hit.t, 1u);
             uint32_t k2 = slab_key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, inv, oinv, tmin, hit.t, 2u);
             uint32_t k3 = slab_key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, inv, oinv, tmin, hit.t, 3u);
+            // select by the slot bits without branches (two levels of v_cndmask)
+            auto child_of = [&](uint32_t key) -> int {
+                const bool b0 = (key & 1u) != 0u, b1 = (key & 2u) != 0u;
+                const int lo = b0 ? ch.y : ch.x, hi = b0 ? ch.w : ch.z;
+                return b1 ? hi : lo;
+            };
             if (!ANY_HIT) { // sorting network: k0 <= k1 <= k2 <= k3 (nearest first, misses last)
                 cswap(k0, k1);
                 cswap(k2, k3);
                 cswap(k0, k2);
                 cswap(k1, k3);
                 cswap(k1, k2);
-            }
-            auto child_of = [&](uint32_t key) -> int {
-                const uint32_t sl = key & 3u;
-                return sl == 0u ? ch.x : (sl == 1u ? ch.y : (sl == 2u ? ch.z : ch.w));
-            };
-            node = kTravDone;
-            if (!ANY_HIT) {
-                if (k0 != 0xffffffffu) {
-                    if (k3 != 0xffffffffu)
+                node = kTravDone;
+                if (k0 != kMiss) {
+                    if (k3 != kMiss)
                         st.push(child_of(k3));
-                    if (k2 != 0xffffffffu)
+                    if (k2 != kMiss)
                         st.push(child_of(k2));
-                    if (k1 != 0xffffffffu)
+                    if (k1 != kMiss)
                         st.push(child_of(k1));
                     node = child_of(k0);
                 }
             } else { // any order: continue with the first hit child, stack the others
-                if (k3 != 0xffffffffu)
+                node = kTravDone;
+                if (k3 != kMiss)
                     node = ch.w;
-                if (k2 != 0xffffffffu) {
+                if (k2 != kMiss) {
                     if (node != kTravDone)
                         st.push(node);
                     node = ch.z;
                 }
-                if (k1 != 0xffffffffu) {
+                if (k1 != kMiss) {
                     if (node != kTravDone)
                         st.push(node);
                     node = ch.y;
                 }
-                if (k0 != 0xffffffffu) {
+                if (k0 != kMiss) {
                     if (node != kTravDone)
                         st.push(node);
                     node = ch.x;
@@ -484,28 +490,30 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
             const uint32_t code = (uint32_t)~node;
             const uint32_t first = code >> 2, count = (code & 3u) + 1u;
             hit.tri_tests += count;
-            if constexpr (kMaxLeafTris <= 2) { // both triangles are fetched before the first test: one round trip per leaf
+            if constexpr (kMaxLeafTris <= 2) {
+                // both triangles are fetched before the first test (one memory round trip per leaf).  A one-triangle
+                // leaf tests its triangle twice: the second test cannot pass t < hit.t again.
                 const uint32_t second = first + count - 1u;
-                const float4 a0 = S.tris[3 * first], b0 = S.tris[3 * first + 1], c0 = S.tris[3 * first + 2];
+                float4 a0 = S.tris[3 * first];
+                const float4 b0 = S.tris[3 * first + 1], c0 = S.tris[3 * first + 2];
                 const float4 a1 = S.tris[3 * second], b1 = S.tris[3 * second + 1], c1 = S.tris[3 * second + 2];
+                // keep the v0 load in this batch: left alone, the compiler sinks it behind the det == 0 test of the
+                // first triangle, a second dependent memory access per leaf
+                asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z));
                 float t, u, v;
                 if (intersect_tri_regs(a0, b0, c0, o, d, tmin, hit.t, t, u, v)) {
                     hit.t = t, hit.u = u, hit.v = v, hit.tri = first, found = true;
                 }
-                if (count > 1u && intersect_tri_regs(a1, b1, c1, o, d, tmin, hit.t, t, u, v)) {
+                if (intersect_tri_regs(a1, b1, c1, o, d, tmin, hit.t, t, u, v)) {
                     hit.t = t, hit.u = u, hit.v = v, hit.tri = second, found = true;
                 }
             } else {
-              for (uint32_t k = 0; k < count; ++k) {
-                float t, u, v;
-                if (intersect_tri(S.tris, first + k, o, d, tmin, hit.t, t, u, v)) {
-                    hit.t = t;
-                    hit.u = u;
-                    hit.v = v;
-                    hit.tri = first + k;
-                    found = true;
+                for (uint32_t k = 0; k < count; ++k) {
+                    float t, u, v;
+                    if (intersect_tri(S.tris, first + k, o, d, tmin, hit.t, t, u, v)) {
+                        hit.t = t, hit.u = u, hit.v = v, hit.tri = first + k, found = true;
+                    }
                 }
-              }
             }
             if (ANY_HIT && found)
                 return true;
