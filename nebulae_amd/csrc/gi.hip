@@ -566,11 +566,12 @@ __device__ __forceinline__ float3 xform_dir(const float* m, float3 p) // (p,0) *
 // ReconstructSurfaceData (pathtracer.hlsl:299-395)
 // Per-triangle shading record (128 B, one cache line) so that a hit costs one line instead of ~10 scattered
 // ones (3 indices, 3 x normal/uv/tangent in three SoA pools):
-//   r0 {n0.xyz, uv0.x} r1 {n1.xyz, uv0.y} r2 {n2.xyz, uv1.x} r3..r5 tangent0..2 r6 {uv1.y, uv2.x, uv2.y, -} r7 spare
+//   r0 {n0.xyz, uv0.x} r1 {n1.xyz, uv0.y} r2 {n2.xyz, uv1.x} r3..r5 tangent0..2 r6 {uv1.y, uv2.x, uv2.y, geometry} r7 {primitive,-,-,-}
 struct TriShade {
     float3 n0, n1, n2;
     float2 uv0, uv1, uv2;
     float4 t0, t1, t2;
+    uint32_t geom; // GeometryIndex() of the triangle (r6.w); PrimitiveIndex() is r7.x (debug records only)
 };
 __device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t tri)
 {
@@ -583,6 +584,7 @@ __device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t 
     t.uv0 = make_float2(r0.w, r1.w);
     t.uv1 = make_float2(r2.w, r6.x);
     t.uv2 = make_float2(r6.y, r6.z);
+    t.geom = __float_as_uint(r6.w);
     t.t0 = r[3];
     t.t1 = r[4];
     t.t2 = r[5];
@@ -590,13 +592,16 @@ __device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t 
 }
 
 // ReconstructSurfaceData (pathtracer.hlsl:299-395); `tri` is the sorted triangle index of the hit.
-__device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, uint32_t geom, float bu, float bv, Surface& out)
+__device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, float bv, Surface& out, uint32_t& geom)
 {
+    // the record is fetched first and names its geometry itself: one gathered line per hit, and the geometry / material
+    // table reads hang off it instead of off a second gather into the triangle array
+    const TriShade ts = load_tri_shade(S, tri);
+    geom = ts.geom;
     const DevGeom g = S.geoms[geom];
     const float b0 = 1.0f - (bu + bv), b1 = bu, b2 = bv;
     if (!g.valid)
         return false; // :313-318
-    const TriShade ts = load_tri_shade(S, tri);
     const float3 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
     const float3 gn = normalize3(f3(n0.x * b0 + n1.x * b1 + n2.x * b2, n0.y * b0 + n1.y * b1 + n2.y * b2, n0.z * b0 + n1.z * b1 + n2.z * b2));
     out.GN = normalize3(xform_dir(g.m, gn)); // :340
@@ -665,6 +670,8 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
         r[5] = make_float4(S.tangents[4 * i2], S.tangents[4 * i2 + 1], S.tangents[4 * i2 + 2], S.tangents[4 * i2 + 3]);
         r[6] = make_float4(S.uvs[2 * i1 + 1], S.uvs[2 * i2], S.uvs[2 * i2 + 1], 0.f);
     }
+    r[6].w = __uint_as_float(geom);
+    r[7].x = __uint_as_float(prim);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         out[8 * (size_t)ti + k] = r[k];
@@ -808,7 +815,8 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
         a.R.ray_o[i] = make_float4(org.x, org.y, org.z, 0.01f);
         a.R.ray_d[i] = make_float4(dir.x, dir.y, dir.z, bounce ? 1.0f : 0.0f);
-        a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
+        if (a.sample + 1 < a.c.samplesPerPixel) // only the next sample of this pixel reads it
+            a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
         float4 h = make_float4(bounce ? -1.0f : -2.0f, 0.f, 0.f, 0.f); // -2: no bounce at all, nothing is added
         rays = bounce ? 1u : 0u;
         if (a.bsort_keys) {
@@ -885,13 +893,14 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
             sum.z += a.c.skyColor[2] * throughput.z;
         } else if (alive && h.x >= 0.0f) {
             const uint32_t tri = __float_as_uint(h.w);
-            const float4 ids = a.S.tris[3 * tri + 2];
-            const uint32_t geom = __float_as_uint(ids.y), prim = __float_as_uint(ids.z);
+            Surface surf;
+            uint32_t geom;
+            const bool shaded = reconstruct_surface(a.S, tri, h.y, h.z, surf, geom);
             dbg.t = h.x;
             dbg.geometry = geom;
-            dbg.primitive = prim;
-            Surface surf;
-            if (reconstruct_surface(a.S, tri, geom, h.y, h.z, surf)) {
+            if (a.hits)
+                dbg.primitive = __float_as_uint(a.S.shade[8 * (size_t)tri + 7].x);
+            if (shaded) {
                 const float4 ro = a.R.ray_o[i];
                 const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
                 const float3 hitP = org + dir * h.x;
@@ -927,13 +936,13 @@ __global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
                     a.R.ray_o[i] = make_float4(no.x, no.y, no.z, 0.001f);
                     next_d = make_float4(Ld.x, Ld.y, Ld.z, 1.0f);
                     a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
-                } else {
-                    a.R.path[i] = make_float4(pth.x, pth.y, pth.z, __uint_as_float(rng));
-                }
-                a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
+                } // (the last vertex leaves R.path alone: the next sample's ray generation rewrites it)
+                if (a.sample + 1 < a.c.samplesPerPixel) // V and the RNG stream carry over to the next sample only
+                    a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
             }
         }
-        a.R.ray_d[i] = next_d;
+        if (a.bounce + 1 < a.c.maxPathVertices) // nobody traces or shades a ray after the last vertex
+            a.R.ray_d[i] = next_d;
         a.R.sray_d[i] = shadow_d;
         a.R.sum[i] = sum;
         if (a.sort_keys) { // shadow rays are all (nearly) parallel: grouping them by origin makes a wave's rays walk the same nodes
