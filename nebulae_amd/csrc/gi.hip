@@ -705,7 +705,7 @@ __device__ __forceinline__ uint32_t morton30(float3 p, const float* smin, const 
 // Radix-sort key width for ray ordering: the top kSortBits bits of the 30-bit Morton code of the ray origin
 // (each 8 bits are one onesweep pass over the keys).
 #ifndef NEB_SORT_BITS
-#define NEB_SORT_BITS 24
+#define NEB_SORT_BITS 16
 #endif
 constexpr int kSortBits = NEB_SORT_BITS;
 
