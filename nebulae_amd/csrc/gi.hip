@@ -60,14 +60,21 @@ struct BvhNode {
 
 // 128-byte BVH4 node produced by collapsing the LBVH (SoA per axis: one float4 per bound and axis).
 // child >= 0: inner node index; child < 0: leaf, code = ~child = (first_triangle << 2) | (count - 1), count <= 4;
-// unused slots carry an inverted (never-hit) box.
+// unused slots carry an inverted (never-hit) box.  The lower and the upper plane of an axis sit 64 bytes apart, so
+// a ray picks its near plane with a per-ray byte offset (0 or 64 by the sign of its direction) and the far plane
+// with offset ^ 64: no min / max per slab.
 struct Bvh4Node {
-    float4 lox, loy, loz, hix, hiy, hiz;
-    int4 child;
+    float4 lox, loy, loz; //  0, 16, 32
+    int4 child;           // 48
+    float4 hix, hiy, hiz; // 64, 80, 96
     int4 pad;
 };
+static_assert(sizeof(Bvh4Node) == 128 && offsetof(Bvh4Node, hix) == offsetof(Bvh4Node, lox) + 64, "node layout");
 #ifndef NEB_TRACE_WAVES
 #define NEB_TRACE_WAVES 8 // waves per SIMD the traversal kernels are register-budgeted for
+#endif
+#ifndef NEB_SHADE_WAVES
+#define NEB_SHADE_WAVES 4 // waves per SIMD gi_shade_kernel is register-budgeted for
 #endif
 #ifndef NEB_MAX_LEAF_TRIS
 #define NEB_MAX_LEAF_TRIS 2 // 1..4 (the leaf code keeps count - 1 in two bits); measured 1/2/3/4: 1407 / 1390 / 1403 / 1500 us of GI per 1080p frame
@@ -335,8 +342,10 @@ struct Hit {
     uint32_t node_visits, tri_tests; // traversal statistics (neb_gi_traversal_stats)
 };
 
-// Moeller-Trumbore in the operation order of oracle/trace_ref.cpp.  The early returns stay: a leaf step usually runs
-// with few lanes active, whole waves leave at the first rejection, and a branch-free version measured 9 % slower.
+// Moeller-Trumbore in the operation order of oracle/trace_ref.cpp.  Before the oracle's own tests run, the undivided
+// numerators (U = u * det, ...) are screened against det with its sign and a few ulps of slack, so the IEEE division
+// -- 11 instructions -- is only paid by a wave in which some lane (nearly) hits; a leaf step usually runs with few lanes
+// active and whole waves leave at the first rejection.  The screen only rejects what the exact tests reject too.
 __device__ __forceinline__ bool intersect_tri_regs(float4 a, float4 b, float4 c, float3 o, float3 d, float tmin, float tmax, float& t,
                                                    float& u, float& v)
 {
@@ -345,17 +354,27 @@ __device__ __forceinline__ bool intersect_tri_regs(float4 a, float4 b, float4 c,
     const float det = dot3(e1, p);
     if (det == 0.0f)
         return false;
-    const float inv = 1.0f / det;
     const float3 tv = o - v0;
-    u = dot3(tv, p) * inv;
-    if (u < 0.0f || u > 1.0f)
+    const float ads = fabsf(det) * 1.000002f; // |det| plus ~16 ulps
+    const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    const float U = dot3(tv, p);
+    const float Us = __uint_as_float(__float_as_uint(U) ^ sgn); // U * sign(det)
+    if (Us < 0.0f || Us > ads)
         return false;
     const float3 q = cross3(tv, e1);
-    v = dot3(d, q) * inv;
-    if (v < 0.0f || u + v > 1.0f)
+    const float V = dot3(d, q);
+    const float Vs = __uint_as_float(__float_as_uint(V) ^ sgn);
+    if (Vs < 0.0f || Us + Vs > ads)
         return false;
-    t = dot3(e2, q) * inv;
-    return t > tmin && t < tmax;
+    const float T = dot3(e2, q);
+    const float Ts = __uint_as_float(__float_as_uint(T) ^ sgn);
+    if (!(Ts > 0.0f && Ts <= tmax * ads)) // (tmin >= 0 everywhere)
+        return false;
+    const float inv = 1.0f / det;
+    u = U * inv;
+    v = V * inv;
+    t = T * inv;
+    return u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && t > tmin && t < tmax;
 }
 
 __device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, uint32_t ti, float3 o, float3 d, float tmin,
@@ -365,16 +384,17 @@ __device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, u
 }
 
 // Entry distance of the ray into box k of a BVH4 node, as an ordered uint key (misses = 0xffffffff).
-// One fma per plane: t = plane * (1/d) - o/d.  fminf/fmaxf drop NaNs (inf - inf for axis-parallel rays), which
-// only makes the interval more conservative; hits themselves are decided by the triangle test.
-__device__ __forceinline__ uint32_t slab_key(float lox, float loy, float loz, float hix, float hiy, float hiz, float3 inv, float3 oinv,
+// n* / f* are the planes the ray meets first / last on each axis (picked by the sign of the direction when the node
+// is loaded).  One fma per plane: t = plane * (1/d) - o/d.  fminf/fmaxf drop NaNs (inf - inf for axis-parallel
+// rays), which only makes the interval more conservative; hits themselves are decided by the triangle test.
+__device__ __forceinline__ uint32_t slab_key(float nx, float ny, float nz, float fx, float fy, float fz, float3 inv, float3 oinv,
                                              float tmin, float tmax, uint32_t slot)
 {
-    const float ax = fmaf(lox, inv.x, -oinv.x), bx = fmaf(hix, inv.x, -oinv.x);
-    const float ay = fmaf(loy, inv.y, -oinv.y), by = fmaf(hiy, inv.y, -oinv.y);
-    const float az = fmaf(loz, inv.z, -oinv.z), bz = fmaf(hiz, inv.z, -oinv.z);
-    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    const float ax = fmaf(nx, inv.x, -oinv.x), bx = fmaf(fx, inv.x, -oinv.x);
+    const float ay = fmaf(ny, inv.y, -oinv.y), by = fmaf(fy, inv.y, -oinv.y);
+    const float az = fmaf(nz, inv.z, -oinv.z), bz = fmaf(fz, inv.z, -oinv.z);
+    const float t0 = fmaxf(fmaxf(ax, ay), fmaxf(az, tmin));
+    const float t1 = fminf(fminf(bx, by), fminf(bz, tmax));
     // t0 >= tmin >= 0: its bit pattern orders like an unsigned integer; the low 2 bits carry the slot
     return (t0 <= t1) ? ((__float_as_uint(t0) & ~3u) | slot) : 0xffffffffu;
 }
@@ -416,7 +436,7 @@ struct TravStack {
 // round trips per iteration.  Shadow rays skip the front-to-back ordering of the children.
 constexpr int kTravDone = (int)0x80000000;
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool STATS>
 __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit)
 {
     hit.t = tmax;
@@ -426,6 +446,8 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
         return false;
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    // byte offset of the plane the ray enters through, per axis, inside a Bvh4Node (the exit plane is offset ^ 64)
+    const uint32_t onx = d.x < 0.0f ? 64u : 0u, ony = d.y < 0.0f ? 80u : 16u, onz = d.z < 0.0f ? 96u : 32u;
     bool found = false;
     int spill_mem[kSpillStack];
     TravStack st{lds_stack, spill_mem, 0};
@@ -433,14 +455,18 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
         if (node >= 0) {
-            hit.node_visits++;
-            const Bvh4Node* n = S.nodes + node;
-            const float4 lox = n->lox, loy = n->loy, loz = n->loz, hix = n->hix, hiy = n->hiy, hiz = n->hiz;
-            const int4 ch = n->child;
-            uint32_t k0 = slab_key(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, inv, oinv, tmin, hit.t, 0u);
-            uint32_t k1 = slab_key(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, inv, oinv, tmin, hit.t, 1u);
-            uint32_t k2 = slab_key(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, inv, oinv, tmin, hit.t, 2u);
-            uint32_t k3 = slab_key(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, inv, oinv, tmin, hit.t, 3u);
+            if (STATS)
+                hit.node_visits++;
+            const char* nodes = reinterpret_cast<const char*>(S.nodes);
+            const uint32_t nb = (uint32_t)node << 7; // 32-bit byte offset (scalar base + vector offset addressing)
+            const float4 nx = *reinterpret_cast<const float4*>(nodes + (nb + onx)), fx = *reinterpret_cast<const float4*>(nodes + (nb + (onx ^ 64u)));
+            const float4 ny = *reinterpret_cast<const float4*>(nodes + (nb + ony)), fy = *reinterpret_cast<const float4*>(nodes + (nb + (ony ^ 64u)));
+            const float4 nz = *reinterpret_cast<const float4*>(nodes + (nb + onz)), fz = *reinterpret_cast<const float4*>(nodes + (nb + (onz ^ 64u)));
+            const int4 ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
+            uint32_t k0 = slab_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, inv, oinv, tmin, hit.t, 0u);
+            uint32_t k1 = slab_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, inv, oinv, tmin, hit.t, 1u);
+            uint32_t k2 = slab_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, inv, oinv, tmin, hit.t, 2u);
+            uint32_t k3 = slab_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, inv, oinv, tmin, hit.t, 3u);
             // select by the slot bits without branches (two levels of v_cndmask)
             auto child_of = [&](uint32_t key) -> int {
                 const bool b0 = (key & 1u) != 0u, b1 = (key & 2u) != 0u;
@@ -489,7 +515,8 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
         if (node < 0 && node != kTravDone) {
             const uint32_t code = (uint32_t)~node;
             const uint32_t first = code >> 2, count = (code & 3u) + 1u;
-            hit.tri_tests += count;
+            if (STATS)
+                hit.tri_tests += count;
             if constexpr (kMaxLeafTris <= 2) {
                 // both triangles are fetched before the first test (one memory round trip per leaf).  A one-triangle
                 // leaf tests its triangle twice: the second test cannot pass t < hit.t again.
@@ -523,10 +550,13 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     return found;
 }
 
+// `stats` (wave-uniform, diagnostics) selects the instantiation that also counts node visits and triangle tests.
 __device__ __forceinline__ bool traverse(const SceneView& S, float3 o, float3 d, float tmin, float tmax, bool any_hit, int* lds_stack,
-                                         Hit& hit)
+                                         Hit& hit, bool stats = false)
 {
-    return any_hit ? traverse_t<true>(S, o, d, tmin, tmax, lds_stack, hit) : traverse_t<false>(S, o, d, tmin, tmax, lds_stack, hit);
+    if (stats)
+        return any_hit ? traverse_t<true, true>(S, o, d, tmin, tmax, lds_stack, hit) : traverse_t<false, true>(S, o, d, tmin, tmax, lds_stack, hit);
+    return any_hit ? traverse_t<true, false>(S, o, d, tmin, tmax, lds_stack, hit) : traverse_t<false, false>(S, o, d, tmin, tmax, lds_stack, hit);
 }
 
 // SampleLevel(linear, wrap, mip 0) of an RGBA8 UNORM texture (pathtracer.hlsl:359,377,390).
@@ -825,7 +855,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         }
         if (bounce && !a.raygen_only) {
             Hit hit;
-            if (traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit))
+            if (traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit, a.stats != 0))
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only
                 atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
@@ -870,7 +900,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_bounce_trace_kernel(Gi
         count_rays(a.bounce_counts, rays);
 }
 
-__global__ __launch_bounds__(64) void gi_shade_kernel(GiArgs a)
+__global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
 {
     uint32_t x, y;
     size_t i;
@@ -993,7 +1023,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
     if (rd.w != 0.0f) {
         const float4 ro = a.R.sray_o[i];
         Hit sh;
-        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh);
+        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh, a.stats != 0);
         if (a.stats) { // diagnostics only
             atomicAdd(a.ray_counter + 3, (unsigned long long)sh.node_visits);
             atomicAdd(a.ray_counter + 4, (unsigned long long)sh.tri_tests);
