@@ -108,7 +108,7 @@ struct GiState {
     unsigned long long* d_ray_counter = nullptr;
     neb_gi_hit* d_hits = nullptr;
     bool debug_hits = false;
-    float4* d_records = nullptr; // 7 float4 planes over the resident pixels (GiRecords)
+    float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
     unsigned long long last_stats[8] = {};
     bool defer_resolve = false;
     bool sort_shadow = true;  // "gi_sort_rays" bit 0
@@ -749,14 +749,17 @@ __device__ __forceinline__ uint32_t bounce_sort_key(float3 o, float3 d, const fl
 struct GiRecords {
     float4* ray_o;   // {origin.xyz, tmin}      bounce ray of the path
     float4* ray_d;   // {direction.xyz, alive}  alive = 1: the path continues with this ray
-    float4* sray_o;  // {origin.xyz, tmin}      sun shadow ray of the current vertex
-    float4* sray_d;  // {direction.xyz, valid}  valid = 1: trace it
     float4* hit;     // {t (<0 miss), u, v, tri bits}
     float4* path;    // {throughput.xyz, rng bits}
-    float4* contrib; // {BRDF * sunRadiance * throughput, -}
     float4* state;   // {V.xyz, rng bits}: survives across the samples of a pixel
-    float4* sum;     // {sum of the samples' radiance, -}
+    // Everything the shadow pass needs about a pixel sits in ONE 64-byte line, because that pass visits the pixels in
+    // sorted (scattered) order and every separate plane would cost it another line per ray:
+    //   [0] {origin.xyz, tmin}  [1] {direction.xyz, valid}  sun shadow ray of the current vertex (valid = 1: trace it)
+    //   [2] {BRDF * sunRadiance * throughput, traversal iterations (diagnostics)}
+    //   [3] {sum of the samples' radiance so far, -}
+    float4* srec;
 };
+constexpr int kSrO = 0, kSrD = 1, kSrContrib = 2, kSrSum = 3;
 
 struct GiArgs {
     SceneView S;
@@ -775,7 +778,7 @@ struct GiArgs {
     uint32_t sample;             // index of the sample this launch handles
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
     uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
-    uint32_t defer_resolve;      // 1: leave the frame's sum in R.sum; neb_gi_resolve adds it into radiance[cur] later
+    uint32_t defer_resolve;      // 1: leave the frame's sum in the record plane; neb_gi_resolve adds it into radiance[cur] later
     uint32_t* sort_keys;         // shadow-ray sorting ("gi_sort_shadow_rays"): Morton key of the ray origin per pixel, or null
     uint32_t* sort_vals;         // pixel index per key
     const uint32_t* sort_order;  // pixel indices in key order (after the radix sort), or null: pixel order
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
             if (a.stats) { // diagnostics only
                 atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
                 atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
-                a.R.contrib[i].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2)); // loop iterations of this ray
+                a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2)); // loop iterations of this ray
             }
         }
         a.R.hit[i] = h;
@@ -906,14 +909,18 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
     size_t i;
     const bool active = gi_pixel(a, x, y, i);
     uint32_t rays = 0;
+    // the pixel's shadow record (GiRecords::srec), built in registers and stored through an LDS transpose below
+    float4 rec_o = make_float4(0.f, 0.f, 0.f, 0.f), rec_c = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 shadow_d = make_float4(0.f, 0.f, 0.f, 0.f); // valid = 0: no shadow ray
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
         const float4 h = a.R.hit[i];
         const float4 pth = a.R.path[i];
         const float4 rd = a.R.ray_d[i];
-        const uint32_t trav_iters = a.stats ? __float_as_uint(a.R.contrib[i].w) : 0u; // diagnostics (written by the tracer)
+        const uint32_t trav_iters = a.stats ? __float_as_uint(a.R.srec[4 * i + kSrContrib].w) : 0u; // diagnostics (written by the tracer)
         float3 throughput = f3(pth.x, pth.y, pth.z);
-        float4 sum = (a.sample == 0 && a.bounce == 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : a.R.sum[i];
-        float4 shadow_d = make_float4(0.f, 0.f, 0.f, 0.f); // valid = 0: no shadow ray
+        if (!(a.sample == 0 && a.bounce == 1))
+            sum = a.R.srec[4 * i + kSrSum];
         float4 next_d = make_float4(0.f, 0.f, 0.f, 0.f);   // alive = 0: the path ends here
         neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
         const bool alive = rd.w != 0.0f; // (vertex 1 with maxPathVertices <= 1: hit.x == -2, nothing is added)
@@ -947,9 +954,9 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
                 const bool transition = dot3(surf.GN, inc) <= 0.0f;
                 const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
                 const float3 O = evaluate_direct_brdf(surf, V, L) * sun_rad * throughput; // :573-574
-                a.R.sray_o[i] = make_float4(so.x, so.y, so.z, 0.001f);
+                rec_o = make_float4(so.x, so.y, so.z, 0.001f);
                 shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
-                a.R.contrib[i] = make_float4(O.x, O.y, O.z, 0.f);
+                rec_c = make_float4(O.x, O.y, O.z, 0.f);
                 rays = 1;
                 if (a.bounce + 1 < a.c.maxPathVertices) { // not the last vertex (:579-583): sample the next bounce
                     // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
@@ -973,13 +980,10 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
         }
         if (a.bounce + 1 < a.c.maxPathVertices) // nobody traces or shades a ray after the last vertex
             a.R.ray_d[i] = next_d;
-        a.R.sray_d[i] = shadow_d;
-        a.R.sum[i] = sum;
         if (a.sort_keys) { // shadow rays are all (nearly) parallel: grouping them by origin makes a wave's rays walk the same nodes
             uint32_t key = (1u << kSortBits) - 1u; // pixels without a shadow ray sort last
             if (shadow_d.w != 0.0f) {
-                const float4 so4 = a.R.sray_o[i];
-                key = min(morton30(f3(so4.x, so4.y, so4.z), a.smin, a.sinv) >> (30 - kSortBits), (1u << kSortBits) - 2u);
+                key = min(morton30(f3(rec_o.x, rec_o.y, rec_o.z), a.smin, a.sinv) >> (30 - kSortBits), (1u << kSortBits) - 2u);
             }
             a.sort_keys[i] = key;
             a.sort_vals[i] = (uint32_t)i;
@@ -998,6 +1002,23 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
                 dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py)
             a.hits[i] = dbg;
         }
+    }
+    // Store the 64-byte records of the wave's 8x8 tile.  Lane-per-pixel stores would write 16 bytes at a 64-byte stride
+    // four times over; transposed through LDS, every store instruction writes two 512-byte runs (one tile row each).
+    __shared__ float4 xpose[64 * 4];
+    const uint32_t lane = threadIdx.x;
+    xpose[lane * 4 + kSrO] = rec_o;
+    xpose[lane * 4 + kSrD] = shadow_d;
+    xpose[lane * 4 + kSrContrib] = rec_c;
+    xpose[lane * 4 + kSrSum] = sum;
+    __syncthreads(); // the workgroup is this one wave
+    const uint32_t tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t row = 2 * k + (lane >> 5), col = (lane & 31u) >> 2, comp = lane & 3u;
+        const uint32_t px = tile_x * 8 + col, py = a.row0 + tile_y * 8 + row;
+        if (px < a.W && py < a.row1)
+            a.R.srec[4 * ((size_t)(py - a.row_begin) * a.W + px) + comp] = xpose[(row * 8 + col) * 4 + comp];
     }
     count_rays(a.shadow_counts, rays);
 }
@@ -1018,10 +1039,11 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
     } else if (!gi_pixel(a, x, y, i)) {
         return;
     }
-    const float4 rd = a.R.sray_d[i];
-    float4 sum = a.R.sum[i];
+    const float4* rec = a.R.srec + 4 * i;
+    const float4 rd = rec[kSrD];
+    float4 sum = rec[kSrSum];
     if (rd.w != 0.0f) {
-        const float4 ro = a.R.sray_o[i];
+        const float4 ro = rec[kSrO];
         Hit sh;
         const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh, a.stats != 0);
         if (a.stats) { // diagnostics only
@@ -1029,7 +1051,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
             atomicAdd(a.ray_counter + 4, (unsigned long long)sh.tri_tests);
         }
         if (!occluded) { // radiance += BRDF * sunRadiance * throughput (:571-575)
-            const float4 c = a.R.contrib[i];
+            const float4 c = rec[kSrContrib];
             sum.x += c.x;
             sum.y += c.y;
             sum.z += c.z;
@@ -1046,7 +1068,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
         r.z += sum.z * inv_spp;
         a.radiance[i] = r;
     } else {
-        a.R.sum[i] = sum;
+        a.R.srec[4 * i + kSrSum] = sum;
     }
 }
 
@@ -1149,13 +1171,13 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
 // The reference adds the indirect term into radiance[cur] in a separate step (nrc Resolve, DeferredRenderer.cpp:586).
 // neb_gi_resolve is that step when the trace ran with "gi_defer_resolve": it lets a caller overlap the GI stages of
 // frame f+1 (which touch only the G-buffer and the GI records) with the SVGF passes of frame f on another stream.
-__global__ __launch_bounds__(256) void gi_resolve_kernel(float4* __restrict__ radiance, const float4* __restrict__ sum, size_t first, size_t n,
+__global__ __launch_bounds__(256) void gi_resolve_kernel(float4* __restrict__ radiance, const float4* __restrict__ srec, size_t first, size_t n,
                                                          float inv_spp)
 {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n)
         return;
-    const float4 s = sum[first + k];
+    const float4 s = srec[4 * (first + k) + kSrSum];
     float4 r = radiance[first + k];
     r.x += s.x * inv_spp;
     r.y += s.y * inv_spp;
@@ -1843,11 +1865,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     a.R.ray_d = g->d_records + npx;
     a.R.hit = g->d_records + 2 * npx;
     a.R.path = g->d_records + 3 * npx;
-    a.R.contrib = g->d_records + 4 * npx;
-    a.R.state = g->d_records + 5 * npx;
-    a.R.sum = g->d_records + 6 * npx;
-    a.R.sray_o = g->d_records + 7 * npx;
-    a.R.sray_d = g->d_records + 8 * npx;
+    a.R.state = g->d_records + 4 * npx;
+    a.R.srec = g->d_records + 5 * npx;
     a.albedo = (const uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
     a.rough_metal = (const uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
     a.world_pos = (const uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
@@ -1960,7 +1979,7 @@ int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     const size_t first = (size_t)(g->pending_row0 - ctx->row_begin) * ctx->W, n = (size_t)(g->pending_row1 - g->pending_row0) * ctx->W;
     hipLaunchKernelGGL(gi_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], g->d_records + 6 * npx, first, n, 1.0f / (float)g->pending_spp);
+                       (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], g->d_records + 5 * npx, first, n, 1.0f / (float)g->pending_spp);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
 }

@@ -28,3 +28,35 @@ mx3 = np.sort(b, axis=1).reshape(-1, 64).max(axis=1).sum()
 mx3_base = b.reshape(-1, 16, 64)
 print("sorted inside 32x32 blocks: gain x%.2f" % (wave_cost(t)[0] / (mx3 * (t.size / b.size))))
 print("iterations per ray: mean %.1f p50 %d p90 %d p99 %d max %d" % (it.mean(), np.percentile(it, 50), np.percentile(it, 90), np.percentile(it, 99), it.max()))
+
+# (d) workgroup-level periodic compaction: a workgroup of G rays runs rounds of at most N iterations; after each round the
+# unfinished rays are packed into as few waves as possible (state handed over through LDS) and the other waves retire.
+def compaction_cost(G, N, overhead):
+    tiles = it[: (H // 8) * 8, : (W // 8) * 8].reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+    nw = G // 64
+    tiles = tiles[: (tiles.shape[0] // nw) * nw].reshape(-1, G).astype(np.int64)  # consecutive tiles form a workgroup
+    rem = tiles.copy()
+    total = 0.0
+    first = True
+    while True:
+        alive = rem > 0
+        if not alive.any():
+            break
+        if first:
+            packed = rem  # initial assignment: pixel order
+            first = False
+        else:
+            # pack unfinished rays to the front (order preserved)
+            idx = np.argsort(~alive, axis=1, kind="stable")
+            packed = np.take_along_axis(rem, idx, axis=1)
+        waves = packed.reshape(packed.shape[0], nw, 64)
+        wmax = waves.max(axis=2)
+        run = np.minimum(wmax, N)
+        total += run.sum() + overhead * (wmax > 0).sum()
+        rem = np.maximum(packed - N, 0)
+    return total / tiles.size * t.size
+base = wave_cost(t)[0]
+for G in (256, 512, 1024):
+    for N in (8, 16, 24, 32):
+        c = compaction_cost(G, N, 2.0)
+        print("workgroup %4d rays, rounds of %2d iterations (+2 per live wave and round): cost x%.2f of baseline" % (G, N, c / base))
