@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
                     // w = Kx*Ky * exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) as ONE exp2:
                     // exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d == 0 -> -inf -> weight 0)
                     const float lk = atrous_log2k(dx, dy);
-                    const float d = fmaxf(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)), 0.0f);
+                    const float d = fminf(fmaxf(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)), 0.0f), 1.0f);
                     float e = fmaf(phiN, fast_log2(d), lk);
                     e = fmaf(-fabsf(z0[k] - tA.w), cz, e);
                     e = fmaf(-fabsf(lum0[k] - tB.w), cl[k], e);
