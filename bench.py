@@ -68,6 +68,27 @@ def measured_traffic(width, height, levels):
     return best
 
 
+def measured_valu(width, height, levels):
+    """f32 VALU occupancy of the a-trous launches from the newest committed SQ counter summary (profiles/*sq_counters.json):
+    {"lane_instructions_per_pixel", "issue_us_per_launch"} averaged over the levels, or None.  The kernel is bound by
+    vector-instruction issue, not by HBM; the HBM roofline above is the one the contract asks for."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        per = [v for k, v in d.get("kernels", {}).items() if "svgf_atrous_lds_kernel" in k]
+        if len(per) == levels:
+            insts = sum(v["SQ_INSTS_VALU"] for v in per) / len(per)
+            quad = sum(v["SQ_ACTIVE_INST_VALU"] for v in per) / len(per)
+            best = {"lane_instructions_per_pixel": insts * 64.0 / (width * height),
+                    "issue_us_per_launch": quad / 1024.0 * 4.0 / 2.4e3,  # quad-cycles per SIMD at the 2.4 GHz peak clock
+                    "source": os.path.basename(f)}
+    return best
+
+
 def host_cores():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return max(1, min(n, 16))  # a 1-GPU box shares its host: 16 cores is this job's CPU share
@@ -258,6 +279,9 @@ def main():
         fps_equiv = args.steps / dt * world               # 1080p-frame equivalents per second, whole job
         achieved = ATROUS_BYTES_PX * own_px / t_atrous / 1e9
         traffic = measured_traffic(GW, GH, L) if world == 1 else None
+        valu = measured_valu(GW, GH, L) if world == 1 else None
+        if valu:
+            valu["busy_frac"] = valu["issue_us_per_launch"] / (sum(per_level) / len(per_level) * 1e6)
         out = {
             "metric": "denoised frames/s (1920x1080-frame equivalents: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
                       "denoised frames/s (1920x1080-frame equivalents: SVGF temporal + a-trous only)",
@@ -277,7 +301,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
-                         "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None},
+                         "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
+                         "valu": valu},
             "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s"},
         }
