@@ -217,6 +217,9 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
 int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5]);
 /* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);
+/* Diagnostics / tests: runs the library's ray-reordering sort (raysort.hip: stable LSD radix sort on key bits
+ * [0, bits), bits <= 16) on n host (key, value) pairs and returns the values in sorted order.  Synchronises. */
+int neb_debug_sort_pairs(neb_ctx* ctx, const uint32_t* keys, const uint32_t* values, uint32_t n, int bits, uint32_t* sorted_values);
 /* "next" row f1: DeferredRenderer::SubmitCommandsPBRLighting (src/DeferredRenderer.cpp:326-394) driving
  * assets/shaders/deferred_pbr.hlsl:39-115: Cook-Torrance sun light x one any-hit shadow ray per pixel; OVERWRITES
  * radiance[cur] (alpha = 1).  Uses cameraWorldPos, sunLight*, sunTanHalfAngle and frameIndex of the constants. */

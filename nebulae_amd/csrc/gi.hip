@@ -733,11 +733,12 @@ __device__ __forceinline__ uint32_t morton30(float3 p, const float* smin, const 
 }
 
 // Radix-sort key width for ray ordering: the top kSortBits bits of the 30-bit Morton code of the ray origin
-// (each 8 bits are one onesweep pass over the keys).
+// (each 8 bits are one pass of raysort.hip over the pairs).
 #ifndef NEB_SORT_BITS
 #define NEB_SORT_BITS 16
 #endif
 constexpr int kSortBits = NEB_SORT_BITS;
+static_assert(kSortBits >= 1 && kSortBits <= 16, "raysort.hip sorts at most two 8-bit digits");
 
 __device__ __forceinline__ uint32_t bounce_sort_key(float3 o, float3 d, const float* smin, const float* sinv)
 {
@@ -1896,10 +1897,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             GI_HIP(ctx, hipMalloc(&p, 8 * npx * sizeof(uint32_t))); // {keys, vals, keys_out, vals_out} x {shadow, bounce}
             g->allocs.push_back(p);
             g->d_sort = (uint32_t*)p;
-            size_t bytes = 0;
-            GI_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, g->d_sort, g->d_sort + 2 * npx, g->d_sort + npx, g->d_sort + 3 * npx,
-                                                             (int)npx, 0, kSortBits, (hipStream_t)stream));
-            GI_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
+            const size_t bytes = ray_sort_scratch_bytes(npx);
+            GI_HIP(ctx, hipMalloc(&p, bytes));
             g->allocs.push_back(p);
             g->d_sort_temp = p;
             g->sort_temp_bytes = bytes;
@@ -1939,24 +1938,24 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             if (b == 1)
                 hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             if (g->sort_bounce) {
-                size_t bytes = g->sort_temp_bytes;
-                uint32_t* bs = g->d_sort + 4 * npx;
-                GI_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(g->d_sort_temp, bytes, bs + a.first_px, bs + 2 * npx + a.first_px, bs + npx + a.first_px,
-                                                                 bs + 3 * npx + a.first_px, (int)a.n_px, 0, kSortBits, (hipStream_t)stream));
+                uint32_t* bs = g->d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
+                GI_HIP(ctx, ray_sort_pairs(bs + a.first_px, bs + npx + a.first_px, bs + 2 * npx + a.first_px, bs + 3 * npx + a.first_px,
+                                           bs + npx + a.first_px, a.n_px, kSortBits, g->d_sort_temp, (hipStream_t)stream));
                 GiArgs b1 = a;
-                b1.sort_order = bs + 3 * npx + a.first_px;
+                b1.sort_order = bs + npx + a.first_px;
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, dim3((a.n_px + 63) / 64), block, 0, (hipStream_t)stream, b1);
             } else if (b > 1) {
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             }
             hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
             if (g->sort_shadow) {
-                size_t bytes = g->sort_temp_bytes;
-                GI_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(g->d_sort_temp, bytes, g->d_sort + a.first_px, g->d_sort + 2 * npx + a.first_px,
-                                                                 g->d_sort + npx + a.first_px, g->d_sort + 3 * npx + a.first_px, (int)a.n_px, 0, kSortBits,
-                                                                 (hipStream_t)stream));
+                // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the
+                // sorted pixel indices land back in vals
+                GI_HIP(ctx, ray_sort_pairs(g->d_sort + a.first_px, g->d_sort + npx + a.first_px, g->d_sort + 2 * npx + a.first_px,
+                                           g->d_sort + 3 * npx + a.first_px, g->d_sort + npx + a.first_px, a.n_px, kSortBits, g->d_sort_temp,
+                                           (hipStream_t)stream));
                 GiArgs b2 = a;
-                b2.sort_order = g->d_sort + 3 * npx + a.first_px;
+                b2.sort_order = g->d_sort + npx + a.first_px;
                 hipLaunchKernelGGL(gi_shadow_trace_kernel, dim3((a.n_px + 63) / 64), block, 0, (hipStream_t)stream, b2);
             } else {
                 hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);

@@ -31,6 +31,11 @@ hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* r
 hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
                          const uint16_t* variance, const uint32_t* depth, const uint2* normal, hipStream_t s);
 
+// raysort.hip: stable LSD radix sort of (key, value) pairs on key bits [0, bits), bits <= 16 (enqueue only)
+size_t ray_sort_scratch_bytes(size_t n);
+hipError_t ray_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t* vals_out, size_t n, int bits,
+                          void* scratch, hipStream_t stream);
+
 struct GiState;               // gi.hip: scene tables, LBVH, counters
 void gi_destroy(GiState* g);
 void gi_on_resize(GiState* g);
