@@ -41,6 +41,12 @@ struct DevMat {
     int32_t tex[3];
     float albedo[3];
     float rough, metal;
+    // When the material has all three maps and they share one size, their bilinear footprints are also stored
+    // interleaved, one 64-byte entry per texel position {albedo 4 texels, normal 4, roughness/metalness 4, pad}: the
+    // three filtered fetches of a hit (same uv) then touch one line instead of three.  bundle_w == 0: not bundled.
+    uint32_t bundle;   // first entry, in 64-byte units, into SceneView::bundles
+    uint32_t bundle_w, bundle_h;
+    uint32_t pad;
 };
 struct DevTex {
     uint32_t offset; // in footprint entries (16 B), into the texel pool
@@ -92,6 +98,7 @@ struct SceneView {
     const float* uvs;        // 2 per vertex
     const float* tangents;   // 4 per vertex
     const uint32_t* texels;  // RGBA8 bilinear footprint table: 4 texels (16 B) per texel position, see sample_texture
+    const uint4* bundles;    // per-material interleaved footprints (4 x uint4 per texel position), see DevMat::bundle
     const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
     uint32_t n_tris;
     int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
@@ -560,21 +567,24 @@ __device__ __forceinline__ bool traverse(const SceneView& S, float3 o, float3 d,
 }
 
 // SampleLevel(linear, wrap, mip 0) of an RGBA8 UNORM texture (pathtracer.hlsl:359,377,390).
-__device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
+// wrap-addressed texel position and bilinear fractions of (u, v) in a w x h texture
+__device__ __forceinline__ void texel_position(uint32_t w, uint32_t h, float u, float v, int& x0, int& y0, float& fx, float& fy)
 {
-    const DevTex t = S.texs[ti];
-    const float x = u * (float)t.w - 0.5f, y = v * (float)t.h - 0.5f;
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
-    const float fx = x - fx0, fy = y - fy0;
-    const int W = (int)t.w, H = (int)t.h;
-    int x0 = (int)fx0 % W, y0 = (int)fy0 % H;
+    fx = x - fx0;
+    fy = y - fy0;
+    const int W = (int)w, H = (int)h;
+    x0 = (int)fx0 % W;
+    y0 = (int)fy0 % H;
     if (x0 < 0)
         x0 += W;
     if (y0 < 0)
         y0 += H;
-    // bilinear footprint table: entry (x0, y0) holds the four texels {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} with the
-    // wrap already applied, so a filtered fetch is ONE 16-byte load instead of four scattered dwords
-    const uint4 fp = reinterpret_cast<const uint4*>(S.texels)[(size_t)t.offset + (size_t)y0 * W + x0];
+}
+// bilinear filter of one footprint {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} of RGBA8 UNORM texels
+__device__ __forceinline__ float4 filter_footprint(uint4 fp, float fx, float fy)
+{
     const uint32_t p00 = fp.x, p10 = fp.y, p01 = fp.z, p11 = fp.w;
     float r[4];
 #pragma unroll
@@ -585,6 +595,17 @@ __device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
         r[c] = top + fy * (bot - top);
     }
     return make_float4(r[0], r[1], r[2], r[3]);
+}
+__device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
+{
+    const DevTex t = S.texs[ti];
+    int x0, y0;
+    float fx, fy;
+    texel_position(t.w, t.h, u, v, x0, y0, fx, fy);
+    // bilinear footprint table: entry (x0, y0) holds the four texels {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} with the
+    // wrap already applied, so a filtered fetch is ONE 16-byte load instead of four scattered dwords
+    const uint4 fp = reinterpret_cast<const uint4*>(S.texels)[(size_t)t.offset + (size_t)y0 * (int)t.w + x0];
+    return filter_footprint(fp, fx, fy);
 }
 
 __device__ __forceinline__ float3 load3(const float* p, uint32_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -640,10 +661,22 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, 
     if (g.material < 0)
         return false; // :349
     const DevMat m = S.mats[g.material];
+    float4 t_albedo, t_normal, t_rm;
+    const bool bundled = m.bundle_w != 0; // then all three maps exist
+    if (bundled) {
+        int x0, y0;
+        float fx, fy;
+        texel_position(m.bundle_w, m.bundle_h, u, v, x0, y0, fx, fy);
+        const uint4* e = S.bundles + 4 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
+        const uint4 fa = e[0], fn = e[1], fr = e[2]; // one 64-byte line
+        t_albedo = filter_footprint(fa, fx, fy);
+        t_normal = filter_footprint(fn, fx, fy);
+        t_rm = filter_footprint(fr, fx, fy);
+    }
     if (m.tex[0] < 0) {
         out.albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
     } else {
-        const float4 t = sample_texture(S, m.tex[0], u, v);
+        const float4 t = bundled ? t_albedo : sample_texture(S, m.tex[0], u, v);
         out.albedo = f3(t.x, t.y, t.z);
     }
     if (m.tex[1] < 0) {
@@ -660,7 +693,7 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, 
             tg[k] /= l4;
         const float3 T = f3(tg[0], tg[1], tg[2]);
         const float3 B = normalize3(cross3(out.GN, T) * tg[3]);
-        const float4 t = sample_texture(S, m.tex[1], u, v);
+        const float4 t = bundled ? t_normal : sample_texture(S, m.tex[1], u, v);
         const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
         out.SN = normalize3(T * N.x + B * N.y + out.GN * N.z); // mul(N, float3x3(T, B, GN))
     }
@@ -668,7 +701,7 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, 
         out.roughness = m.rough;
         out.metalness = m.metal;
     } else {
-        const float4 t = sample_texture(S, m.tex[2], u, v);
+        const float4 t = bundled ? t_rm : sample_texture(S, m.tex[2], u, v);
         out.roughness = t.y; // .g
         out.metalness = t.z; // .b
     }
@@ -1568,6 +1601,37 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
             }
         }
     }
+    // interleaved footprints of the materials whose three maps share one size (DevMat::bundle); 64 B per texel position
+    std::vector<uint4> bundles;
+    constexpr size_t kBundleBudget = (size_t)4 << 30; // bytes; beyond it the remaining materials sample their maps separately
+    for (uint32_t i = 0; i < n_mats; ++i) {
+        DevMat& d = dmats[i];
+        d.bundle = d.bundle_w = d.bundle_h = d.pad = 0;
+        if (d.tex[0] < 0 || d.tex[1] < 0 || d.tex[2] < 0)
+            continue;
+        const DevTex &ta = dtexs[d.tex[0]], &tn = dtexs[d.tex[1]], &tr = dtexs[d.tex[2]];
+        if (ta.w != tn.w || ta.w != tr.w || ta.h != tn.h || ta.h != tr.h)
+            continue;
+        const size_t n_pos = (size_t)ta.w * ta.h;
+        if ((bundles.size() + 4 * n_pos) * sizeof(uint4) > kBundleBudget || bundles.size() / 4 + n_pos > 0xffffffffull)
+            continue;
+        d.bundle = (uint32_t)(bundles.size() / 4);
+        d.bundle_w = ta.w;
+        d.bundle_h = ta.h;
+        const size_t base = bundles.size();
+        bundles.resize(base + 4 * n_pos);
+        const uint4* fa = reinterpret_cast<const uint4*>(texels.data()) + ta.offset;
+        const uint4* fn = reinterpret_cast<const uint4*>(texels.data()) + tn.offset;
+        const uint4* fr = reinterpret_cast<const uint4*>(texels.data()) + tr.offset;
+        for (size_t k = 0; k < n_pos; ++k) {
+            bundles[base + 4 * k] = fa[k];
+            bundles[base + 4 * k + 1] = fn[k];
+            bundles[base + 4 * k + 2] = fr[k];
+            bundles[base + 4 * k + 3] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (bundles.empty())
+        bundles.push_back(make_uint4(0, 0, 0, 0));
     g->n_tris = (uint32_t)(g->h_tris.size() / 12);
     memcpy(g->scene_min, smin, sizeof(smin));
     memcpy(g->scene_max, smax, sizeof(smax));
@@ -1575,7 +1639,8 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
     if ((e = upload(g, dgeoms, &g->view.geoms)) != hipSuccess || (e = upload(g, dmats, &g->view.mats)) != hipSuccess ||
         (e = upload(g, dtexs, &g->view.texs)) != hipSuccess || (e = upload(g, indices, &g->view.indices)) != hipSuccess ||
         (e = upload(g, normals, &g->view.normals)) != hipSuccess || (e = upload(g, uvs, &g->view.uvs)) != hipSuccess ||
-        (e = upload(g, tangents, &g->view.tangents)) != hipSuccess || (e = upload(g, texels, &g->view.texels)) != hipSuccess) {
+        (e = upload(g, tangents, &g->view.tangents)) != hipSuccess || (e = upload(g, texels, &g->view.texels)) != hipSuccess ||
+        (e = upload(g, bundles, &g->view.bundles)) != hipSuccess) {
         gi_destroy(g);
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: upload", e);
     }
