@@ -1095,12 +1095,16 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
     }
     const bool last_vertex = a.bounce + 1 >= a.c.maxPathVertices;
     if (a.sample + 1 == a.c.samplesPerPixel && last_vertex && !a.defer_resolve) { // stands in for NRC Resolve: radiance[cur] += mean over spp
-        const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
-        float4 r = a.radiance[i];
-        r.x += sum.x * inv_spp;
-        r.y += sum.y * inv_spp;
-        r.z += sum.z * inv_spp;
-        a.radiance[i] = r;
+        // (pixels are visited in sorted order here: the read-modify-write is a gather + scatter, so an occluded ray
+        // with nothing else to add -- about half of them -- leaves radiance[cur] alone: x + 0 == x)
+        if (sum.x != 0.0f || sum.y != 0.0f || sum.z != 0.0f) {
+            const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
+            float4 r = a.radiance[i];
+            r.x += sum.x * inv_spp;
+            r.y += sum.y * inv_spp;
+            r.z += sum.z * inv_spp;
+            a.radiance[i] = r;
+        }
     } else {
         a.R.srec[4 * i + kSrSum] = sum;
     }
