@@ -26,16 +26,28 @@ def upload_gbuffer(r, gb):
     r.svgf.upload(PLANE_DEPTH, SLOT_CURRENT, gb["depth"])
 
 
+def _atrium_mixed_textures():
+    """atrium_small with every other textured material given a normal map of another, non-square size: those materials
+    cannot use the interleaved footprint table (DevMat::bundle) and sample their three maps separately."""
+    sc = S.atrium_standin(target_triangles=30000, n_submeshes=60, tex_size=64)
+    for k, m in enumerate(sc.materials):
+        if m["textures"][1] >= 0 and k % 2 == 0:
+            sc.textures[m["textures"][1]] = np.ascontiguousarray(S._proc_texture("normal", 900 + k, 48)[:32])  # 32 rows x 48 columns
+    return sc
+
+
 def scenes():
     return {
+        "atrium_mixed_tex": (_atrium_mixed_textures, S.sponza_camera(), 320, 184),
         "cornell": (lambda: S.cornell_standin(textured=True), S.orbit_camera(), 256, 256),
         "cornell_factors": (lambda: S.cornell_standin(textured=False), S.orbit_camera(yaw_deg=10.0, pitch_deg=80.0, distance=2.6), 200, 152),
         "atrium_small": (lambda: S.atrium_standin(target_triangles=30000, n_submeshes=60, tex_size=64), S.sponza_camera(), 320, 184),
     }
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_factors", "atrium_small"])
-@pytest.mark.parametrize("spp,sort_rays", [(1, 0), (3, 1), (1, 3), (2, 2)])
+@pytest.mark.parametrize("name,spp,sort_rays",
+                         [(n, s, m) for n in ("cornell", "cornell_factors", "atrium_small") for s, m in ((1, 0), (3, 1), (1, 3), (2, 2))]
+                         + [("atrium_mixed_tex", 1, 1)])
 def test_gi_matches_oracle(name, spp, sort_rays):
     make, cam, W, H = scenes()[name]
     sc = make()
