@@ -292,7 +292,8 @@ def main():
                                    f"{args.spp} spp one-bounce GI + SVGF temporal + {L} a-trous levels"
                                    + ("" if do_gi else " [GI skipped: --svgf-only]"),
                        "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
-                       "parallelism": f"row-strips x{world} + RCCL a-trous halo exchange" if world > 1 else "single GPU",
+                       "parallelism": (f"row-strips x{world} + RCCL halo exchange ({'one per frame' if part.scheme == 'once' else 'one per a-trous level'}, "
+                                       f"{part.exchanged_bytes_per_frame() / 1e6:.1f} MB sent per rank and frame)") if world > 1 else "single GPU",
                        "frames_in_flight": 2 if overlap else 1},
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
             "gi_kernel_mrays_per_s": (rays_ev / 8 / t_gi / 1e6) if do_gi else None,

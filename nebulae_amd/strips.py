@@ -4,20 +4,26 @@ The reference is single-GPU; this is new functionality whose ora
 "N-GPU output == 1-GPU output, bit for bit".  Every stage of the path is per-pixel except the
 a-trous wavelet, whose level l reads rows up to 2 * 2^l away (svgf_atrous.hlsl:51-65), so:
 
-* rank r owns image rows [r*H/N, (r+1)*H/N) and keeps rows [own0 - h, own1 + h) resident,
-  h = 2 * 2^(L-1) (the widest level's reach), clipped to the image; the G-buffer producer fills
-  depth/normal for all resident rows (no exchange: variance is only read at the centre texel,
-  quirk 4, and depth/normal halos come from the producer);
-* GI, temporal accumulation and every a-trous level run on the OWNED rows only;
-* before level l each rank swaps the 2 * 2^l boundary rows of that level's source radiance plane
-  with its up/down neighbour -- contiguous row blocks sent straight out of the plane
-  (``torch.distributed`` P2P, backend "nccl" = RCCL over xGMI; one direct link per neighbour);
-* history needs no exchange: next frame's temporal pass reads history at owned rows only.
+* rank r owns image rows [r*H/N, (r+1)*H/N) and keeps `halo` more rows resident on either side, clipped to the
+  image; the G-buffer producer fills depth/normal for all resident rows (no exchange for those);
+* GI and temporal accumulation run on the OWNED rows only; history needs no exchange (next frame's temporal
+  pass reads history at owned rows only).
 
-Per frame and direction that is sum_l 2*2^l rows (62 for L=5) of W*16 B.  The alternative of
-SURVEY.md 8e (recompute the narrow levels on overlapped rows, exchange only the widest level plus a
-history-consistency block) moves the same number of rows in 2 messages instead of L; it is not
-implemented yet (DESIGN.md "Multi-GPU").
+Two exchange schemes (``StripPartition(scheme=...)``, both bit-identical to one GPU):
+
+``"once"`` (default) -- ONE exchange per frame.  After the temporal pass each rank swaps its h = sum_l 2*2^l
+  (62 for L = 5) boundary rows of the temporally accumulated radiance (16 B/px) and of the variance plane
+  (2 B/px, read at a level's centre texel) with its up/down neighbour, then runs level l on
+  ``owned +- e_l`` rows, e_l = sum_{m>l} 2*2^m: the rows later levels still reach into.  The redundant a-trous
+  work is sum_l 2 e_l rows (392 row-levels against 5 * 540 at 4K/4, +14 % of a stage that is a fifth of the frame)
+  and buys 4 fewer exchange / stream-sync points per frame.  This is SURVEY.md 8e's "fully redundant tiling"
+  applied to the cheap stage only: GI and temporal are never recomputed.
+
+``"per_level"`` -- L exchanges per frame: before level l the 2 * 2^l boundary rows of that level's source plane
+  are swapped; every level runs on owned rows only; halo = 2 * 2^(L-1).
+
+Both move 62 radiance rows per direction and frame at L = 5; rows are contiguous row blocks sent straight out of
+the plane (``torch.distributed`` P2P, backend "nccl" = RCCL over xGMI; one direct link per neighbour).
 
 The compute backend is injected (``denoiser_factory``): the product uses the HIP ``SVGFDenoiser``;
 the world_size-2 gloo tests inject an oracle-backed stand-in to exercise exactly this file on CPU.
@@ -25,7 +31,7 @@ the world_size-2 gloo tests inject an oracle-backed stand-in to exercise exactly
 import math
 
 from .renderer import DeferredRenderer
-from .svgf import PLANE_RADIANCE, PLANE_SCRATCH, SVGFDenoiser
+from .svgf import PLANE_RADIANCE, PLANE_SCRATCH, PLANE_VARIANCE, SVGFDenoiser
 
 
 def frame_factors(n):
@@ -37,11 +43,18 @@ def frame_factors(n):
 
 
 class StripPartition:
-    def __init__(self, width, height, world, levels):
+    def __init__(self, width, height, world, levels, scheme=None):
+        import os
         if height % world:
             raise ValueError(f"image height {height} is not divisible by {world} strips")
+        self.scheme = scheme or os.environ.get("NEB_STRIPS_SCHEME") or "once"
+        if self.scheme not in ("once", "per_level"):
+            raise ValueError(f"unknown exchange scheme {self.scheme!r}")
         self.W, self.H, self.N, self.L = width, height, world, levels
-        self.halo = 2 * (1 << (levels - 1)) if (world > 1 and levels > 0) else 0
+        if world > 1 and levels > 0:
+            self.halo = 2 * ((1 << levels) - 1) if self.scheme == "once" else 2 * (1 << (levels - 1))
+        else:
+            self.halo = 0
         if world > 1 and height // world < self.halo:
             raise ValueError("strips are shorter than the a-trous reach; use fewer GPUs or fewer levels")
 
@@ -57,13 +70,19 @@ class StripPartition:
         a, b = self.owned(r)
         return b - a
 
-    def atrous_rows(self, r, level):
-        a, b = self.owned(r)
-        return b - a
+    def level_extension(self, level):
+        """rows beyond the owned strip that `level` must also filter: what the later levels still reach into"""
+        if self.N == 1 or self.scheme != "once":
+            return 0
+        return sum(2 * (1 << m) for m in range(level + 1, self.L))
 
-    def level_exchange(self, r, level):
-        """[(peer, (send_row0, send_row1), (recv_row0, recv_row1))] for the source plane of `level`."""
-        n = 2 * (1 << level)
+    def atrous_rows(self, r, level):
+        """image rows [row0, row1) rank r filters at `level`"""
+        a, b = self.owned(r)
+        e = self.level_extension(level)
+        return max(0, a - e), min(self.H, b + e)
+
+    def _swap(self, r, n):
         a, b = self.owned(r)
         out = []
         if r > 0:
@@ -72,9 +91,20 @@ class StripPartition:
             out.append((r + 1, (b - n, b), (b, b + n)))
         return out
 
+    def frame_exchange(self, r):
+        """scheme "once": [(peer, (send_row0, send_row1), (recv_row0, recv_row1))] after the temporal pass"""
+        return self._swap(r, self.halo) if (self.scheme == "once" and self.halo) else []
+
+    def level_exchange(self, r, level):
+        """scheme "per_level": the same for the source plane of `level`"""
+        return self._swap(r, 2 * (1 << level)) if (self.scheme == "per_level" and self.N > 1) else []
+
     def exchanged_bytes_per_frame(self):
-        """radiance bytes a middle rank sends per frame (both neighbours)."""
-        return 2 * sum(2 * (1 << l) for l in range(self.L)) * self.W * 16 if self.N > 1 else 0
+        """bytes a middle rank sends per frame (both neighbours)"""
+        if self.N == 1:
+            return 0
+        rows = sum(2 * (1 << l) for l in range(self.L))
+        return 2 * rows * self.W * (16 + 2 if self.scheme == "once" else 16)
 
 
 class StripRenderer(DeferredRenderer):
@@ -100,16 +130,15 @@ class StripRenderer(DeferredRenderer):
     def submit_commands_gi_pathtrace(self, rows=None, stream=None):
         super().submit_commands_gi_pathtrace(rows=self.part.owned(self.rank) if rows is None else rows, stream=stream)
 
-    def exchange_halo(self, level):
-        """Swap the boundary rows of `level`'s source plane with the neighbouring strips."""
+    def _swap_rows(self, planes, plan):
+        """One batched P2P exchange: for every (plane, slot) and every (peer, send rows, recv rows) of the plan."""
+        import torch
         import torch.distributed as dist
-        (sp, ss), _ = self.svgf.atrous_level_planes(level)
-        plan = self.part.level_exchange(self.rank, level)
         if not plan:
             return
-        import torch
-        send = [self._plane_rows(sp, ss, s0, s1) for _, (s0, s1), _ in plan]
-        recv = [self._plane_rows(sp, ss, r0, r1) for _, _, (r0, r1) in plan]
+        send = [self._plane_rows(p, sl, s0, s1) for p, sl in planes for _, (s0, s1), _ in plan]
+        recv = [self._plane_rows(p, sl, r0, r1) for p, sl in planes for _, _, (r0, r1) in plan]
+        peers = [peer for _ in planes for peer, _, _ in plan]
         # staging modes: None = zero copy (rows go straight out of / into the plane: the default on RCCL);
         # "host" = through host memory (gloo rehearsal on a box without RCCL peers);
         # "device" = through torch-allocated device buffers (NEB_STRIPS_STAGING=device: for RCCL builds that insist on
@@ -126,7 +155,7 @@ class StripRenderer(DeferredRenderer):
             send = [t.clone() for t in send]
             dst = [torch.empty_like(t) for t in recv]
         ops = []
-        for k, (peer, _, _) in enumerate(plan):
+        for k, peer in enumerate(peers):
             ops.append(dist.P2POp(dist.isend, send[k], peer, group=self.group))
             ops.append(dist.P2POp(dist.irecv, dst[k], peer, group=self.group))
         for w in dist.batch_isend_irecv(ops):
@@ -134,6 +163,16 @@ class StripRenderer(DeferredRenderer):
         if mode is not None:
             for d, s_ in zip(recv, dst):
                 d.copy_(s_)
+
+    def exchange_frame_halo(self):
+        """scheme "once": swap the boundary rows of the temporally accumulated radiance and of the variance plane"""
+        cur = self.svgf.get_current_resource_index()
+        self._swap_rows([(PLANE_RADIANCE, cur), (PLANE_VARIANCE, 0)], self.part.frame_exchange(self.rank))
+
+    def exchange_halo(self, level):
+        """scheme "per_level": swap the boundary rows of `level`'s source plane with the neighbouring strips"""
+        (sp, ss), _ = self.svgf.atrous_level_planes(level)
+        self._swap_rows([(sp, ss)], self.part.level_exchange(self.rank, level))
 
     def submit_commands_svgf_denoising(self, events=None):
         if self.dynamic_scene_this_frame:  # src/DeferredRenderer.cpp:595
@@ -149,12 +188,14 @@ class StripRenderer(DeferredRenderer):
         if events is not None:
             events["t1"].record()
         L = self.part.L
+        if self.part.N > 1 and self.part.scheme == "once":
+            self.exchange_frame_halo()
         for level in range(L):
-            if self.part.N > 1:
+            if self.part.N > 1 and self.part.scheme == "per_level":
                 self.exchange_halo(level)
             if events is not None:
                 events["levels"][level][0].record()
-            self.svgf.submit_atrous_level(level, own, st)
+            self.svgf.submit_atrous_level(level, self.part.atrous_rows(self.rank, level), st)
             if events is not None:
                 events["levels"][level][1].record()
         if L == 1:  # single level filters into the scratch plane: copy the owned rows back (api.hip: neb_svgf_atrous)

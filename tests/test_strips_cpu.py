@@ -18,16 +18,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_partition_geometry():
+    # default scheme: one exchange per frame, levels run on owned +- (rows the later levels still reach into)
     p = strips.StripPartition(3840, 2160, 4, 5)
-    assert p.halo == 32 and p.owned(1) == (540, 1080) and p.resident(0) == (0, 572) and p.resident(3) == (1588, 2160)
-    assert p.level_exchange(0, 4) == [(1, (508, 540), (540, 572))]
-    assert p.level_exchange(2, 0) == [(1, (1080, 1082), (1078, 1080)), (3, (1618, 1620), (1620, 1622))]
-    assert p.exchanged_bytes_per_frame() == 2 * 62 * 3840 * 16  # 62 rows per direction
+    assert p.scheme == "once" and p.halo == 62 and p.owned(1) == (540, 1080)
+    assert p.resident(0) == (0, 602) and p.resident(3) == (1558, 2160)
+    assert [p.level_extension(l) for l in range(5)] == [60, 56, 48, 32, 0]
+    assert p.atrous_rows(0, 0) == (0, 600) and p.atrous_rows(2, 1) == (1080 - 56, 1620 + 56) and p.atrous_rows(3, 4) == (1620, 2160)
+    assert p.frame_exchange(0) == [(1, (478, 540), (540, 602))]
+    assert p.frame_exchange(2) == [(1, (1080, 1142), (1018, 1080)), (3, (1558, 1620), (1620, 1682))]
+    assert p.level_exchange(2, 0) == []
+    assert p.exchanged_bytes_per_frame() == 2 * 62 * 3840 * 18  # 62 rows per direction of radiance + variance
+    # SURVEY.md 8e's per-level scheme
+    q = strips.StripPartition(3840, 2160, 4, 5, scheme="per_level")
+    assert q.halo == 32 and q.resident(0) == (0, 572) and q.resident(3) == (1588, 2160)
+    assert q.level_exchange(0, 4) == [(1, (508, 540), (540, 572))]
+    assert q.level_exchange(2, 0) == [(1, (1080, 1082), (1078, 1080)), (3, (1618, 1620), (1620, 1622))]
+    assert q.frame_exchange(1) == [] and q.atrous_rows(1, 0) == q.owned(1)
+    assert q.exchanged_bytes_per_frame() == 2 * 62 * 3840 * 16  # 62 rows per direction
     assert strips.frame_factors(1) == (1, 1) and strips.frame_factors(4) == (2, 2) and strips.frame_factors(8) == (2, 4)
     one = strips.StripPartition(1920, 1080, 1, 5)
-    assert one.halo == 0 and one.resident(0) == (0, 1080) and one.level_exchange(0, 3) == []
+    assert one.halo == 0 and one.resident(0) == (0, 1080) and one.level_exchange(0, 3) == [] and one.frame_exchange(0) == []
+    assert one.atrous_rows(0, 2) == (0, 1080)
     with pytest.raises(ValueError):
-        strips.StripPartition(64, 48, 4, 5)  # 12-row strips cannot feed a 32-row reach
+        strips.StripPartition(64, 48, 4, 5)  # 12-row strips cannot feed the a-trous reach
 
 
 def _frames(W, H, n):
@@ -56,12 +69,12 @@ def _run_frames(r, part, rank, frames, moving_frame=None):
     return r.svgf.plane_tensor(PLANE_RADIANCE, cur)[own0 - res0:own1 - res0].clone(), ran
 
 
-def _worker(rank, world, port, W, H, L, nframes, moving_frame, out_dir):
+def _worker(rank, world, port, W, H, L, nframes, moving_frame, out_dir, scheme):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OracleDenoiser
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    part = strips.StripPartition(W, H, world, L)
+    part = strips.StripPartition(W, H, world, L, scheme=scheme)
     r = strips.StripRenderer(part, rank, group=dist.group.WORLD, denoiser_factory=OracleDenoiser)
     out, ran = _run_frames(r, part, rank, _frames(W, H, nframes), moving_frame)
     np.save(os.path.join(out_dir, f"strip_{rank}.npy"), out.numpy())
@@ -70,12 +83,14 @@ def _worker(rank, world, port, W, H, L, nframes, moving_frame, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H,L,moving", [(2, 64, 144, 5, None), (3, 72, 120, 4, None), (2, 64, 80, 3, 2), (2, 40, 64, 1, None)])
-def test_strips_equal_single_process_bit_for_bit(tmp_path, world, W, H, L, moving):
+@pytest.mark.parametrize("world,W,H,L,moving,scheme", [(2, 64, 144, 5, None, "once"), (3, 72, 120, 4, None, "once"), (2, 64, 80, 3, 2, "once"),
+                                                        (2, 40, 64, 1, None, "once"), (2, 64, 144, 5, None, "per_level"),
+                                                        (3, 72, 120, 4, 3, "per_level")])
+def test_strips_equal_single_process_bit_for_bit(tmp_path, world, W, H, L, moving, scheme):
     from oracle_backend import OracleDenoiser
     nframes = 4
     port = 29500 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, W, H, L, nframes, moving, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, W, H, L, nframes, moving, str(tmp_path), scheme), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"strip_{k}.npy") for k in range(world)], axis=0)
     part1 = strips.StripPartition(W, H, 1, L)
     r1 = strips.StripRenderer(part1, 0, denoiser_factory=OracleDenoiser)

@@ -8,28 +8,26 @@ import torch
 from nebulae_amd import scene as S
 from nebulae_amd import strips
 from nebulae_amd.renderer import RenderInfo
-from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE
+from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE, PLANE_VARIANCE
 
 pytestmark = pytest.mark.gpu
 
 
-def test_two_strips_equal_full_image_gi_plus_svgf():
+@pytest.mark.parametrize("scheme", ["once", "per_level"])
+def test_two_strips_equal_full_image_gi_plus_svgf(scheme):
     W, H, L, N = 256, 192, 5, 2
     sc = S.atrium_standin(target_triangles=20000, n_submeshes=40, tex_size=32)
     cam = S.sponza_camera()
     full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
-    part = strips.StripPartition(W, H, N, L)
+    part = strips.StripPartition(W, H, N, L, scheme=scheme)
     rs = [strips.StripRenderer(part, k) for k in range(N)]
 
-    def make_exchange(me):
-        def exchange(level):
-            (sp, ss), _ = rs[me].svgf.atrous_level_planes(level)
-            for peer, (s0, s1), (r0, r1) in part.level_exchange(me, level):
+    def pull(me, planes, plan):
+        for p, sl in planes:
+            for peer, _, (r0, r1) in plan:
                 # pull what the peer would send: its owned rows [r0, r1) of the same plane
-                rs[me]._plane_rows(sp, ss, r0, r1).copy_(rs[peer]._plane_rows(sp, ss, r0, r1))
-        return exchange
+                rs[me]._plane_rows(p, sl, r0, r1).copy_(rs[peer]._plane_rows(p, sl, r0, r1))
 
-    outs = []
     for f in range(1, 6):
         info = RenderInfo(scene=sc, camera=cam, frame_index=f)
         for r in [full] + rs:
@@ -40,23 +38,27 @@ def test_two_strips_equal_full_image_gi_plus_svgf():
             r.submit_commands_gi_pathtrace()
         torch.cuda.synchronize()
         ran_full = full.submit_commands_svgf_denoising()
-        # strips: run the denoiser level by level in lock-step so the emulated exchange sees finished rows
-        ran = []
-        for k, r in enumerate(rs):
-            r.exchange_halo = make_exchange(k)
+        # strips: run the denoiser in lock-step so the emulated exchange sees finished rows
         if not rs[0].dynamic_scene_this_frame:
             for r in rs:
                 if r.reset_history:
                     r.reset_history = False
                     r.svgf.reset_history()
                 r.svgf.submit_temporal_accumulation(rows=part.owned(r.rank))
+            torch.cuda.synchronize()
+            if scheme == "once":
+                for k, r in enumerate(rs):
+                    cur = r.svgf.get_current_resource_index()
+                    pull(k, [(PLANE_RADIANCE, cur), (PLANE_VARIANCE, 0)], part.frame_exchange(k))
             for level in range(L):
                 torch.cuda.synchronize()
-                for r in rs:
-                    r.exchange_halo(level)
+                if scheme == "per_level":
+                    for k, r in enumerate(rs):
+                        (sp, ss), _ = r.svgf.atrous_level_planes(level)
+                        pull(k, [(sp, ss)], part.level_exchange(k, level))
                 torch.cuda.synchronize()
                 for r in rs:
-                    r.svgf.submit_atrous_level(level, part.owned(r.rank))
+                    r.svgf.submit_atrous_level(level, part.atrous_rows(r.rank, level))
             ran = [True] * N
         else:
             ran = [False] * N
