@@ -130,12 +130,14 @@ class StripRenderer(DeferredRenderer):
     def submit_commands_gi_pathtrace(self, rows=None, stream=None):
         super().submit_commands_gi_pathtrace(rows=self.part.owned(self.rank) if rows is None else rows, stream=stream)
 
-    def _swap_rows(self, planes, plan):
-        """One batched P2P exchange: for every (plane, slot) and every (peer, send rows, recv rows) of the plan."""
+    def _swap_rows_begin(self, planes, plan):
+        """Starts one batched P2P exchange -- for every (plane, slot) and every (peer, send rows, recv rows) of the plan --
+        and returns the function that completes it (makes the current stream wait for the transfer).  Work enqueued on
+        the current stream between the two runs beside the transfer; it must not touch the rows being received."""
         import torch
         import torch.distributed as dist
         if not plan:
-            return
+            return lambda: None
         send = [self._plane_rows(p, sl, s0, s1) for p, sl in planes for _, (s0, s1), _ in plan]
         recv = [self._plane_rows(p, sl, r0, r1) for p, sl in planes for _, _, (r0, r1) in plan]
         peers = [peer for _ in planes for peer, _, _ in plan]
@@ -158,16 +160,23 @@ class StripRenderer(DeferredRenderer):
         for k, peer in enumerate(peers):
             ops.append(dist.P2POp(dist.isend, send[k], peer, group=self.group))
             ops.append(dist.P2POp(dist.irecv, dst[k], peer, group=self.group))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if mode is not None:
-            for d, s_ in zip(recv, dst):
-                d.copy_(s_)
+        works = dist.batch_isend_irecv(ops)
 
-    def exchange_frame_halo(self):
-        """scheme "once": swap the boundary rows of the temporally accumulated radiance and of the variance plane"""
+        def finish():
+            for w in works:
+                w.wait()
+            if mode is not None:
+                for d, s_ in zip(recv, dst):
+                    d.copy_(s_)
+        return finish
+
+    def _swap_rows(self, planes, plan):
+        self._swap_rows_begin(planes, plan)()
+
+    def exchange_frame_halo_begin(self):
+        """scheme "once": start swapping the boundary rows of the temporally accumulated radiance and of the variance plane"""
         cur = self.svgf.get_current_resource_index()
-        self._swap_rows([(PLANE_RADIANCE, cur), (PLANE_VARIANCE, 0)], self.part.frame_exchange(self.rank))
+        return self._swap_rows_begin([(PLANE_RADIANCE, cur), (PLANE_VARIANCE, 0)], self.part.frame_exchange(self.rank))
 
     def exchange_halo(self, level):
         """scheme "per_level": swap the boundary rows of `level`'s source plane with the neighbouring strips"""
@@ -188,14 +197,27 @@ class StripRenderer(DeferredRenderer):
         if events is not None:
             events["t1"].record()
         L = self.part.L
-        if self.part.N > 1 and self.part.scheme == "once":
-            self.exchange_frame_halo()
+        once = self.part.N > 1 and self.part.scheme == "once"
         for level in range(L):
+            rows = self.part.atrous_rows(self.rank, level)
             if self.part.N > 1 and self.part.scheme == "per_level":
                 self.exchange_halo(level)
             if events is not None:
                 events["levels"][level][0].record()
-            self.svgf.submit_atrous_level(level, self.part.atrous_rows(self.rank, level), st)
+            if once and level == 0:
+                # the exchange runs beside level 0 on the rows that need none of the incoming halo (taps reach 2 rows)
+                finish = self.exchange_frame_halo_begin()
+                top = own[0] + 2 if self.rank > 0 else rows[0]
+                bot = own[1] - 2 if self.rank < self.part.N - 1 else rows[1]
+                if top < bot:
+                    self.svgf.submit_atrous_level(0, (top, bot), st)
+                finish()
+                if rows[0] < top:
+                    self.svgf.submit_atrous_level(0, (rows[0], top), st)
+                if bot < rows[1]:
+                    self.svgf.submit_atrous_level(0, (bot, rows[1]), st)
+            else:
+                self.svgf.submit_atrous_level(level, rows, st)
             if events is not None:
                 events["levels"][level][1].record()
         if L == 1:  # single level filters into the scratch plane: copy the owned rows back (api.hip: neb_svgf_atrous)
