@@ -16,6 +16,7 @@
 #pragma clang fp contract(off)
 
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 #include <cmath>
 #include <cstring>
@@ -86,6 +87,9 @@ static_assert(sizeof(Bvh4Node) == 128 && offsetof(Bvh4Node, hix) == offsetof(Bvh
 #define NEB_LEAF_BATCH 12
 #endif
 constexpr int kLeafBatch = NEB_LEAF_BATCH;
+#ifndef NEB_TOP_SAH
+#define NEB_TOP_SAH 2 // > 0: LBVH subtrees of up to this many triangles are re-linked by a sweep-SAH top level (host pass); 0 / 512 / 64 / 16 / 8 / 4 / 2 / 1 measured 464 / 454 / 437 / 427 / 419 / 403 / 400 / 474 us for the closest-hit pass
+#endif
 #ifndef NEB_MAX_LEAF_TRIS
 #define NEB_MAX_LEAF_TRIS 2 // 1..4 (the leaf code keeps count - 1 in two bits); measured 1/2/3/4: 1407 / 1390 / 1403 / 1500 us of GI per 1080p frame
 #endif
@@ -1826,12 +1830,159 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
                 int id;        // binary child code: >= 0 inner, < 0 ~triangle
                 float lo[3], hi[3];
             };
+            int bin_root = 0;
+#if NEB_TOP_SAH
+            // ---- HLBVH-style top level: the LBVH subtrees of at most NEB_TOP_SAH triangles stay as built on the device;
+            // the levels above them are re-linked here by a sweep-SAH build over those subtrees' boxes.  Morton splits
+            // are blind to box overlap and hurt most near the root, where every ray pays for them. ----
+            {
+                struct Cluster {
+                    Ref ref;
+                    uint32_t cnt;
+                    float c[3];
+                };
+                std::vector<Cluster> cl;
+                {
+                    std::vector<Ref> stk;
+                    Ref root{0, {0, 0, 0}, {0, 0, 0}};
+                    for (int q = 0; q < 3; ++q) {
+                        root.lo[q] = fminf(bin[0].c0min[q], bin[0].c1min[q]);
+                        root.hi[q] = fmaxf(bin[0].c0max[q], bin[0].c1max[q]);
+                    }
+                    stk.push_back(root);
+                    while (!stk.empty()) {
+                        const Ref r = stk.back();
+                        stk.pop_back();
+                        const uint32_t c = r.id >= 0 ? count[r.id] : 1u;
+                        if (r.id < 0 || c <= (uint32_t)NEB_TOP_SAH) {
+                            Cluster k{r, c, {0.5f * (r.lo[0] + r.hi[0]), 0.5f * (r.lo[1] + r.hi[1]), 0.5f * (r.lo[2] + r.hi[2])}};
+                            cl.push_back(k);
+                            continue;
+                        }
+                        Ref a, b;
+                        a.id = bin[r.id].c0;
+                        b.id = bin[r.id].c1;
+                        memcpy(a.lo, bin[r.id].c0min, 12);
+                        memcpy(a.hi, bin[r.id].c0max, 12);
+                        memcpy(b.lo, bin[r.id].c1min, 12);
+                        memcpy(b.hi, bin[r.id].c1max, 12);
+                        stk.push_back(a);
+                        stk.push_back(b);
+                    }
+                }
+                if (cl.size() > 1) {
+                    auto area = [](const float* lo, const float* hi) {
+                        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                        return dx * dy + dy * dz + dz * dx;
+                    };
+                    std::vector<uint32_t> idx(cl.size());
+                    for (size_t k = 0; k < idx.size(); ++k)
+                        idx[k] = (uint32_t)k;
+                    std::vector<float> suffix_area;
+                    std::vector<uint32_t> suffix_cnt;
+                    // explicit work stack: {l, r, slot to patch}; a patch slot is (node index << 1 | child) or -1 for the root
+                    struct Job {
+                        size_t l, r;
+                        long patch;
+                    };
+                    std::vector<Job> jobs{{0, cl.size(), -1}};
+                    auto set_child = [&](long patch, const Ref& rf) {
+                        if (patch < 0) {
+                            bin_root = rf.id;
+                            return;
+                        }
+                        BvhNode& nd = bin[(size_t)(patch >> 1)];
+                        if (patch & 1) {
+                            nd.c1 = rf.id;
+                            memcpy(nd.c1min, rf.lo, 12);
+                            memcpy(nd.c1max, rf.hi, 12);
+                        } else {
+                            nd.c0 = rf.id;
+                            memcpy(nd.c0min, rf.lo, 12);
+                            memcpy(nd.c0max, rf.hi, 12);
+                        }
+                    };
+                    while (!jobs.empty()) {
+                        const Job jb = jobs.back();
+                        jobs.pop_back();
+                        const size_t m = jb.r - jb.l;
+                        if (m == 1) {
+                            set_child(jb.patch, cl[idx[jb.l]].ref);
+                            continue;
+                        }
+                        int best_axis = 0;
+                        size_t best_k = jb.l + m / 2;
+                        float best_cost = INFINITY;
+                        for (int ax = 0; ax < 3; ++ax) {
+                            std::sort(idx.begin() + (long)jb.l, idx.begin() + (long)jb.r,
+                                      [&](uint32_t a, uint32_t b) { return cl[a].c[ax] < cl[b].c[ax] || (cl[a].c[ax] == cl[b].c[ax] && a < b); });
+                            suffix_area.assign(m + 1, 0.f);
+                            suffix_cnt.assign(m + 1, 0u);
+                            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                            for (size_t k = m; k-- > 0;) {
+                                const Cluster& c = cl[idx[jb.l + k]];
+                                for (int q = 0; q < 3; ++q) {
+                                    lo[q] = fminf(lo[q], c.ref.lo[q]);
+                                    hi[q] = fmaxf(hi[q], c.ref.hi[q]);
+                                }
+                                suffix_area[k] = area(lo, hi);
+                                suffix_cnt[k] = suffix_cnt[k + 1] + c.cnt;
+                            }
+                            float plo[3] = {INFINITY, INFINITY, INFINITY}, phi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                            uint32_t pc = 0;
+                            for (size_t k = 1; k < m; ++k) { // split before element k
+                                const Cluster& c = cl[idx[jb.l + k - 1]];
+                                for (int q = 0; q < 3; ++q) {
+                                    plo[q] = fminf(plo[q], c.ref.lo[q]);
+                                    phi[q] = fmaxf(phi[q], c.ref.hi[q]);
+                                }
+                                pc += c.cnt;
+                                const float cost = area(plo, phi) * (float)pc + suffix_area[k] * (float)suffix_cnt[k];
+                                if (cost < best_cost) {
+                                    best_cost = cost;
+                                    best_axis = ax;
+                                    best_k = jb.l + k;
+                                }
+                            }
+                        }
+                        if (best_axis != 2)
+                            std::sort(idx.begin() + (long)jb.l, idx.begin() + (long)jb.r, [&](uint32_t a, uint32_t b) {
+                                return cl[a].c[best_axis] < cl[b].c[best_axis] || (cl[a].c[best_axis] == cl[b].c[best_axis] && a < b);
+                            });
+                        // new inner node over [l, best_k) and [best_k, r)
+                        Ref self;
+                        self.id = (int)bin.size();
+                        for (int q = 0; q < 3; ++q) {
+                            self.lo[q] = INFINITY;
+                            self.hi[q] = -INFINITY;
+                        }
+                        uint32_t total = 0;
+                        for (size_t k = jb.l; k < jb.r; ++k) {
+                            const Cluster& c = cl[idx[k]];
+                            for (int q = 0; q < 3; ++q) {
+                                self.lo[q] = fminf(self.lo[q], c.ref.lo[q]);
+                                self.hi[q] = fmaxf(self.hi[q], c.ref.hi[q]);
+                            }
+                            total += c.cnt;
+                        }
+                        bin.emplace_back();
+                        count.push_back(total);
+                        first.push_back(0); // (never a leaf: it spans more than one cluster)
+                        set_child(jb.patch, self);
+                        jobs.push_back({jb.l, best_k, ((long)self.id << 1) | 0});
+                        jobs.push_back({best_k, jb.r, ((long)self.id << 1) | 1});
+                    }
+                }
+            }
+#endif
             auto leaf_code = [&](const Ref& r) -> int {
                 const uint32_t f = r.id >= 0 ? first[r.id] : (uint32_t)~r.id;
                 const uint32_t c = r.id >= 0 ? count[r.id] : 1u;
                 return ~(int)((f << 2) | (c - 1u));
             };
-            auto is_leaf = [&](const Ref& r) { return r.id < 0 || count[r.id] <= (uint32_t)kMaxLeafTris; };
+            // (only a device-built LBVH subtree covers a contiguous run of the sorted triangles; the top nodes linked
+            // above never do, however few triangles they hold)
+            auto is_leaf = [&](const Ref& r) { return r.id < 0 || (r.id < (int)(n - 1) && count[r.id] <= (uint32_t)kMaxLeafTris); };
             auto area = [](const Ref& r) {
                 const float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
                 return dx * dy + dy * dz + dz * dx;
@@ -1849,7 +2000,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             } else {
                 root_code = 0;
                 // work list of (binary node, wide slot index); wide nodes are emitted in DFS order
-                std::vector<std::pair<int, int>> work{{0, 0}};
+                std::vector<std::pair<int, int>> work{{bin_root, 0}};
                 wide.emplace_back();
                 while (!work.empty()) {
                     const auto [bi, wi] = work.back();
