@@ -90,6 +90,10 @@ constexpr int kLeafBatch = NEB_LEAF_BATCH;
 #ifndef NEB_TOP_SAH
 #define NEB_TOP_SAH 2 // > 0: LBVH subtrees of up to this many triangles are re-linked by a sweep-SAH top level (host pass); 0 / 512 / 64 / 16 / 8 / 4 / 2 / 1 measured 464 / 454 / 437 / 427 / 419 / 403 / 400 / 474 us for the closest-hit pass
 #endif
+#ifndef NEB_FAST_SHADE
+#define NEB_FAST_SHADE 1 // gi_shade_kernel uses the 1-ulp hardware rcp / rsq / sqrt (see fdiv)
+#endif
+constexpr bool kFastShade = NEB_FAST_SHADE != 0;
 #ifndef NEB_MAX_LEAF_TRIS
 #define NEB_MAX_LEAF_TRIS 2 // 1..4 (the leaf code keeps count - 1 in two bits); measured 1/2/3/4: 1407 / 1390 / 1403 / 1500 us of GI per 1080p frame
 #endif
@@ -183,8 +187,27 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b)
 {
     return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ float3 normalize3(float3 a)
+// Arithmetic policy of the shading code.  FAST = false is the C arithmetic of oracle/trace_ref.cpp (IEEE division,
+// square root and powf: 11-45 instructions each on gfx950); FAST = true uses the 1-ulp hardware forms an HLSL
+// compiler emits for the same source (rcp, rsq, sqrt; x^5 by multiplication; UNORM8 * (1/255)).  Only gi_shade_kernel
+// uses it: its inputs (the hit) are fixed by then, so the result moves by ~1e-7 relative.  Ray generation keeps the
+// exact forms -- a ray direction that moves by an ulp lands on a slightly different texel footprint, which showed up as
+// 3e-5 relative L2 against the oracle -- and so do the G-buffer / direct-light producers.
+template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float fsqrt(float x) { return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+template <bool FAST> __device__ __forceinline__ float fpow5(float x)
 {
+    if (!FAST)
+        return powf(x, 5.0f);
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+template <bool FAST = false> __device__ __forceinline__ float3 normalize3(float3 a)
+{
+    if (FAST) {
+        const float r = __builtin_amdgcn_rsqf(dot3(a, a));
+        return f3(a.x * r, a.y * r, a.z * r);
+    }
     const float l = sqrtf(dot3(a, a));
     return f3(a.x / l, a.y / l, a.z / l);
 }
@@ -277,27 +300,27 @@ __device__ __forceinline__ float3 specular_f0(float3 albedo, float metal)
 {
     return f3(lerp1(0.04f, albedo.x, metal), lerp1(0.04f, albedo.y, metal), lerp1(0.04f, albedo.z, metal));
 }
-__device__ __forceinline__ float3 fresnel_schlick(float3 f0, float vdoth) // brdf.hlsli:22-25, as written
+template <bool FAST = false> __device__ __forceinline__ float3 fresnel_schlick(float3 f0, float vdoth) // brdf.hlsli:22-25, as written
 {
-    const float k = 1.0f - powf(vdoth, 5.0f);
+    const float k = 1.0f - fpow5<FAST>(vdoth);
     return f3(f0.x + (1.0f - f0.x) * k, f0.y + (1.0f - f0.y) * k, f0.z + (1.0f - f0.z) * k);
 }
-__device__ __forceinline__ float specular_probability(float vdotn, float3 f0, float3 albedo) // brdf.hlsli:129-143
+template <bool FAST = false> __device__ __forceinline__ float specular_probability(float vdotn, float3 f0, float3 albedo) // brdf.hlsli:129-143
 {
     const float dr = luminance3(albedo);
-    const float fres = saturate1(luminance3(fresnel_schlick(f0, saturate1(vdotn))));
+    const float fres = saturate1(luminance3(fresnel_schlick<FAST>(f0, saturate1(vdotn))));
     const float diff = dr * (1.0f - fres);
-    const float p = diff / fmaxf(0.0001f, fres + diff);
+    const float p = fdiv<FAST>(diff, fmaxf(0.0001f, fres + diff));
     return fminf(fmaxf(p, 0.1f), 0.9f);
 }
-__device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
+template <bool FAST = false> __device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
 {
-    const float a = sqrtf(u0), b = kPiTwo * u1;
-    const float3 z = f3(a * cosf(b), a * sinf(b), sqrtf(1.0f - u0));
+    const float a = fsqrt<FAST>(u0), b = kPiTwo * u1;
+    const float3 z = f3(a * cosf(b), a * sinf(b), fsqrt<FAST>(1.0f - u0));
     const float3 up = fabsf(sn.z) < 0.999f ? f3(0, 0, 1) : f3(1, 0, 0);
-    const float3 tx = normalize3(cross3(up, sn));
+    const float3 tx = normalize3<FAST>(cross3(up, sn));
     const float3 ty = cross3(sn, tx);
-    return normalize3(tx * z.x + ty * z.y + sn * z.z);
+    return normalize3<FAST>(tx * z.x + ty * z.y + sn * z.z);
 }
 __device__ __forceinline__ float3 perpendicular(float3 u) // sun_disk_sampling.hlsli:45-52
 {
@@ -315,13 +338,13 @@ struct Surface {
 
 // EvaluateDirectBRDF (pathtracer.hlsl:209-228).  A zero Cook-Torrance denominator gives 0 instead of
 // the reference's 0 * inf = NaN (which NRC discards there) -- DESIGN.md "Deliberate divergences".
-__device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
+template <bool FAST = false> __device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
 {
     const float3 N = s.SN;
-    const float3 Hv = normalize3(V + L);
+    const float3 Hv = normalize3<FAST>(V + L);
     const float LdotN = dot3(L, N), VdotH = saturate1(dot3(V, Hv)), VdotN = dot3(V, N), NdotH = dot3(N, Hv);
     const float3 F0 = specular_f0(s.albedo, s.metalness);
-    const float3 F = fresnel_schlick(F0, saturate1(VdotH));
+    const float3 F = fresnel_schlick<FAST>(F0, saturate1(VdotH));
     const float3 Kd = f3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
     const float3 diff = Kd * (s.albedo * kPiInv);
     const float vn = saturate1(VdotN), ln = saturate1(LdotN), nh = saturate1(NdotH);
@@ -331,12 +354,12 @@ __device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
         const float alpha = s.roughness * s.roughness;
         const float a2 = alpha * alpha;
         const float dd = (nh * nh) * (a2 - 1.0f) + 1.0f;
-        const float ndf = a2 / (kPi * dd * dd);
+        const float ndf = fdiv<FAST>(a2, kPi * dd * dd);
         const float k = alpha * 0.5f;
-        const float gv = vn * (1.0f / (vn * (1.0f - k) + k));
-        const float gl = ln * (1.0f / (ln * (1.0f - k) + k));
+        const float gv = vn * fdiv<FAST>(1.0f, vn * (1.0f - k) + k);
+        const float gl = ln * fdiv<FAST>(1.0f, ln * (1.0f - k) + k);
         const float c = ndf * (gv * gl);
-        const float inv = 1.0f / den;
+        const float inv = fdiv<FAST>(1.0f, den);
         spec = f3(c * F.x * inv, c * F.y * inv, c * F.z * inv);
     }
     return diff + spec;
@@ -598,20 +621,21 @@ __device__ __forceinline__ void texel_position(uint32_t w, uint32_t h, float u, 
         y0 += H;
 }
 // bilinear filter of one footprint {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} of RGBA8 UNORM texels
-__device__ __forceinline__ float4 filter_footprint(uint4 fp, float fx, float fy)
+template <bool FAST = false> __device__ __forceinline__ float4 filter_footprint(uint4 fp, float fx, float fy)
 {
     const uint32_t p00 = fp.x, p10 = fp.y, p01 = fp.z, p11 = fp.w;
     float r[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float a = (float)((p00 >> (8 * c)) & 0xffu) / 255.0f, b = (float)((p10 >> (8 * c)) & 0xffu) / 255.0f;
-        const float cc = (float)((p01 >> (8 * c)) & 0xffu) / 255.0f, dd = (float)((p11 >> (8 * c)) & 0xffu) / 255.0f;
+        // UNORM8 -> float: exact division as the oracle, or one v_cvt_f32_ubyte + one multiply
+        auto un = [&](uint32_t p) { const float q = (float)((p >> (8 * c)) & 0xffu); return FAST ? q * (1.0f / 255.0f) : q / 255.0f; };
+        const float a = un(p00), b = un(p10), cc = un(p01), dd = un(p11);
         const float top = a + fx * (b - a), bot = cc + fx * (dd - cc);
         r[c] = top + fy * (bot - top);
     }
     return make_float4(r[0], r[1], r[2], r[3]);
 }
-__device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
+template <bool FAST = false> __device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
 {
     const DevTex t = S.texs[ti];
     int x0, y0;
@@ -620,7 +644,7 @@ __device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
     // bilinear footprint table: entry (x0, y0) holds the four texels {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} with the
     // wrap already applied, so a filtered fetch is ONE 16-byte load instead of four scattered dwords
     const uint4 fp = reinterpret_cast<const uint4*>(S.texels)[(size_t)t.offset + (size_t)y0 * (int)t.w + x0];
-    return filter_footprint(fp, fx, fy);
+    return filter_footprint<FAST>(fp, fx, fy);
 }
 
 __device__ __forceinline__ float3 load3(const float* p, uint32_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
@@ -658,7 +682,7 @@ __device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t 
 }
 
 // ReconstructSurfaceData (pathtracer.hlsl:299-395); `tri` is the sorted triangle index of the hit.
-__device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, float bv, Surface& out, uint32_t& geom)
+template <bool FAST = false> __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, float bv, Surface& out, uint32_t& geom)
 {
     // the record is fetched first and names its geometry itself: one gathered line per hit, and the geometry / material
     // table reads hang off it instead of off a second gather into the triangle array
@@ -669,8 +693,8 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, 
     if (!g.valid)
         return false; // :313-318
     const float3 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
-    const float3 gn = normalize3(f3(n0.x * b0 + n1.x * b1 + n2.x * b2, n0.y * b0 + n1.y * b1 + n2.y * b2, n0.z * b0 + n1.z * b1 + n2.z * b2));
-    out.GN = normalize3(xform_dir(g.m, gn)); // :340
+    const float3 gn = normalize3<FAST>(f3(n0.x * b0 + n1.x * b1 + n2.x * b2, n0.y * b0 + n1.y * b1 + n2.y * b2, n0.z * b0 + n1.z * b1 + n2.z * b2));
+    out.GN = normalize3<FAST>(xform_dir(g.m, gn)); // :340
     const float u = ts.uv0.x * b0 + ts.uv1.x * b1 + ts.uv2.x * b2;
     const float v = ts.uv0.y * b0 + ts.uv1.y * b1 + ts.uv2.y * b2;
     if (g.material < 0)
@@ -684,14 +708,14 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, 
         texel_position(m.bundle_w, m.bundle_h, u, v, x0, y0, fx, fy);
         const uint4* e = S.bundles + 4 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
         const uint4 fa = e[0], fn = e[1], fr = e[2]; // one 64-byte line
-        t_albedo = filter_footprint(fa, fx, fy);
-        t_normal = filter_footprint(fn, fx, fy);
-        t_rm = filter_footprint(fr, fx, fy);
+        t_albedo = filter_footprint<FAST>(fa, fx, fy);
+        t_normal = filter_footprint<FAST>(fn, fx, fy);
+        t_rm = filter_footprint<FAST>(fr, fx, fy);
     }
     if (m.tex[0] < 0) {
         out.albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
     } else {
-        const float4 t = bundled ? t_albedo : sample_texture(S, m.tex[0], u, v);
+        const float4 t = bundled ? t_albedo : sample_texture<FAST>(S, m.tex[0], u, v);
         out.albedo = f3(t.x, t.y, t.z);
     }
     if (m.tex[1] < 0) {
@@ -702,21 +726,21 @@ __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, 
         tg[1] = ts.t0.y * b0 + ts.t1.y * b1 + ts.t2.y * b2;
         tg[2] = ts.t0.z * b0 + ts.t1.z * b1 + ts.t2.z * b2;
         tg[3] = ts.t0.w * b0 + ts.t1.w * b1 + ts.t2.w * b2;
-        const float l4 = sqrtf(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2] + tg[3] * tg[3]); // normalize(float4), :371
+        const float l4 = fsqrt<FAST>(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2] + tg[3] * tg[3]); // normalize(float4), :371
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            tg[k] /= l4;
+            tg[k] = fdiv<FAST>(tg[k], l4);
         const float3 T = f3(tg[0], tg[1], tg[2]);
-        const float3 B = normalize3(cross3(out.GN, T) * tg[3]);
-        const float4 t = bundled ? t_normal : sample_texture(S, m.tex[1], u, v);
+        const float3 B = normalize3<FAST>(cross3(out.GN, T) * tg[3]);
+        const float4 t = bundled ? t_normal : sample_texture<FAST>(S, m.tex[1], u, v);
         const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
-        out.SN = normalize3(T * N.x + B * N.y + out.GN * N.z); // mul(N, float3x3(T, B, GN))
+        out.SN = normalize3<FAST>(T * N.x + B * N.y + out.GN * N.z); // mul(N, float3x3(T, B, GN))
     }
     if (m.tex[2] < 0) {
         out.roughness = m.rough;
         out.metalness = m.metal;
     } else {
-        const float4 t = bundled ? t_rm : sample_texture(S, m.tex[2], u, v);
+        const float4 t = bundled ? t_rm : sample_texture<FAST>(S, m.tex[2], u, v);
         out.roughness = t.y; // .g
         out.metalness = t.z; // .b
     }
@@ -981,7 +1005,7 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
             const uint32_t tri = __float_as_uint(h.w);
             Surface surf;
             uint32_t geom;
-            const bool shaded = reconstruct_surface(a.S, tri, h.y, h.z, surf, geom);
+            const bool shaded = reconstruct_surface<kFastShade>(a.S, tri, h.y, h.z, surf, geom);
             dbg.t = h.x;
             dbg.geometry = geom;
             if (a.hits)
@@ -990,19 +1014,22 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
                 const float4 ro = a.R.ray_o[i];
                 const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
                 const float3 hitP = org + dir * h.x;
-                const float3 V = normalize3(-dir); // :522
+                const float3 V = normalize3<kFastShade>(-dir); // :522
                 uint32_t rng = __float_as_uint(pth.w);
                 const float a0 = rand01(rng), a1 = rand01(rng);
-                const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
+                const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<kFastShade>(a1);
                 const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
                 const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
-                const float3 L = normalize3(-sun_dir);
-                const float3 Bv = normalize3(perpendicular(L));
+                const float3 L = normalize3<kFastShade>(-sun_dir);
+                const float3 Bv = normalize3<kFastShade>(perpendicular(L));
                 const float3 T = cross3(Bv, L);
-                const float3 inc = normalize3(L + (Bv * sinf(angle) + T * cosf(angle)) * a.c.sunTanHalfAngle * dist);
+                // (the disk offset is scaled by tan(0.29 deg) = 0.005: the ~1e-6 error of v_sin / v_cos moves the direction by
+                // less than an ulp, so the hardware forms are safe here; the hemisphere sampler keeps sinf / cosf)
+                const float sn_a = kFastShade ? __sinf(angle) : sinf(angle), cs_a = kFastShade ? __cosf(angle) : cosf(angle);
+                const float3 inc = normalize3<kFastShade>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
                 const bool transition = dot3(surf.GN, inc) <= 0.0f;
                 const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
-                const float3 O = evaluate_direct_brdf(surf, V, L) * sun_rad * throughput; // :573-574
+                const float3 O = evaluate_direct_brdf<kFastShade>(surf, V, L) * sun_rad * throughput; // :573-574
                 rec_o = make_float4(so.x, so.y, so.z, 0.001f);
                 shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
                 rec_c = make_float4(O.x, O.y, O.z, 0.f);
@@ -1011,14 +1038,14 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
                     // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
                     // so the Rand(rng) of :614 returns the same number as the first of them.
                     uint32_t rng_copy = rng;
-                    const float3 SNn = normalize3(surf.SN);
+                    const float3 SNn = normalize3<kFastShade>(surf.SN);
                     const float e0 = rand01(rng_copy), e1 = rand01(rng_copy);
-                    const float3 Ld = cosine_hemisphere_aligned(e0, e1, SNn);
-                    const float pdiff = 1.0f - specular_probability(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
+                    const float3 Ld = cosine_hemisphere_aligned<kFastShade>(e0, e1, SNn);
+                    const float pdiff = 1.0f - specular_probability<kFastShade>(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
                     const float3 no = hitP + surf.GN * 1e-2f; // :607
                     throughput = throughput * (surf.albedo * (1.0f - surf.metalness)); // :613
                     if (rand01(rng) < pdiff)
-                        throughput = f3(throughput.x / pdiff, throughput.y / pdiff, throughput.z / pdiff); // :614-618
+                        throughput = f3(fdiv<kFastShade>(throughput.x, pdiff), fdiv<kFastShade>(throughput.y, pdiff), fdiv<kFastShade>(throughput.z, pdiff)); // :614-618
                     a.R.ray_o[i] = make_float4(no.x, no.y, no.z, 0.001f);
                     next_d = make_float4(Ld.x, Ld.y, Ld.z, 1.0f);
                     a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
