@@ -5,11 +5,13 @@
 //   rtxgi/Nrc.hlsli:579-621, nrcMaxPathVertices = 2), :299-395 ReconstructSurfaceData, :209-228
 //   EvaluateDirectBRDF; brdf.hlsli; rand.hlsli; sun_disk_sampling.hlsli:45-52;
 //   src/nri/GIProcessedScene.cpp:16-137 (scene tables); RTAccelerationStructureBuilder.cpp:14-130
-//   (driver BVH -> replaced by a Karras LBVH built here); deferred_gbuffers.hlsl:36-104 (G-buffer encodings).
-// Not a DXR transliteration: there is no ray-gen/miss/closest-hit pipeline and no driver BVH.  A wave
-// owns an 8x8 pixel tile; each lane generates its ray from the G-buffer, walks the LBVH with a per-lane
-// stack kept in LDS (lane-contiguous, conflict-free), shades its hit from SoA attribute pools and
-// fires the sun shadow ray through the same traverser in any-hit mode.
+//   (driver BVH -> replaced by a Karras LBVH built here, its upper levels re-linked by SAH and collapsed to a
+//   4-wide tree); deferred_gbuffers.hlsl:36-104 (G-buffer encodings).
+// Not a DXR transliteration: there is no ray-gen/miss/closest-hit pipeline and no driver BVH.  The path runs as
+// wavefront stages over per-pixel records: a wave owns an 8x8 pixel tile, each lane generates its ray from the
+// G-buffer and walks the BVH4 with a per-lane stack kept in LDS (lane-contiguous, conflict-free); a second kernel
+// shades the hits from one 128-byte record per triangle; the sun shadow rays are sorted by origin (raysort.hip) and
+// go through the same traverser in any-hit mode.
 //
 // Floating-point contraction is OFF in this file so that ray setup and the Moeller-Trumbore test
 // round exactly like the scalar CPU oracle (hit/miss decisions at triangle edges then agree).
@@ -784,7 +786,7 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
 //   gi_raygen_trace_kernel : G-buffer -> RNG -> throughput -> cosine ray -> closest-hit traversal
 //   gi_shade_kernel        : miss -> sky; hit -> ReconstructSurfaceData, sun-disk shadow ray + BRDF contribution
 //   gi_shadow_trace_kernel : any-hit traversal of the shadow ray, accumulate; last sample adds into radiance[cur]
-// Splitting keeps the two traversal kernels at 60-66 VGPRs (7-8 waves/SIMD) and the register-hungry shading
+// Splitting keeps the two traversal kernels at <= 64 VGPRs (8 waves/SIMD) and the register-hungry shading
 // away from them.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
