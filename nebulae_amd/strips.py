@@ -156,11 +156,24 @@ class StripRenderer(DeferredRenderer):
         elif mode == "device":
             send = [t.clone() for t in send]
             dst = [torch.empty_like(t) for t in recv]
-        ops = []
-        for k, peer in enumerate(peers):
-            ops.append(dist.P2POp(dist.isend, send[k], peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, dst[k], peer, group=self.group))
-        works = dist.batch_isend_irecv(ops)
+        def post(send_, dst_):
+            ops = []
+            for k, peer in enumerate(peers):
+                ops.append(dist.P2POp(dist.isend, send_[k], peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, dst_[k], peer, group=self.group))
+            return dist.batch_isend_irecv(ops)
+
+        try:
+            works = post(send, dst)
+        except RuntimeError:
+            # a backend that refuses the context's hipMalloc'ed planes (raised while posting, the same on every rank):
+            # stage through torch-allocated buffers from now on
+            if mode is not None:
+                raise
+            mode = self._staging = "device"
+            send = [t.clone() for t in send]
+            dst = [torch.empty_like(t) for t in recv]
+            works = post(send, dst)
 
         def finish():
             for w in works:
