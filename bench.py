@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--triangles", type=int, default=262267)
     ap.add_argument("--cpu-frames", type=int, default=3, help="SVGF frames of the CPU oracle to time (0 = skip the CPU leg)")
     ap.add_argument("--svgf-only", action="store_true", help="skip the GI dispatch (synthetic noisy radiance instead)")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time the loop with the final gather of all strips to rank 0 after every frame")
     ap.add_argument("--sort-rays", type=int, default=-1, help="GI ray sorting mask: bit 0 shadow rays, bit 1 bounce rays (-1 = library default)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the GI stages of frame f+1 on a side stream while frame f is denoised (measured: +1 %%, off by default)")
@@ -260,6 +261,19 @@ def main():
     else:
         rays_total = float(rays_timed)
 
+    # ---- optional: the same loop with SURVEY.md 8e's final gather of the strips to rank 0 after every frame ----
+    fps_with_gather = None
+    if args.gather and world > 1:
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            r.gather_frame(dst=0)
+        barrier()
+        dtg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=stats.device)
+        dist.all_reduce(dtg, op=dist.ReduceOp.MAX)
+        fps_with_gather = args.steps / float(dtg[0].item()) * world
+
     # ---- per-kernel durations: HIP events on the launch stream, 8 extra frames ----
     ev = []
     for _ in range(8):
@@ -297,6 +311,7 @@ def main():
                        "parallelism": (f"row-strips x{world} + RCCL halo exchange ({'one per frame' if part.scheme == 'once' else 'one per a-trous level'}, "
                                        f"{part.exchanged_bytes_per_frame() / 1e6:.1f} MB sent per rank and frame)") if world > 1 else "single GPU",
                        "frames_in_flight": 2 if overlap else 1},
+            "frames_per_s_with_final_gather": fps_with_gather,
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
             "gi_kernel_mrays_per_s": (rays_ev / 8 / t_gi / 1e6) if do_gi else None,
             "frame_algorithmic_GBps": (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L) * own_px * world * (args.steps / dt) / 1e9,

@@ -196,6 +196,25 @@ class StripRenderer(DeferredRenderer):
         (sp, ss), _ = self.svgf.atrous_level_planes(level)
         self._swap_rows([(sp, ss)], self.part.level_exchange(self.rank, level))
 
+    def gather_frame(self, dst=0, plane=PLANE_RADIANCE, slot=None):
+        """SURVEY.md 8e "final image gather": the owned rows of every strip to rank `dst` (display / tonemap / readback),
+        one [H/N, W, C] block per rank over `torch.distributed.gather` (RCCL: point-to-point into `dst`, up to seven links
+        in parallel).  Returns the full image tensor on `dst`, None elsewhere.  Not part of the timed frame: the path's
+        output is the per-GPU strip, `bench.py --gather` reports the rate with it."""
+        import torch
+        import torch.distributed as dist
+        if slot is None:
+            slot = self.svgf.get_current_resource_index()
+        own = self.part.owned(self.rank)
+        mine = self._plane_rows(plane, slot, *own)
+        if self.part.N == 1:
+            return mine
+        staged = mine.is_cuda and dist.get_backend(self.group) == "gloo"
+        src = mine.cpu() if staged else mine.contiguous()
+        out = [torch.empty_like(src) for _ in range(self.part.N)] if self.rank == dst else None
+        dist.gather(src, out, dst=dst, group=self.group)
+        return torch.cat(out, dim=0) if self.rank == dst else None
+
     def submit_commands_svgf_denoising(self, events=None):
         if self.dynamic_scene_this_frame:  # src/DeferredRenderer.cpp:595
             return False

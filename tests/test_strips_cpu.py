@@ -77,6 +77,11 @@ def _worker(rank, world, port, W, H, L, nframes, moving_frame, out_dir, scheme):
     part = strips.StripPartition(W, H, world, L, scheme=scheme)
     r = strips.StripRenderer(part, rank, group=dist.group.WORLD, denoiser_factory=OracleDenoiser)
     out, ran = _run_frames(r, part, rank, _frames(W, H, nframes), moving_frame)
+    full = r.gather_frame(dst=0)  # SURVEY.md 8e final gather: rank 0 ends up with the whole image
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), full.numpy())
+    else:
+        assert full is None
     np.save(os.path.join(out_dir, f"strip_{rank}.npy"), out.numpy())
     np.save(os.path.join(out_dir, f"ran_{rank}.npy"), np.array(ran))
     dist.barrier()
@@ -96,6 +101,7 @@ def test_strips_equal_single_process_bit_for_bit(tmp_path, world, W, H, L, movin
     r1 = strips.StripRenderer(part1, 0, denoiser_factory=OracleDenoiser)
     want, ran1 = _run_frames(r1, part1, 0, _frames(W, H, nframes), moving)
     assert not np.isnan(got).any(), "a strip read a row that was not resident"
+    assert np.array_equal(np.load(tmp_path / "gathered.npy"), got)
     assert np.array_equal(got, want.numpy())
     for k in range(world):  # every rank takes the same skip/reset decisions as the single process
         assert np.array_equal(np.load(tmp_path / f"ran_{k}.npy"), np.array(ran1))
