@@ -1,0 +1,605 @@
+// gi_device.h -- device-side arithmetic of the GI path: vector helpers, the RNG and BRDF of the reference's shaders,
+// G-buffer encodings, the BVH4 traverser, texture footprints and surface reconstruction.  Included by gi.hip (wavefront
+// kernels) and gi_build.hip (record packing).
+//
+// Floating-point contraction is OFF from here on so that ray setup and the Moeller-Trumbore test round exactly like
+// the scalar CPU oracle (hit/miss decisions at triangle edges then agree).
+#pragma once
+#pragma clang fp contract(off)
+
+#include "gi_internal.h"
+
+namespace neb {
+
+// ------------------------------------------------------------------------------------------------
+// Small vector helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float3 operator*(float3 a, float3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ float3 operator-(float3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float3 cross3(float3 a, float3 b)
+{
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// Arithmetic policy of the shading code.  FAST = false is the C arithmetic of oracle/trace_ref.cpp (IEEE division,
+// square root and powf: 11-45 instructions each on gfx950); FAST = true uses the 1-ulp hardware forms an HLSL
+// compiler emits for the same source (rcp, rsq, sqrt; x^5 by multiplication; UNORM8 * (1/255)).  Only gi_shade_kernel
+// uses it: its inputs (the hit) are fixed by then, so the result moves by ~1e-7 relative.  Ray generation keeps the
+// exact forms -- a ray direction that moves by an ulp lands on a slightly different texel footprint, which showed up as
+// 3e-5 relative L2 against the oracle -- and so do the G-buffer / direct-light producers.
+template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float fsqrt(float x) { return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+template <bool FAST> __device__ __forceinline__ float fpow5(float x)
+{
+    if (!FAST)
+        return powf(x, 5.0f);
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+template <bool FAST = false> __device__ __forceinline__ float3 normalize3(float3 a)
+{
+    if (FAST) {
+        const float r = __builtin_amdgcn_rsqf(dot3(a, a));
+        return f3(a.x * r, a.y * r, a.z * r);
+    }
+    const float l = sqrtf(dot3(a, a));
+    return f3(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ float saturate1(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float lerp1(float a, float b, float t) { return a + t * (b - a); }
+
+constexpr float kPi = 3.14159265f;      // brdf.hlsli:28
+constexpr float kPiInv = 1.0f / kPi;
+constexpr float kPiTwo = 2.0f * kPi;
+constexpr float kTraceMax = 10000.0f;   // TRACING_MAX_DISTANCE, pathtracer.hlsl:9
+
+// rand.hlsli:6-55
+__device__ __forceinline__ uint32_t jenkins(uint32_t x)
+{
+    x += x << 10;
+    x ^= x >> 6;
+    x += x << 3;
+    x ^= x >> 11;
+    x += x << 15;
+    return x;
+}
+__device__ __forceinline__ float rand01(uint32_t& s)
+{
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return __uint_as_float(0x3f800000u | (s >> 9)) - 1.0f;
+}
+
+// octahedron_encoding.hlsli:16-34
+__device__ __forceinline__ float3 oct_unpack(float ex, float ey)
+{
+    float3 v = f3(ex, ey, 1.0f - fabsf(ex) - fabsf(ey));
+    if (v.z < 0.0f) {
+        const float sx = (v.x > 0.f) ? 1.f : -1.f, sy = (v.y > 0.f) ? 1.f : -1.f;
+        const float nx = (1.0f - fabsf(v.y)) * sx, ny = (1.0f - fabsf(v.x)) * sy;
+        v.x = nx;
+        v.y = ny;
+    }
+    return normalize3(v);
+}
+__device__ __forceinline__ float2 oct_pack(float3 v)
+{
+    const float s = 1.0f / (fabsf(v.x) + fabsf(v.y) + fabsf(v.z));
+    const float px = v.x * s, py = v.y * s;
+    if (v.z <= 0.0f) {
+        const float sx = (px > 0.f) ? 1.f : -1.f, sy = (py > 0.f) ? 1.f : -1.f;
+        return make_float2((1.0f - fabsf(py)) * sx, (1.0f - fabsf(px)) * sy);
+    }
+    return make_float2(px, py);
+}
+
+// R11G11B10_FLOAT: unsigned small floats, 5-bit exponent (bias 15), 6/6/5-bit mantissa.
+__device__ __forceinline__ float small_float_decode(uint32_t bits, int mbits)
+{
+    const uint32_t e = bits >> mbits, m = bits & ((1u << mbits) - 1u);
+    const float scale = (float)(1u << mbits);
+    if (e == 0)
+        return ldexpf((float)m / scale, -14);
+    if (e == 31)
+        return m ? __uint_as_float(0x7fc00000u) : __uint_as_float(0x7f800000u);
+    return ldexpf(1.0f + (float)m / scale, (int)e - 15);
+}
+__device__ __forceinline__ uint32_t small_float_encode(float f, int mbits)
+{
+    // negatives / NaN -> 0, round-to-nearest-even, overflow -> largest finite (DESIGN.md "G-buffer encodings")
+    if (!(f > 0.0f))
+        return 0;
+    const uint32_t max_bits = (30u << mbits) | ((1u << mbits) - 1u);
+    int e;
+    const float m = frexpf(f, &e);
+    e -= 1;
+    if (e > 15)
+        return max_bits;
+    if (e < -14)
+        return (uint32_t)rintf(ldexpf(f, 14 + mbits));
+    const float q = rintf(ldexpf(2.0f * m - 1.0f, mbits));
+    const uint32_t bits = ((uint32_t)(e + 15) << mbits) + (uint32_t)q;
+    return bits > max_bits ? max_bits : bits;
+}
+__device__ __forceinline__ float3 unpack_r11g11b10(uint32_t v)
+{
+    return f3(small_float_decode(v & 0x7ffu, 6), small_float_decode((v >> 11) & 0x7ffu, 6),
+              small_float_decode((v >> 22) & 0x3ffu, 5));
+}
+
+// brdf.hlsli
+__device__ __forceinline__ float luminance3(float3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
+__device__ __forceinline__ float3 specular_f0(float3 albedo, float metal)
+{
+    return f3(lerp1(0.04f, albedo.x, metal), lerp1(0.04f, albedo.y, metal), lerp1(0.04f, albedo.z, metal));
+}
+template <bool FAST = false> __device__ __forceinline__ float3 fresnel_schlick(float3 f0, float vdoth) // brdf.hlsli:22-25, as written
+{
+    const float k = 1.0f - fpow5<FAST>(vdoth);
+    return f3(f0.x + (1.0f - f0.x) * k, f0.y + (1.0f - f0.y) * k, f0.z + (1.0f - f0.z) * k);
+}
+template <bool FAST = false> __device__ __forceinline__ float specular_probability(float vdotn, float3 f0, float3 albedo) // brdf.hlsli:129-143
+{
+    const float dr = luminance3(albedo);
+    const float fres = saturate1(luminance3(fresnel_schlick<FAST>(f0, saturate1(vdotn))));
+    const float diff = dr * (1.0f - fres);
+    const float p = fdiv<FAST>(diff, fmaxf(0.0001f, fres + diff));
+    return fminf(fmaxf(p, 0.1f), 0.9f);
+}
+template <bool FAST = false> __device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
+{
+    const float a = fsqrt<FAST>(u0), b = kPiTwo * u1;
+    const float3 z = f3(a * cosf(b), a * sinf(b), fsqrt<FAST>(1.0f - u0));
+    const float3 up = fabsf(sn.z) < 0.999f ? f3(0, 0, 1) : f3(1, 0, 0);
+    const float3 tx = normalize3<FAST>(cross3(up, sn));
+    const float3 ty = cross3(sn, tx);
+    return normalize3<FAST>(tx * z.x + ty * z.y + sn * z.z);
+}
+__device__ __forceinline__ float3 perpendicular(float3 u) // sun_disk_sampling.hlsli:45-52
+{
+    const float3 a = f3(fabsf(u.x), fabsf(u.y), fabsf(u.z));
+    const uint32_t xm = ((a.x - a.y) < 0 && (a.x - a.z) < 0) ? 1 : 0;
+    const uint32_t ym = (a.y - a.z) < 0 ? (1 ^ xm) : 0;
+    const uint32_t zm = 1 ^ (xm | ym);
+    return cross3(u, f3((float)xm, (float)ym, (float)zm));
+}
+
+struct Surface {
+    float3 GN, SN, albedo;
+    float roughness, metalness;
+};
+
+// EvaluateDirectBRDF (pathtracer.hlsl:209-228).  A zero Cook-Torrance denominator gives 0 instead of
+// the reference's 0 * inf = NaN (which NRC discards there) -- DESIGN.md "Deliberate divergences".
+template <bool FAST = false> __device__ float3 evaluate_direct_brdf(const Surface& s, float3 V, float3 L)
+{
+    const float3 N = s.SN;
+    const float3 Hv = normalize3<FAST>(V + L);
+    const float LdotN = dot3(L, N), VdotH = saturate1(dot3(V, Hv)), VdotN = dot3(V, N), NdotH = dot3(N, Hv);
+    const float3 F0 = specular_f0(s.albedo, s.metalness);
+    const float3 F = fresnel_schlick<FAST>(F0, saturate1(VdotH));
+    const float3 Kd = f3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
+    const float3 diff = Kd * (s.albedo * kPiInv);
+    const float vn = saturate1(VdotN), ln = saturate1(LdotN), nh = saturate1(NdotH);
+    float3 spec = f3(0, 0, 0);
+    const float den = 4.0f * vn * ln;
+    if (den > 0.0f) {
+        const float alpha = s.roughness * s.roughness;
+        const float a2 = alpha * alpha;
+        const float dd = (nh * nh) * (a2 - 1.0f) + 1.0f;
+        const float ndf = fdiv<FAST>(a2, kPi * dd * dd);
+        const float k = alpha * 0.5f;
+        const float gv = vn * fdiv<FAST>(1.0f, vn * (1.0f - k) + k);
+        const float gl = ln * fdiv<FAST>(1.0f, ln * (1.0f - k) + k);
+        const float c = ndf * (gv * gl);
+        const float inv = fdiv<FAST>(1.0f, den);
+        spec = f3(c * F.x * inv, c * F.y * inv, c * F.z * inv);
+    }
+    return diff + spec;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traversal
+// ------------------------------------------------------------------------------------------------
+#ifndef NEB_LDS_STACK
+#define NEB_LDS_STACK 16
+#endif
+constexpr int kLdsStack = NEB_LDS_STACK; // per-lane entries kept in LDS (4 KB per wave at 16)
+constexpr int kSpillStack = 64 - kLdsStack; // deeper entries go to a private (scratch) array; rarely touched
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri;
+    uint32_t node_visits, tri_tests; // traversal statistics (neb_gi_traversal_stats)
+};
+
+// Moeller-Trumbore in the operation order of oracle/trace_ref.cpp.  Before the oracle's own tests run, the undivided
+// numerators (U = u * det, ...) are screened against det with its sign and a few ulps of slack, so the IEEE division
+// -- 11 instructions -- is only paid by a wave in which some lane (nearly) hits; a leaf step usually runs with few lanes
+// active and whole waves leave at the first rejection.  The screen only rejects what the exact tests reject too.
+__device__ __forceinline__ bool intersect_tri_regs(float4 a, float4 b, float4 c, float3 o, float3 d, float tmin, float tmax, float& t,
+                                                   float& u, float& v)
+{
+    const float3 v0 = f3(a.x, a.y, a.z), e1 = f3(a.w, b.x, b.y), e2 = f3(b.z, b.w, c.x);
+    const float3 p = cross3(d, e2);
+    const float det = dot3(e1, p);
+    if (det == 0.0f)
+        return false;
+    const float3 tv = o - v0;
+    const float ads = fabsf(det) * 1.000002f; // |det| plus ~16 ulps
+    const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    const float U = dot3(tv, p);
+    const float Us = __uint_as_float(__float_as_uint(U) ^ sgn); // U * sign(det)
+    if (Us < 0.0f || Us > ads)
+        return false;
+    const float3 q = cross3(tv, e1);
+    const float V = dot3(d, q);
+    const float Vs = __uint_as_float(__float_as_uint(V) ^ sgn);
+    if (Vs < 0.0f || Us + Vs > ads)
+        return false;
+    const float T = dot3(e2, q);
+    const float Ts = __uint_as_float(__float_as_uint(T) ^ sgn);
+    if (!(Ts > 0.0f && Ts <= tmax * ads)) // (tmin >= 0 everywhere)
+        return false;
+    const float inv = 1.0f / det;
+    u = U * inv;
+    v = V * inv;
+    t = T * inv;
+    return u >= 0.0f && u <= 1.0f && v >= 0.0f && u + v <= 1.0f && t > tmin && t < tmax;
+}
+
+__device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, uint32_t ti, float3 o, float3 d, float tmin,
+                                              float tmax, float& t, float& u, float& v)
+{
+    return intersect_tri_regs(tris[3 * ti], tris[3 * ti + 1], tris[3 * ti + 2], o, d, tmin, tmax, t, u, v);
+}
+
+// Entry distance of the ray into box k of a BVH4 node, as an ordered uint key (misses = 0xffffffff).
+// n* / f* are the planes the ray meets first / last on each axis (picked by the sign of the direction when the node
+// is loaded).  One fma per plane: t = plane * (1/d) - o/d.  fminf/fmaxf drop NaNs (inf - inf for axis-parallel
+// rays), which only makes the interval more conservative; hits themselves are decided by the triangle test.
+__device__ __forceinline__ uint32_t slab_key(float nx, float ny, float nz, float fx, float fy, float fz, float3 inv, float3 oinv,
+                                             float tmin, float tmax, uint32_t slot)
+{
+    const float ax = fmaf(nx, inv.x, -oinv.x), bx = fmaf(fx, inv.x, -oinv.x);
+    const float ay = fmaf(ny, inv.y, -oinv.y), by = fmaf(fy, inv.y, -oinv.y);
+    const float az = fmaf(nz, inv.z, -oinv.z), bz = fmaf(fz, inv.z, -oinv.z);
+    const float t0 = fmaxf(fmaxf(ax, ay), fmaxf(az, tmin));
+    const float t1 = fminf(fminf(bx, by), fminf(bz, tmax));
+    // t0 >= tmin >= 0: its bit pattern orders like an unsigned integer; the low 2 bits carry the slot
+    return (t0 <= t1) ? ((__float_as_uint(t0) & ~3u) | slot) : 0xffffffffu;
+}
+
+__device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b)
+{
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+// The stack pointer and the LDS column are plain scalars and the spill array is its own object: when all three
+// sat in one struct the dynamically indexed array kept the whole struct (stack pointer included) in scratch memory,
+// and every push / pop paid a scratch round trip behind an s_waitcnt vmcnt(0).
+struct TravStack {
+    int* lds;   // this lane's column of an LDS array [kLdsStack][64]
+    int* spill; // private array of kSpillStack entries
+    int sp;
+    __device__ __forceinline__ void push(int v)
+    {
+        if (sp < kLdsStack)
+            lds[64 * sp] = v;
+        else if (sp < kLdsStack + kSpillStack)
+            spill[sp - kLdsStack] = v;
+        else
+            return; // deeper than 64 pending nodes: drop (cannot happen for a BVH4 over 64-bit Morton keys)
+        sp++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        sp--;
+        return sp < kLdsStack ? lds[64 * sp] : spill[sp - kLdsStack];
+    }
+};
+
+// Closest-hit (ANY_HIT = false) or first-hit (ANY_HIT = true) traversal of the BVH4.
+// A step handles an inner node and then, if the lane lands on a leaf, the leaf in the same iteration
+// (if-if), so lanes in the node phase and lanes in the leaf phase of a wave do not serialise two memory
+// round trips per iteration.  Shadow rays skip the front-to-back ordering of the children.
+constexpr int kTravDone = (int)0x80000000;
+
+template <bool ANY_HIT, bool STATS>
+__device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit)
+{
+    hit.t = tmax;
+    hit.tri = ~0u;
+    hit.node_visits = hit.tri_tests = 0;
+    if (S.n_tris == 0)
+        return false;
+    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    // byte offset of the plane the ray enters through, per axis, inside a Bvh4Node (the exit plane is offset ^ 64)
+    const uint32_t onx = d.x < 0.0f ? 64u : 0u, ony = d.y < 0.0f ? 80u : 16u, onz = d.z < 0.0f ? 96u : 32u;
+    bool found = false;
+    int spill_mem[kSpillStack];
+    TravStack st{lds_stack, spill_mem, 0};
+    int node = S.root;
+    constexpr uint32_t kMiss = 0xffffffffu;
+    while (node != kTravDone) {
+        if (node >= 0) {
+            if (STATS)
+                hit.node_visits++;
+            const char* nodes = reinterpret_cast<const char*>(S.nodes);
+            const uint32_t nb = (uint32_t)node << 7; // 32-bit byte offset (scalar base + vector offset addressing)
+            const float4 nx = *reinterpret_cast<const float4*>(nodes + (nb + onx)), fx = *reinterpret_cast<const float4*>(nodes + (nb + (onx ^ 64u)));
+            const float4 ny = *reinterpret_cast<const float4*>(nodes + (nb + ony)), fy = *reinterpret_cast<const float4*>(nodes + (nb + (ony ^ 64u)));
+            const float4 nz = *reinterpret_cast<const float4*>(nodes + (nb + onz)), fz = *reinterpret_cast<const float4*>(nodes + (nb + (onz ^ 64u)));
+            const int4 ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
+            uint32_t k0 = slab_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, inv, oinv, tmin, hit.t, 0u);
+            uint32_t k1 = slab_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, inv, oinv, tmin, hit.t, 1u);
+            uint32_t k2 = slab_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, inv, oinv, tmin, hit.t, 2u);
+            uint32_t k3 = slab_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, inv, oinv, tmin, hit.t, 3u);
+            // select by the slot bits without branches (two levels of v_cndmask)
+            auto child_of = [&](uint32_t key) -> int {
+                const bool b0 = (key & 1u) != 0u, b1 = (key & 2u) != 0u;
+                const int lo = b0 ? ch.y : ch.x, hi = b0 ? ch.w : ch.z;
+                return b1 ? hi : lo;
+            };
+            if (!ANY_HIT) { // sorting network: k0 <= k1 <= k2 <= k3 (nearest first, misses last)
+                cswap(k0, k1);
+                cswap(k2, k3);
+                cswap(k0, k2);
+                cswap(k1, k3);
+                cswap(k1, k2);
+                node = kTravDone;
+                if (k0 != kMiss) {
+                    if (k3 != kMiss)
+                        st.push(child_of(k3));
+                    if (k2 != kMiss)
+                        st.push(child_of(k2));
+                    if (k1 != kMiss)
+                        st.push(child_of(k1));
+                    node = child_of(k0);
+                }
+            } else { // any order: continue with the first hit child, stack the others
+                node = kTravDone;
+                if (k3 != kMiss)
+                    node = ch.w;
+                if (k2 != kMiss) {
+                    if (node != kTravDone)
+                        st.push(node);
+                    node = ch.z;
+                }
+                if (k1 != kMiss) {
+                    if (node != kTravDone)
+                        st.push(node);
+                    node = ch.y;
+                }
+                if (k0 != kMiss) {
+                    if (node != kTravDone)
+                        st.push(node);
+                    node = ch.x;
+                }
+            }
+            if (node == kTravDone && st.sp)
+                node = st.pop();
+        }
+        // Any-hit rays batch their leaf steps: a lane that holds a leaf waits until kLeafBatch lanes of the wave do (or
+        // none has a node left), so the triangle code runs with fuller waves (shadow pass 213 -> 206 us; the closest-hit
+        // pass, whose lanes need the shrunk hit.t at once, measured no gain at 4 / 12 and lost at 24).
+        const bool holds_leaf = node < 0 && node != kTravDone;
+        bool run_leaves = true;
+        if (ANY_HIT && kLeafBatch > 1)
+            run_leaves = __popcll(__ballot(holds_leaf)) >= kLeafBatch || __ballot(node >= 0) == 0ull;
+        if (holds_leaf && run_leaves) {
+            const uint32_t code = (uint32_t)~node;
+            const uint32_t first = code >> 2, count = (code & 3u) + 1u;
+            if (STATS)
+                hit.tri_tests += count;
+            if constexpr (kMaxLeafTris <= 2) {
+                // both triangles are fetched before the first test (one memory round trip per leaf).  A one-triangle
+                // leaf tests its triangle twice: the second test cannot pass t < hit.t again.
+                const uint32_t second = first + count - 1u;
+                float4 a0 = S.tris[3 * first];
+                const float4 b0 = S.tris[3 * first + 1], c0 = S.tris[3 * first + 2];
+                const float4 a1 = S.tris[3 * second], b1 = S.tris[3 * second + 1], c1 = S.tris[3 * second + 2];
+                // keep the v0 load in this batch: left alone, the compiler sinks it behind the det == 0 test of the
+                // first triangle, a second dependent memory access per leaf
+                asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z));
+                float t, u, v;
+                if (intersect_tri_regs(a0, b0, c0, o, d, tmin, hit.t, t, u, v)) {
+                    hit.t = t, hit.u = u, hit.v = v, hit.tri = first, found = true;
+                }
+                if (intersect_tri_regs(a1, b1, c1, o, d, tmin, hit.t, t, u, v)) {
+                    hit.t = t, hit.u = u, hit.v = v, hit.tri = second, found = true;
+                }
+            } else {
+                for (uint32_t k = 0; k < count; ++k) {
+                    float t, u, v;
+                    if (intersect_tri(S.tris, first + k, o, d, tmin, hit.t, t, u, v)) {
+                        hit.t = t, hit.u = u, hit.v = v, hit.tri = first + k, found = true;
+                    }
+                }
+            }
+            if (ANY_HIT && found)
+                return true;
+            node = st.sp ? st.pop() : kTravDone;
+        }
+    }
+    return found;
+}
+
+// `stats` (wave-uniform, diagnostics) selects the instantiation that also counts node visits and triangle tests.
+__device__ __forceinline__ bool traverse(const SceneView& S, float3 o, float3 d, float tmin, float tmax, bool any_hit, int* lds_stack,
+                                         Hit& hit, bool stats = false)
+{
+    if (stats)
+        return any_hit ? traverse_t<true, true>(S, o, d, tmin, tmax, lds_stack, hit) : traverse_t<false, true>(S, o, d, tmin, tmax, lds_stack, hit);
+    return any_hit ? traverse_t<true, false>(S, o, d, tmin, tmax, lds_stack, hit) : traverse_t<false, false>(S, o, d, tmin, tmax, lds_stack, hit);
+}
+
+// SampleLevel(linear, wrap, mip 0) of an RGBA8 UNORM texture (pathtracer.hlsl:359,377,390).
+// wrap-addressed texel position and bilinear fractions of (u, v) in a w x h texture
+__device__ __forceinline__ void texel_position(uint32_t w, uint32_t h, float u, float v, int& x0, int& y0, float& fx, float& fy)
+{
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    fx = x - fx0;
+    fy = y - fy0;
+    const int W = (int)w, H = (int)h;
+    x0 = (int)fx0 % W;
+    y0 = (int)fy0 % H;
+    if (x0 < 0)
+        x0 += W;
+    if (y0 < 0)
+        y0 += H;
+}
+// bilinear filter of one footprint {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} of RGBA8 UNORM texels
+template <bool FAST = false> __device__ __forceinline__ float4 filter_footprint(uint4 fp, float fx, float fy)
+{
+    const uint32_t p00 = fp.x, p10 = fp.y, p01 = fp.z, p11 = fp.w;
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // UNORM8 -> float: exact division as the oracle, or one v_cvt_f32_ubyte + one multiply
+        auto un = [&](uint32_t p) { const float q = (float)((p >> (8 * c)) & 0xffu); return FAST ? q * (1.0f / 255.0f) : q / 255.0f; };
+        const float a = un(p00), b = un(p10), cc = un(p01), dd = un(p11);
+        const float top = a + fx * (b - a), bot = cc + fx * (dd - cc);
+        r[c] = top + fy * (bot - top);
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+template <bool FAST = false> __device__ float4 sample_texture(const SceneView& S, int ti, float u, float v)
+{
+    const DevTex t = S.texs[ti];
+    int x0, y0;
+    float fx, fy;
+    texel_position(t.w, t.h, u, v, x0, y0, fx, fy);
+    // bilinear footprint table: entry (x0, y0) holds the four texels {(x0,y0), (x0+1,y0), (x0,y0+1), (x0+1,y0+1)} with the
+    // wrap already applied, so a filtered fetch is ONE 16-byte load instead of four scattered dwords
+    const uint4 fp = reinterpret_cast<const uint4*>(S.texels)[(size_t)t.offset + (size_t)y0 * (int)t.w + x0];
+    return filter_footprint<FAST>(fp, fx, fy);
+}
+
+__device__ __forceinline__ float3 load3(const float* p, uint32_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ float3 xform_dir(const float* m, float3 p) // (p,0) * M, row-vector convention
+{
+    return f3(p.x * m[0] + p.y * m[3] + p.z * m[6], p.x * m[1] + p.y * m[4] + p.z * m[7], p.x * m[2] + p.y * m[5] + p.z * m[8]);
+}
+
+// ReconstructSurfaceData (pathtracer.hlsl:299-395)
+// Per-triangle shading record (128 B, one cache line) so that a hit costs one line instead of ~10 scattered
+// ones (3 indices, 3 x normal/uv/tangent in three SoA pools):
+//   r0 {n0.xyz, uv0.x} r1 {n1.xyz, uv0.y} r2 {n2.xyz, uv1.x} r3..r5 tangent0..2 r6 {uv1.y, uv2.x, uv2.y, geometry} r7 {primitive,-,-,-}
+struct TriShade {
+    float3 n0, n1, n2;
+    float2 uv0, uv1, uv2;
+    float4 t0, t1, t2;
+    uint32_t geom; // GeometryIndex() of the triangle (r6.w); PrimitiveIndex() is r7.x (debug records only)
+};
+__device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t tri)
+{
+    const float4* r = S.shade + 8 * (size_t)tri;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r6 = r[6];
+    TriShade t;
+    t.n0 = f3(r0.x, r0.y, r0.z);
+    t.n1 = f3(r1.x, r1.y, r1.z);
+    t.n2 = f3(r2.x, r2.y, r2.z);
+    t.uv0 = make_float2(r0.w, r1.w);
+    t.uv1 = make_float2(r2.w, r6.x);
+    t.uv2 = make_float2(r6.y, r6.z);
+    t.geom = __float_as_uint(r6.w);
+    t.t0 = r[3];
+    t.t1 = r[4];
+    t.t2 = r[5];
+    return t;
+}
+
+// ReconstructSurfaceData (pathtracer.hlsl:299-395); `tri` is the sorted triangle index of the hit.
+template <bool FAST = false> __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, float bv, Surface& out, uint32_t& geom)
+{
+    // the record is fetched first and names its geometry itself: one gathered line per hit, and the geometry / material
+    // table reads hang off it instead of off a second gather into the triangle array
+    const TriShade ts = load_tri_shade(S, tri);
+    geom = ts.geom;
+    const DevGeom g = S.geoms[geom];
+    const float b0 = 1.0f - (bu + bv), b1 = bu, b2 = bv;
+    if (!g.valid)
+        return false; // :313-318
+    const float3 n0 = ts.n0, n1 = ts.n1, n2 = ts.n2;
+    const float3 gn = normalize3<FAST>(f3(n0.x * b0 + n1.x * b1 + n2.x * b2, n0.y * b0 + n1.y * b1 + n2.y * b2, n0.z * b0 + n1.z * b1 + n2.z * b2));
+    out.GN = normalize3<FAST>(xform_dir(g.m, gn)); // :340
+    const float u = ts.uv0.x * b0 + ts.uv1.x * b1 + ts.uv2.x * b2;
+    const float v = ts.uv0.y * b0 + ts.uv1.y * b1 + ts.uv2.y * b2;
+    if (g.material < 0)
+        return false; // :349
+    const DevMat m = S.mats[g.material];
+    float4 t_albedo, t_normal, t_rm;
+    const bool bundled = m.bundle_w != 0; // then all three maps exist
+    if (bundled) {
+        int x0, y0;
+        float fx, fy;
+        texel_position(m.bundle_w, m.bundle_h, u, v, x0, y0, fx, fy);
+        const uint4* e = S.bundles + 4 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
+        const uint4 fa = e[0], fn = e[1], fr = e[2]; // one 64-byte line
+        t_albedo = filter_footprint<FAST>(fa, fx, fy);
+        t_normal = filter_footprint<FAST>(fn, fx, fy);
+        t_rm = filter_footprint<FAST>(fr, fx, fy);
+    }
+    if (m.tex[0] < 0) {
+        out.albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    } else {
+        const float4 t = bundled ? t_albedo : sample_texture<FAST>(S, m.tex[0], u, v);
+        out.albedo = f3(t.x, t.y, t.z);
+    }
+    if (m.tex[1] < 0) {
+        out.SN = out.GN;
+    } else {
+        float tg[4];
+        tg[0] = ts.t0.x * b0 + ts.t1.x * b1 + ts.t2.x * b2;
+        tg[1] = ts.t0.y * b0 + ts.t1.y * b1 + ts.t2.y * b2;
+        tg[2] = ts.t0.z * b0 + ts.t1.z * b1 + ts.t2.z * b2;
+        tg[3] = ts.t0.w * b0 + ts.t1.w * b1 + ts.t2.w * b2;
+        const float l4 = fsqrt<FAST>(tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2] + tg[3] * tg[3]); // normalize(float4), :371
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            tg[k] = fdiv<FAST>(tg[k], l4);
+        const float3 T = f3(tg[0], tg[1], tg[2]);
+        const float3 B = normalize3<FAST>(cross3(out.GN, T) * tg[3]);
+        const float4 t = bundled ? t_normal : sample_texture<FAST>(S, m.tex[1], u, v);
+        const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
+        out.SN = normalize3<FAST>(T * N.x + B * N.y + out.GN * N.z); // mul(N, float3x3(T, B, GN))
+    }
+    if (m.tex[2] < 0) {
+        out.roughness = m.rough;
+        out.metalness = m.metal;
+    } else {
+        const float4 t = bundled ? t_rm : sample_texture<FAST>(S, m.tex[2], u, v);
+        out.roughness = t.y; // .g
+        out.metalness = t.z; // .b
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t morton30(float3 p, const float* smin, const float* sinv)
+{
+    const uint32_t qx = (uint32_t)fminf(fmaxf((p.x - smin[0]) * sinv[0] * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf((p.y - smin[1]) * sinv[1] * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf((p.z - smin[2]) * sinv[2] * 1024.0f, 0.0f), 1023.0f);
+    return (expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz);
+}
+
+} // namespace neb

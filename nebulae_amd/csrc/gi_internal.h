@@ -1,0 +1,165 @@
+// gi_internal.h -- scene tables, BVH node layouts and the GI state shared by gi_build.hip (scene upload, BVH build)
+// and gi.hip (wavefront kernels, C ABI of the trace).  Tuning knobs are -D macros with the measured defaults.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "neb_device.h"
+#include "neb_internal.h"
+
+namespace neb {
+
+
+// ------------------------------------------------------------------------------------------------
+// Device-side scene
+// ------------------------------------------------------------------------------------------------
+struct DevGeom {
+    float m[9];          // upper 3x3 of surfaceToWorld (row-vector convention)
+    int32_t material;
+    uint32_t firstIndex; // into the uint32 index pool
+    uint32_t vertexBase; // into the SoA vertex pools
+    uint32_t valid;      // all four attribute streams + indices present
+    uint32_t pad[3];
+};
+struct DevMat {
+    int32_t tex[3];
+    float albedo[3];
+    float rough, metal;
+    // When the material has all three maps and they share one size, their bilinear footprints are also stored
+    // interleaved, one 64-byte entry per texel position {albedo 4 texels, normal 4, roughness/metalness 4, pad}: the
+    // three filtered fetches of a hit (same uv) then touch one line instead of three.  bundle_w == 0: not bundled.
+    uint32_t bundle;   // first entry, in 64-byte units, into SceneView::bundles
+    uint32_t bundle_w, bundle_h;
+    uint32_t pad;
+};
+struct DevTex {
+    uint32_t offset; // in footprint entries (16 B), into the texel pool
+    uint32_t w, h, pad;
+};
+// 64-byte BVH2 node: both children's boxes live in the parent, so one node fetch decides both.
+struct BvhNode {
+    float c0min[3];
+    int32_t c0; // >= 0: inner node, < 0: leaf, triangle = ~c
+    float c0max[3];
+    int32_t c1;
+    float c1min[3];
+    uint32_t pad0;
+    float c1max[3];
+    uint32_t pad1;
+};
+
+// 128-byte BVH4 node produced by collapsing the LBVH (SoA per axis: one float4 per bound and axis).
+// child >= 0: inner node index; child < 0: leaf, code = ~child = (first_triangle << 2) | (count - 1), count <= 4;
+// unused slots carry an inverted (never-hit) box.  The lower and the upper plane of an axis sit 64 bytes apart, so
+// a ray picks its near plane with a per-ray byte offset (0 or 64 by the sign of its direction) and the far plane
+// with offset ^ 64: no min / max per slab.
+struct Bvh4Node {
+    float4 lox, loy, loz; //  0, 16, 32
+    int4 child;           // 48
+    float4 hix, hiy, hiz; // 64, 80, 96
+    int4 pad;
+};
+static_assert(sizeof(Bvh4Node) == 128 && offsetof(Bvh4Node, hix) == offsetof(Bvh4Node, lox) + 64, "node layout");
+#ifndef NEB_TRACE_WAVES
+#define NEB_TRACE_WAVES 8 // waves per SIMD the traversal kernels are register-budgeted for
+#endif
+#ifndef NEB_SHADE_WAVES
+#define NEB_SHADE_WAVES 4 // waves per SIMD gi_shade_kernel is register-budgeted for
+#endif
+#ifndef NEB_LEAF_BATCH
+#define NEB_LEAF_BATCH 12
+#endif
+constexpr int kLeafBatch = NEB_LEAF_BATCH;
+#ifndef NEB_TOP_SAH
+#define NEB_TOP_SAH 2 // > 0: LBVH subtrees of up to this many triangles are re-linked by a sweep-SAH top level (host pass); 0 / 512 / 64 / 16 / 8 / 4 / 2 / 1 measured 464 / 454 / 437 / 427 / 419 / 403 / 400 / 474 us for the closest-hit pass
+#endif
+#ifndef NEB_FAST_SHADE
+#define NEB_FAST_SHADE 1 // gi_shade_kernel uses the 1-ulp hardware rcp / rsq / sqrt (see fdiv)
+#endif
+constexpr bool kFastShade = NEB_FAST_SHADE != 0;
+#ifndef NEB_MAX_LEAF_TRIS
+#define NEB_MAX_LEAF_TRIS 2 // 1..4 (the leaf code keeps count - 1 in two bits); measured 1/2/3/4: 1407 / 1390 / 1403 / 1500 us of GI per 1080p frame
+#endif
+constexpr int kMaxLeafTris = NEB_MAX_LEAF_TRIS;
+
+struct SceneView {
+    const float4* tris;      // 3 x float4 per triangle: {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, geom, prim, -}
+    const Bvh4Node* nodes;
+    const DevGeom* geoms;
+    const DevMat* mats;
+    const DevTex* texs;
+    const uint32_t* indices;
+    const float* normals;    // 3 per vertex
+    const float* uvs;        // 2 per vertex
+    const float* tangents;   // 4 per vertex
+    const uint32_t* texels;  // RGBA8 bilinear footprint table: 4 texels (16 B) per texel position, see sample_texture
+    const uint4* bundles;    // per-material interleaved footprints (4 x uint4 per texel position), see DevMat::bundle
+    const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
+    uint32_t n_tris;
+    int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
+};
+
+struct GiState {
+    SceneView view{};
+    std::vector<void*> allocs;
+    // host copies kept for the build
+    std::vector<float> h_tris; // 12 floats per triangle
+    float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
+    uint32_t n_tris = 0, n_nodes = 0;
+    bool built = false;
+    unsigned long long* d_ray_counter = nullptr;
+    neb_gi_hit* d_hits = nullptr;
+    bool debug_hits = false;
+    float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
+    unsigned long long last_stats[8] = {};
+    bool defer_resolve = false;
+    bool sort_shadow = true;  // "gi_sort_rays" bit 0
+    bool sort_bounce = false; // "gi_sort_rays" bit 1
+    uint32_t* d_sort = nullptr;      // 4 x npx uint32: keys, vals, keys_out, vals_out
+    void* d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
+    uint32_t* d_block_counts = nullptr; // [2][n_block_counts]: bounce / shadow rays per workgroup
+    size_t n_block_counts = 0;
+};
+
+void gi_on_resize(GiState* g);
+void gi_destroy(GiState* g);
+
+} // namespace neb
+
+// ---- host helpers of the C ABI entry points ----
+static inline int gi_fail(neb_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof(buf), "%s", what);
+    ctx->last_error = buf;
+    return code;
+}
+
+#define GI_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess)                               \
+            return gi_fail((ctx), NEB_ERR_HIP, #call, e_);  \
+    } while (0)
+
+template <typename T>
+static inline hipError_t upload(neb::GiState* g, const std::vector<T>& h, const T** out)
+{
+    *out = nullptr;
+    if (h.empty())
+        return hipSuccess;
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, h.size() * sizeof(T));
+    if (e != hipSuccess)
+        return e;
+    g->allocs.push_back(d);
+    *out = (const T*)d;
+    return hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+}
