@@ -53,6 +53,10 @@ class DeferredRenderer:
         self._sun_key = None
         self.dynamic_scene_this_frame = False
         self.reset_history = False
+        # Beyond the reference ("always-on"): keep denoising while the camera moves.  The
+        # reference skips SVGF on those frames (DeferredRenderer.cpp:595) and resets the history when the camera stops;
+        # with this flag the temporal pass runs every frame (no reprojection: it then exercises quirk 2).
+        self.denoise_while_moving = False
         self.info = None
 
     # ---- DeferredRenderer::Init (src/DeferredRenderer.cpp:26-57) ----
@@ -99,7 +103,7 @@ class DeferredRenderer:
             self.dynamic_scene_this_frame = True
         elif self.dynamic_scene_this_frame:
             self.dynamic_scene_this_frame = False  # camera stopped: reset history and start denoising
-            self.reset_history = True
+            self.reset_history = not self.denoise_while_moving
 
     def end_frame(self):
         self.svgf.end_frame()
@@ -151,7 +155,7 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_resolve(self._ctx, C.c_void_p(self.info.stream if stream is None else stream)), "neb_gi_resolve")
 
     def submit_commands_svgf_denoising(self):
-        if self.dynamic_scene_this_frame:  # :595
+        if self.dynamic_scene_this_frame and not self.denoise_while_moving:  # :595
             return False
         if self.reset_history:
             self.reset_history = False

@@ -216,7 +216,7 @@ class StripRenderer(DeferredRenderer):
         return torch.cat(out, dim=0) if self.rank == dst else None
 
     def submit_commands_svgf_denoising(self, events=None):
-        if self.dynamic_scene_this_frame:  # src/DeferredRenderer.cpp:595
+        if self.dynamic_scene_this_frame and not self.denoise_while_moving:  # src/DeferredRenderer.cpp:595
             return False
         st = self.info.stream
         own = self.part.owned(self.rank)

@@ -105,3 +105,20 @@ def test_strips_equal_single_process_bit_for_bit(tmp_path, world, W, H, L, movin
     assert np.array_equal(got, want.numpy())
     for k in range(world):  # every rank takes the same skip/reset decisions as the single process
         assert np.array_equal(np.load(tmp_path / f"ran_{k}.npy"), np.array(ran1))
+
+
+def test_frame_policy_reference_and_always_on():
+    """src/DeferredRenderer.cpp:133-146,593-614: SVGF is skipped on frames whose camera moved and the history is reset on
+    the first still frame; `denoise_while_moving` (beyond the reference) keeps it on throughout."""
+    from oracle_backend import OracleDenoiser
+    W, H, L = 48, 40, 2
+    frames = _frames(W, H, 5)
+    part = strips.StripPartition(W, H, 1, L)
+    ref = strips.StripRenderer(part, 0, denoiser_factory=OracleDenoiser)
+    out_ref, ran_ref = _run_frames(ref, part, 0, frames, moving_frame=3)
+    assert ran_ref == [False, True, False, True, True]  # frame 1: first camera; frame 3: the camera moves; frame 4: reset + denoise
+    on = strips.StripRenderer(part, 0, denoiser_factory=OracleDenoiser)
+    on.denoise_while_moving = True
+    out_on, ran_on = _run_frames(on, part, 0, frames, moving_frame=3)
+    assert ran_on == [True] * 5
+    assert not np.array_equal(out_on.numpy(), out_ref.numpy())  # the history was never reset
