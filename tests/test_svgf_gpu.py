@@ -225,3 +225,23 @@ def test_full_size_properties_1080p():
     assert rel_l2(got, want) < TOL_E2E
     d.destroy()
     d2.destroy()
+
+
+def test_full_size_matches_oracle_1080p():
+    """BASELINE size (1920x1080, 5 levels), whole image: three frames of the synthetic noisy sequence against the oracle
+    (row-parallel on the host cores), moments and variance included."""
+    import os
+    W, H, L = 1920, 1080, 5
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    d, o = make(W, H, L), OracleSVGF(W, H, L, threads=threads)
+    g = synth.synth_gbuffer(W, H)
+    for f in (1, 2, 3):
+        feed(d, o, f, g, synth.synth_radiance(g["base"], f))
+        d.submit_temporal_accumulation()
+        d.submit_atrous_compute_wavelet()
+        o.temporal_pass()
+        o.atrous_pass()
+        assert rel_l2(d.download(PLANE_RADIANCE), o.radiance[o.cur]) < TOL_E2E
+    tol = 4e-7 * float(synth.synth_radiance(g["base"], 3)[..., :3].max()) ** 2 + 1e-6  # (see test_frames_match_golden)
+    assert half_ulp_mismatch(d.download(PLANE_VARIANCE, 0), o.variance, abs_tol=tol) < 1e-3
+    d.destroy()
