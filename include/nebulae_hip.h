@@ -102,7 +102,8 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene);
  *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (default on),
  *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
- *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it. */
+ *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it;
+ *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3). */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
 /* ---- resource sharing: the ~25 getters of SVGFDenoiser.h:24-70 collapse into one call.
@@ -198,9 +199,14 @@ typedef struct neb_camera {
  * uploads geometry/material tables and textures and bakes world-space triangles. */
 int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_geoms, const neb_material_desc* mats,
                      uint32_t n_mats, const neb_texture_desc* texs, uint32_t n_texs);
-/* DeferredRenderer::InitRTAccelerationStructures (src/DeferredRenderer.cpp:978-1030): builds the LBVH on the device. */
+/* DeferredRenderer::InitRTAccelerationStructures (src/DeferredRenderer.cpp:978-1030): builds the acceleration structure.
+ * One-time setup: enqueues on `stream` and SYNCHRONISES it before returning.  On failure the scene keeps its previous
+ * state (unbuilt, or the previous valid tree); calling it again rebuilds. */
 int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream);
 int neb_gi_scene_info(const neb_ctx* ctx, uint32_t* n_triangles, uint32_t* n_nodes);
+/* Inner-node levels of the BVH4 of the last successful build.  neb_gi_build_bvh returns NEB_ERR_OUT_OF_RANGE (and keeps the
+ * previous tree, if any) when the depth exceeds what the traversal stack covers: 21, or "gi_max_bvh_depth". */
+int neb_gi_bvh_depth(const neb_ctx* ctx, uint32_t* depth);
 /* DeferredRenderer::SubmitCommandsGIPathtrace: radiance[cur].rgb += mean over spp of the path radiance
  * (stands in for NRC Resolve, DeferredRenderer.cpp:586).  Reads the ALBEDO / ROUGH_METAL / WORLDPOS planes and
  * normal[cur].  _rows: image rows [row0,row1) only (multi-GPU strips). */

@@ -45,6 +45,12 @@ static int fail(neb_ctx* ctx, int code, const char* what, hipError_t e = hipSucc
             return fail((ctx), NEB_ERR_HIP, #call, e_);     \
     } while (0)
 
+// scoped: run the rest of the entry point on the context's device, restore the caller's device on return
+#define NEB_GUARD(ctx)                                                       \
+    DeviceGuard neb_guard_((ctx)->device);                                   \
+    if (neb_guard_.err != hipSuccess)                                        \
+    return fail((ctx), NEB_ERR_HIP, "hipSetDevice", neb_guard_.err)
+
 static void free_planes(neb_ctx* ctx)
 {
     for (int p = 0; p < NEB_PLANE_COUNT; ++p)
@@ -94,9 +100,9 @@ int neb_create(const neb_create_info* info, neb_ctx** out_ctx)
         return fail(nullptr, NEB_ERR_NO_DEVICE, "neb_create: no HIP device (this library has no CPU fallback)", e);
     if (info->device < 0 || info->device >= ndev)
         return fail(nullptr, NEB_ERR_INVALID_ARG, "neb_create: device ordinal out of range");
-    e = hipSetDevice(info->device);
-    if (e != hipSuccess)
-        return fail(nullptr, NEB_ERR_HIP, "hipSetDevice", e);
+    DeviceGuard guard(info->device);
+    if (guard.err != hipSuccess)
+        return fail(nullptr, NEB_ERR_HIP, "hipSetDevice", guard.err);
     neb_ctx* ctx = new (std::nothrow) neb_ctx();
     if (!ctx)
         return fail(nullptr, NEB_ERR_HIP, "neb_create: out of host memory");
@@ -129,7 +135,7 @@ int neb_resize(neb_ctx* ctx, uint32_t width, uint32_t height)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_resize: bad argument");
     if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
         return fail(ctx, NEB_ERR_STATE, "neb_resize: only a full-image context can be resized");
-    NEB_HIP(ctx, hipSetDevice(ctx->device));
+    NEB_GUARD(ctx);
     NEB_HIP(ctx, hipDeviceSynchronize());
     free_planes(ctx);
     gi_on_resize(ctx->gi);
@@ -144,7 +150,7 @@ int neb_destroy(neb_ctx* ctx)
 {
     if (!ctx)
         return NEB_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();
     free_planes(ctx);
     gi_destroy(ctx->gi);
@@ -217,6 +223,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_defer_resolve needs a scene (neb_gi_set_scene)");
         return NEB_OK;
     }
+    if (!strcmp(key, "gi_max_bvh_depth")) {
+        if (gi_set_max_bvh_depth(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_max_bvh_depth needs a scene and a depth in 1..21");
+        return NEB_OK;
+    }
     if (!strcmp(key, "gi_debug_hits")) {
         if (gi_set_debug_hits(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_debug_hits needs a scene (neb_gi_set_scene)");
@@ -265,7 +276,7 @@ static int copy_rows(neb_ctx* ctx, int plane, int slot, uint32_t row0, uint32_t 
         return fail(ctx, NEB_ERR_OUT_OF_RANGE, "copy rows: rows not resident in this context");
     const size_t pitch = (size_t)ctx->W * kPlaneInfo[plane].bytes_per_px;
     char* d = (char*)ctx->planes[plane][s] + (size_t)(row0 - ctx->row_begin) * pitch;
-    NEB_HIP(ctx, hipSetDevice(ctx->device));
+    NEB_GUARD(ctx);
     if (upload)
         NEB_HIP(ctx, hipMemcpyAsync(d, host, pitch * nrows, hipMemcpyHostToDevice, (hipStream_t)stream));
     else
@@ -287,7 +298,7 @@ int neb_stream_synchronize(neb_ctx* ctx, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
-    NEB_HIP(ctx, hipSetDevice(ctx->device));
+    NEB_GUARD(ctx);
     NEB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return NEB_OK;
 }
@@ -299,6 +310,7 @@ int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream)
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
     // CopyResource(history <- current); moments/variance are NOT reset (SVGFDenoiser.cpp:57).
+    NEB_GUARD(ctx);
     const size_t bytes = (size_t)ctx->W * (ctx->row_end - ctx->row_begin) * 16;
     NEB_HIP(ctx, hipMemcpyAsync(ctx->planes[NEB_PLANE_RADIANCE][ctx->hist], ctx->planes[NEB_PLANE_RADIANCE][ctx->cur],
                                 bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -308,6 +320,7 @@ int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream)
 static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
 {
     SvgfLaunch L;
+    L.device = ctx->device;
     L.W = ctx->W;
     L.H = ctx->H;
     L.row_begin = ctx->row_begin;
@@ -326,6 +339,7 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
     if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
         return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_temporal_rows: rows not resident");
     const int c = ctx->cur, h = ctx->hist;
+    NEB_GUARD(ctx);
     hipError_t e = launch_temporal(make_launch(ctx, row0, row1), (float4*)ctx->planes[NEB_PLANE_RADIANCE][c],
                                    (const float4*)ctx->planes[NEB_PLANE_RADIANCE][h],
                                    (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][c],
@@ -407,6 +421,7 @@ int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint
     }
     int sp, ss, dp, ds;
     chain_link(ctx, level, &sp, &ss, &dp, &ds);
+    NEB_GUARD(ctx);
     hipError_t e = launch_atrous(make_launch(ctx, row0, row1), ctx->atrous_variant, step,
                                  (const float4*)ctx->planes[sp][ss], (float4*)ctx->planes[dp][ds],
                                  (const uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0],
@@ -430,6 +445,7 @@ int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream)
     }
     if (ctx->levels == 1) {
         const size_t bytes = (size_t)ctx->W * ctx->H * 16;
+        NEB_GUARD(ctx);
         NEB_HIP(ctx, hipMemcpyAsync(ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], ctx->planes[NEB_PLANE_SCRATCH][0], bytes,
                                     hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }

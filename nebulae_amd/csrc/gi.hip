@@ -587,6 +587,7 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: samplesPerPixel must be >= 1 and maxPathVertices <= 8 (MaxPathtracingRecursionDepth)");
     if (row0 == row1)
         return NEB_OK;
+    GI_GUARD(ctx);
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     if (g->debug_hits && !g->d_hits) {
         void* p = nullptr;
@@ -717,6 +718,7 @@ int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
     if (g->pending_row1 <= g->pending_row0)
         return NEB_OK;
+    GI_GUARD(ctx);
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     const size_t first = (size_t)(g->pending_row0 - ctx->row_begin) * ctx->W, n = (size_t)(g->pending_row1 - g->pending_row0) * ctx->W;
     hipLaunchKernelGGL(gi_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -732,6 +734,7 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
     GiState* g = ctx->gi;
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_pbr_direct: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
+    GI_GUARD(ctx);
     GiArgs a{};
     a.S = g->view;
     a.c = *c;
@@ -766,6 +769,7 @@ int neb_tonemap(neb_ctx* ctx, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
+    GI_GUARD(ctx);
     const size_t n = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], (uint32_t*)ctx->planes[NEB_PLANE_LDR][0], n);
@@ -787,6 +791,7 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
     if (!ctx || !ctx->gi)
         return ctx ? gi_fail(ctx, NEB_ERR_STATE, "neb_gi_ray_count: no scene") : NEB_ERR_INVALID_ARG;
     GiState* g = ctx->gi;
+    GI_GUARD(ctx);
     unsigned long long v[8] = {};
     std::vector<uint32_t> counts(2 * g->n_block_counts);
     GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -824,6 +829,7 @@ int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream)
         return NEB_ERR_INVALID_ARG;
     if (!ctx->gi || !ctx->gi->d_hits)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_download_hits: set option gi_debug_hits=1 and trace first");
+    GI_GUARD(ctx);
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     GI_HIP(ctx, hipMemcpyAsync(host, ctx->gi->d_hits, npx * sizeof(neb_gi_hit), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
@@ -837,6 +843,7 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
     GiState* g = ctx->gi;
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gbuffer_raycast: scene/BVH not ready");
+    GI_GUARD(ctx);
     auto norm = [](float* v) {
         const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         v[0] /= l;
@@ -884,6 +891,13 @@ int gi_set_sort_rays(neb_ctx* ctx, int mask)
         return NEB_ERR_STATE;
     ctx->gi->sort_shadow = (mask & 1) != 0;
     ctx->gi->sort_bounce = (mask & 2) != 0;
+    return NEB_OK;
+}
+int gi_set_max_bvh_depth(neb_ctx* ctx, int depth)
+{
+    if (!ctx->gi || depth < 1 || depth > (kLdsStack + kSpillStack) / 3)
+        return NEB_ERR_STATE;
+    ctx->gi->max_bvh_depth = (uint32_t)depth;
     return NEB_OK;
 }
 int gi_set_defer_resolve(neb_ctx* ctx, int on)

@@ -240,7 +240,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         return NEB_ERR_INVALID_ARG;
     if ((n_geoms && !geoms) || (n_mats && !mats) || (n_texs && !texs))
         return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_set_scene: null table");
-    GI_HIP(ctx, hipSetDevice(ctx->device));
+    GI_GUARD(ctx);
     GI_HIP(ctx, hipDeviceSynchronize());
     gi_destroy(ctx->gi);
     ctx->gi = nullptr;
@@ -425,20 +425,29 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     if (!g)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_build_bvh: no scene (call neb_gi_set_scene first)");
     hipStream_t stream = (hipStream_t)stream_;
-    GI_HIP(ctx, hipSetDevice(ctx->device));
+    GI_GUARD(ctx);
     const uint32_t n = g->n_tris;
-    g->built = true;
-    g->n_nodes = 0;
-    g->view.root = -1;
-    if (n == 0)
+    if (n == 0) { // empty scene: every ray misses
+        g->built = true;
+        g->n_nodes = 0;
+        g->view.root = -1;
         return NEB_OK;
+    }
+    // Everything is built into locals and committed to g->view only at the very end, on success: a failed (re)build
+    // leaves the scene exactly as it was -- still unbuilt, or still holding the previous, valid tree.
+    std::vector<void*> fresh; // device arrays of THIS build that outlive it (freed again on failure)
     auto dalloc = [&](size_t bytes, bool keep) -> void* {
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess)
             return nullptr;
         if (keep)
-            g->allocs.push_back(p);
+            fresh.push_back(p);
         return p;
+    };
+    auto drop_fresh = [&]() {
+        for (void* p : fresh)
+            (void)hipFree(p);
+        fresh.clear();
     };
     float* d_tris12 = (float*)dalloc((size_t)n * 48, false);
     float4* d_sorted = (float4*)dalloc((size_t)n * 48, true);
@@ -461,6 +470,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     if (!d_tris12 || !d_sorted || !d_keys || !d_keys2 || !d_nodes || !d_children || !d_parent_inner || !d_parent_leaf || !d_nmin ||
         !d_nmax || !d_visit) {
         free_temps();
+        drop_fresh();
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh: out of device memory");
     }
     hipError_t e = hipMemcpyAsync(d_tris12, g->h_tris.data(), (size_t)n * 48, hipMemcpyHostToDevice, stream);
@@ -521,6 +531,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     // (host pass over the device-built hierarchy: topology and boxes are the LBVH's; one-time setup)
     std::vector<Bvh4Node> wide;
     int root_code = ~0; // leaf {first 0, count 1}
+    int max_depth = 0;  // inner-node levels of the BVH4
     if (e == hipSuccess && n > 1) {
         std::vector<BvhNode> bin(n - 1);
         e = hipMemcpy(bin.data(), d_nodes, (size_t)(n - 1) * sizeof(BvhNode), hipMemcpyDeviceToHost);
@@ -724,11 +735,15 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             } else {
                 root_code = 0;
                 // work list of (binary node, wide slot index); wide nodes are emitted in DFS order
-                std::vector<std::pair<int, int>> work{{bin_root, 0}};
+                struct Work {
+                    int bi, wi, depth;
+                };
+                std::vector<Work> work{{bin_root, 0, 1}};
                 wide.emplace_back();
                 while (!work.empty()) {
-                    const auto [bi, wi] = work.back();
+                    const auto [bi, wi, depth] = work.back();
                     work.pop_back();
+                    max_depth = std::max(max_depth, depth);
                     Ref c[4];
                     int nc = 2;
                     children_of(bi, c);
@@ -761,7 +776,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
                             } else {
                                 ch[k] = (int)wide.size();
                                 wide.emplace_back();
-                                work.push_back({c[k].id, ch[k]});
+                                work.push_back({c[k].id, ch[k], depth + 1});
                             }
                         } else {
                             for (int q = 0; q < 3; ++q) {
@@ -792,14 +807,49 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     if (d_temp)
         (void)hipFree(d_temp);
     free_temps();
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        drop_fresh();
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh", e);
+    }
+    // The traverser keeps at most kLdsStack + kSpillStack pending nodes per ray; a closest-hit descent stacks up to 3
+    // siblings per level, so a tree deeper than that bound could lose hits.  Refuse it here instead.
+    if ((uint32_t)max_depth > g->max_bvh_depth) {
+        drop_fresh();
+        char msg[200];
+        snprintf(msg, sizeof(msg), "neb_gi_build_bvh: BVH4 depth %d exceeds the limit %u (the traversal stack holds %d entries, 3 per level)",
+                 max_depth, g->max_bvh_depth, kLdsStack + kSpillStack);
+        return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, msg);
+    }
+    // ---- commit: release the previous build's arrays (a rebuild), adopt the new ones ----
+    const void* old[] = {g->view.tris, g->view.shade, g->view.nodes};
+    if (g->built)
+        (void)hipDeviceSynchronize(); // no launch may still be walking the tree that is about to be freed
+    for (const void* o : old) {
+        if (!o)
+            continue;
+        for (size_t k = 0; k < g->allocs.size(); ++k)
+            if (g->allocs[k] == o) {
+                g->allocs.erase(g->allocs.begin() + (long)k);
+                (void)hipFree(const_cast<void*>(o));
+                break;
+            }
+    }
+    g->allocs.insert(g->allocs.end(), fresh.begin(), fresh.end());
     g->view.tris = d_sorted;
     g->view.shade = d_shade;
     g->view.nodes = d_wide;
     g->view.root = root_code;
     g->n_nodes = (uint32_t)wide.size();
-    std::vector<float>().swap(g->h_tris);
+    g->bvh_depth = (uint32_t)max_depth;
+    g->built = true; // (h_tris stays: the scene can be rebuilt)
+    return NEB_OK;
+}
+
+int neb_gi_bvh_depth(const neb_ctx* ctx, uint32_t* depth)
+{
+    if (!ctx || !ctx->gi || !depth)
+        return NEB_ERR_STATE;
+    *depth = ctx->gi->bvh_depth;
     return NEB_OK;
 }
 

@@ -211,6 +211,7 @@ template <bool FAST = false> __device__ float3 evaluate_direct_brdf(const Surfac
 #endif
 constexpr int kLdsStack = NEB_LDS_STACK; // per-lane entries kept in LDS (4 KB per wave at 16)
 constexpr int kSpillStack = 64 - kLdsStack; // deeper entries go to a private (scratch) array; rarely touched
+static_assert((kLdsStack + kSpillStack) / 3 == 21, "GiState::max_bvh_depth assumes a 64-entry traversal stack");
 
 struct Hit {
     float t, u, v;
@@ -296,7 +297,7 @@ struct TravStack {
         else if (sp < kLdsStack + kSpillStack)
             spill[sp - kLdsStack] = v;
         else
-            return; // deeper than 64 pending nodes: drop (cannot happen for a BVH4 over 64-bit Morton keys)
+            return; // unreachable: neb_gi_build_bvh refuses trees with 3 * depth > kLdsStack + kSpillStack (GiState::max_bvh_depth)
         sp++;
     }
     __device__ __forceinline__ int pop()

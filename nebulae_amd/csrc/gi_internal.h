@@ -107,7 +107,8 @@ struct GiState {
     // host copies kept for the build
     std::vector<float> h_tris; // 12 floats per triangle
     float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
-    uint32_t n_tris = 0, n_nodes = 0;
+    uint32_t n_tris = 0, n_nodes = 0, bvh_depth = 0;
+    uint32_t max_bvh_depth = 21; // (kLdsStack + kSpillStack) / 3: deeper trees are refused by neb_gi_build_bvh ("gi_max_bvh_depth" lowers it)
     bool built = false;
     unsigned long long* d_ray_counter = nullptr;
     neb_gi_hit* d_hits = nullptr;
@@ -148,6 +149,12 @@ static inline int gi_fail(neb_ctx* ctx, int code, const char* what, hipError_t e
         if (e_ != hipSuccess)                               \
             return gi_fail((ctx), NEB_ERR_HIP, #call, e_);  \
     } while (0)
+
+// scoped: run the rest of the entry point on the context's device, restore the caller's device on return
+#define GI_GUARD(ctx)                                                        \
+    neb::DeviceGuard gi_guard_((ctx)->device);                               \
+    if (gi_guard_.err != hipSuccess)                                         \
+    return gi_fail((ctx), NEB_ERR_HIP, "hipSetDevice", gi_guard_.err)
 
 template <typename T>
 static inline hipError_t upload(neb::GiState* g, const std::vector<T>& h, const T** out)

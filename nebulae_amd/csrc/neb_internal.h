@@ -14,7 +14,31 @@ struct PlaneInfo {
 };
 extern const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT];
 
+// Every entry point that launches or copies runs on its context's device whatever device the calling thread had
+// current, and leaves the thread's current device as it found it (a host may hold strip contexts on several GPUs).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != device)
+            err = hipSetDevice(device);
+        else
+            prev = -1; // nothing to restore
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct SvgfLaunch {
+    int device;            // HIP device ordinal of the context (per-device kernel attributes)
     uint32_t W, H;         // full image size (global clamp uses these)
     uint32_t row_begin;    // first resident image row: plane address of (x, y) is (y - row_begin) * W + x
     uint32_t row_end;      // one past the last resident row
@@ -42,6 +66,7 @@ void gi_on_resize(GiState* g);
 int gi_set_debug_hits(neb_ctx* ctx, int on);
 int gi_set_defer_resolve(neb_ctx* ctx, int on);
 int gi_set_sort_rays(neb_ctx* ctx, int mask);
+int gi_set_max_bvh_depth(neb_ctx* ctx, int depth);
 
 } // namespace neb
 

@@ -281,7 +281,8 @@ extern "C" int neb_debug_sort_pairs(neb_ctx* ctx, const uint32_t* keys, const ui
     }
     if (n == 0)
         return NEB_OK;
-    hipError_t e = hipSetDevice(ctx->device);
+    neb::DeviceGuard guard(ctx->device);
+    hipError_t e = guard.err;
     uint32_t* d = nullptr; // {keys, vals, keys_tmp, vals_tmp}
     void* scratch = nullptr;
     const size_t bytes = (size_t)n * sizeof(uint32_t);

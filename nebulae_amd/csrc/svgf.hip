@@ -12,6 +12,7 @@
 #pragma clang fp contract(off) // fused operations are explicit fmaf: see neb_device.h
 
 #include <algorithm>
+#include <atomic>
 
 #include "neb_device.h"
 #include "neb_internal.h"
@@ -154,6 +155,12 @@ __device__ __forceinline__ float depth_unorm24_fast(uint32_t d)
     return fmaf(rem, r, q);
 }
 
+// max(0, dot(n0, n)) of svgf_atrous.hlsl:74, saturated: the [0, 1] clamp is the free output modifier of the dot
+// product's last fma (a bare max(x, 0) is a separate v_max per tap).  Two unit normals can give 1 + 2 ulp, where the
+// reference's pow(d, 128) would be 1 + 3e-5 and this is 1 -- a deliberate divergence, the same in both
+// kernels so that every variant and every level is one function.
+__device__ __forceinline__ float normal_dot_sat(float d) { return fminf(fmaxf(d, 0.0f), 1.0f); }
+
 __device__ __forceinline__ float lum_scale(float var_f, float phiColor)
 {
     const float varScale = phiColor * __fsqrt_rn(fmaxf(var_f, 1e-8f)); // :41
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
             const float z = depth_unorm24_fast(a.depth[rowoff + qx]);
             const float3 n = oct16_unpack_zw(a.normal[rowoff + qx].y);
             const float lum = luminance(c.x, c.y, c.z);
-            const float d = fmaxf(fmaf(n0.z, n.z, fmaf(n0.y, n.y, n0.x * n.x)), 0.0f);
+            const float d = normal_dot_sat(fmaf(n0.z, n.z, fmaf(n0.y, n.y, n0.x * n.x)));
             float e = fmaf(a.phiNormal, fast_log2(d), atrous_log2k(dx, dy));
             e = fmaf(-fabsf(z0 - z), a.cz, e);
             e = fmaf(-fabsf(lum0 - lum), cl, e);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
                     // w = Kx*Ky * exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) as ONE exp2:
                     // exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d == 0 -> -inf -> weight 0)
                     const float lk = atrous_log2k(dx, dy);
-                    const float d = fminf(fmaxf(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)), 0.0f), 1.0f);
+                    const float d = normal_dot_sat(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)));
                     float e = fmaf(phiN, fast_log2(d), lk);
                     e = fmaf(-fabsf(z0[k] - tA.w), cz, e);
                     e = fmaf(-fabsf(lum0[k] - tB.w), cl[k], e);
@@ -399,17 +406,20 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
 // tile i, one barrier per tile -- 45-94 us per level against 41-49 us for the kernel above; the longer live
 // ranges cost more than the barrier and the exposed decode they remove.)
 template <int S, int R>
-static hipError_t launch_lds(AtrousArgs a, int num_cus, hipStream_t s)
+static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t s)
 {
     using T = AtrousTile<S, R>;
     constexpr size_t lds_bytes = (size_t)T::TOTAL * 2 * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device function attribute: remember which devices have it (one bit each; a
+    // device ordinal beyond the mask just sets it on every launch)
+    static std::atomic<uint64_t> attr_set{0};
+    const uint64_t bit = (device >= 0 && device < 64) ? (1ull << device) : 0ull;
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&svgf_atrous_lds_kernel<S, R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     a.tiles_x = (a.Wd + T::BW - 1) / T::BW;
     const int max_lattice_rows = (a.row1 - a.row0 + S - 1) / S; // per residue class, upper bound
@@ -456,12 +466,12 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
     // as measured; 2 / 3 force R = 2 / R = 4 everywhere (A/B arms)
     if (variant >= 1) {
         switch (step) {
-        case 1: return (variant == 2) ? launch_lds<1, 2>(a, num_cus, s) : launch_lds<1, 4>(a, num_cus, s);
-        case 2: return (variant == 2) ? launch_lds<2, 2>(a, num_cus, s) : launch_lds<2, 4>(a, num_cus, s);
-        case 4: return (variant == 2) ? launch_lds<4, 2>(a, num_cus, s) : launch_lds<4, 4>(a, num_cus, s);
-        case 8: return (variant == 3) ? launch_lds<8, 4>(a, num_cus, s) : launch_lds<8, 2>(a, num_cus, s);
-        case 16: return (variant == 3) ? launch_lds<16, 4>(a, num_cus, s) : launch_lds<16, 2>(a, num_cus, s);
-        case 32: return (variant == 3) ? launch_lds<32, 4>(a, num_cus, s) : launch_lds<32, 2>(a, num_cus, s);
+        case 1: return (variant == 2) ? launch_lds<1, 2>(a, L.device, num_cus, s) : launch_lds<1, 4>(a, L.device, num_cus, s);
+        case 2: return (variant == 2) ? launch_lds<2, 2>(a, L.device, num_cus, s) : launch_lds<2, 4>(a, L.device, num_cus, s);
+        case 4: return (variant == 2) ? launch_lds<4, 2>(a, L.device, num_cus, s) : launch_lds<4, 4>(a, L.device, num_cus, s);
+        case 8: return (variant == 3) ? launch_lds<8, 4>(a, L.device, num_cus, s) : launch_lds<8, 2>(a, L.device, num_cus, s);
+        case 16: return (variant == 3) ? launch_lds<16, 4>(a, L.device, num_cus, s) : launch_lds<16, 2>(a, L.device, num_cus, s);
+        case 32: return (variant == 3) ? launch_lds<32, 4>(a, L.device, num_cus, s) : launch_lds<32, 2>(a, L.device, num_cus, s);
         default: break; // wider steps do not fit the LDS tile: direct kernel
         }
     }

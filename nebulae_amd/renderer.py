@@ -88,6 +88,11 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_scene_info(self._ctx, C.byref(t), C.byref(n)), "neb_gi_scene_info")
         return t.value, n.value
 
+    def bvh_depth(self):
+        d = C.c_uint32()
+        self._check(self._lib.neb_gi_bvh_depth(self._ctx, C.byref(d)), "neb_gi_bvh_depth")
+        return d.value
+
     # ---- DeferredRenderer::BeginFrame (src/DeferredRenderer.cpp:89-149) ----
     def begin_frame(self, info):
         self.info = info

@@ -119,6 +119,7 @@ class StripRenderer(DeferredRenderer):
         self._views = {}
         import os
         self._staging = os.environ.get("NEB_STRIPS_STAGING") or None  # None | "host" | "device"
+        self._staging_decided = False
 
     def _plane_rows(self, plane, slot, row0, row1):
         key = (plane, slot)
@@ -130,10 +131,45 @@ class StripRenderer(DeferredRenderer):
     def submit_commands_gi_pathtrace(self, rows=None, stream=None):
         super().submit_commands_gi_pathtrace(rows=self.part.owned(self.rank) if rows is None else rows, stream=stream)
 
+    def _staging_mode(self, sample):
+        """How halo rows travel, decided ONCE and COLLECTIVELY (every rank must post the same operations):
+        None = zero copy, rows go straight out of / into the context's planes (RCCL: the planes are ordinary hipMalloc'ed
+        device memory); "host" = through host memory (a gloo group over GPU planes: the 1-GPU rehearsal);
+        "device" = through torch-allocated device buffers (NEB_STRIPS_STAGING=device).  The choice is a pure function
+        of the backend and of NEB_STRIPS_STAGING, and the ranks check with an all_reduce that they agree -- a rank
+        never changes mode on its own (an exception while posting is raised, not retried: its peer would hang)."""
+        if self._staging_decided:
+            return self._staging
+        import torch
+        import torch.distributed as dist
+        mode = self._staging
+        if mode not in (None, "host", "device"):
+            raise ValueError(f"NEB_STRIPS_STAGING={mode!r}: expected 'host' or 'device'")
+        if mode is None and sample.is_cuda and dist.get_backend(self.group) == "gloo":
+            mode = "host"
+        code = {None: 0, "host": 1, "device": 2}[mode]
+        on_cuda = sample.is_cuda and dist.get_backend(self.group) != "gloo"
+        v = torch.tensor([code, -code], dtype=torch.int32, device=sample.device if on_cuda else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+        if int(v[0]) != code or int(v[1]) != -code:
+            raise RuntimeError("strip ranks disagree on the halo staging mode (NEB_STRIPS_STAGING must be the same on every rank)")
+        self._staging, self._staging_decided = mode, True
+        return mode
+
+    def _exchange_stream(self):
+        """The exchange (P2P posts, staging copies, waits) must be ordered on the stream the kernels are enqueued on,
+        not on whatever torch's current stream happens to be."""
+        import contextlib
+        import torch
+        st = self.info.stream if self.info is not None else 0
+        if not torch.cuda.is_available() or st == torch.cuda.current_stream().cuda_stream:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(torch.cuda.ExternalStream(st))
+
     def _swap_rows_begin(self, planes, plan):
         """Starts one batched P2P exchange -- for every (plane, slot) and every (peer, send rows, recv rows) of the plan --
-        and returns the function that completes it (makes the current stream wait for the transfer).  Work enqueued on
-        the current stream between the two runs beside the transfer; it must not touch the rows being received."""
+        and returns the function that completes it (makes the launch stream wait for the transfer).  Work enqueued on
+        the launch stream between the two runs beside the transfer; it must not touch the rows being received."""
         import torch
         import torch.distributed as dist
         if not plan:
@@ -141,46 +177,29 @@ class StripRenderer(DeferredRenderer):
         send = [self._plane_rows(p, sl, s0, s1) for p, sl in planes for _, (s0, s1), _ in plan]
         recv = [self._plane_rows(p, sl, r0, r1) for p, sl in planes for _, _, (r0, r1) in plan]
         peers = [peer for _ in planes for peer, _, _ in plan]
-        # staging modes: None = zero copy (rows go straight out of / into the plane: the default on RCCL);
-        # "host" = through host memory (gloo rehearsal on a box without RCCL peers);
-        # "device" = through torch-allocated device buffers (NEB_STRIPS_STAGING=device: for RCCL builds that insist on
-        # memory from the framework's allocator; the planes are hipMalloc'ed by the context and only viewed by torch)
-        mode = self._staging
-        if mode is None and send[0].is_cuda and dist.get_backend(self.group) == "gloo":
-            mode = "host"
-        dst = recv
-        if mode == "host":
-            torch.cuda.current_stream().synchronize()
-            send = [t.cpu() for t in send]
-            dst = [torch.empty(t.shape, dtype=t.dtype) for t in recv]
-        elif mode == "device":
-            send = [t.clone() for t in send]
-            dst = [torch.empty_like(t) for t in recv]
-        def post(send_, dst_):
+        mode = self._staging_mode(send[0])
+        with self._exchange_stream():
+            dst = recv
+            if mode == "host":
+                torch.cuda.current_stream().synchronize()
+                send = [t.cpu() for t in send]
+                dst = [torch.empty(t.shape, dtype=t.dtype) for t in recv]
+            elif mode == "device":
+                send = [t.clone() for t in send]
+                dst = [torch.empty_like(t) for t in recv]
             ops = []
             for k, peer in enumerate(peers):
-                ops.append(dist.P2POp(dist.isend, send_[k], peer, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, dst_[k], peer, group=self.group))
-            return dist.batch_isend_irecv(ops)
-
-        try:
-            works = post(send, dst)
-        except RuntimeError:
-            # a backend that refuses the context's hipMalloc'ed planes (raised while posting, the same on every rank):
-            # stage through torch-allocated buffers from now on
-            if mode is not None:
-                raise
-            mode = self._staging = "device"
-            send = [t.clone() for t in send]
-            dst = [torch.empty_like(t) for t in recv]
-            works = post(send, dst)
+                ops.append(dist.P2POp(dist.isend, send[k], peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, dst[k], peer, group=self.group))
+            works = dist.batch_isend_irecv(ops)
 
         def finish():
-            for w in works:
-                w.wait()
-            if mode is not None:
-                for d, s_ in zip(recv, dst):
-                    d.copy_(s_)
+            with self._exchange_stream():
+                for w in works:
+                    w.wait()
+                if mode is not None:
+                    for d, s_ in zip(recv, dst):
+                        d.copy_(s_)
         return finish
 
     def _swap_rows(self, planes, plan):
@@ -254,5 +273,6 @@ class StripRenderer(DeferredRenderer):
                 events["levels"][level][1].record()
         if L == 1:  # single level filters into the scratch plane: copy the owned rows back (api.hip: neb_svgf_atrous)
             cur = self.svgf.get_current_resource_index()
-            self._plane_rows(PLANE_RADIANCE, cur, *own).copy_(self._plane_rows(PLANE_SCRATCH, 0, *own))
+            with self._exchange_stream():
+                self._plane_rows(PLANE_RADIANCE, cur, *own).copy_(self._plane_rows(PLANE_SCRATCH, 0, *own))
         return True

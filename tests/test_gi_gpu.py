@@ -330,3 +330,38 @@ def test_gi_matches_oracle_at_the_bench_size():
     assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 2e-5
     assert rel_l2(got[..., :3], want[..., :3]) <= 2e-3
     r.destroy()
+
+
+def test_rebuild_and_refused_build_keep_a_valid_tree():
+    """neb_gi_build_bvh commits only on success: a second build gives the same frame, and a build the depth limit refuses
+    (NEB_ERR_OUT_OF_RANGE instead of a traversal stack that silently drops nodes) leaves the previous tree in place."""
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=7))
+    depth = r.bvh_depth()
+    assert 1 <= depth <= 21  # 3 * depth <= the 64-entry traversal stack
+    upload_gbuffer(r, gb)
+
+    def frame():
+        r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+        r.submit_commands_gi_pathtrace()
+        return r.svgf.download(PLANE_RADIANCE)
+
+    first = frame()
+    assert float(np.abs(first).max()) > 0
+    r._check(r._lib.neb_gi_build_bvh(r._ctx, C.c_void_p(0)), "rebuild")     # a second build of the same scene
+    assert r.bvh_depth() == depth and np.array_equal(frame(), first)
+    r.svgf.set_option("gi_max_bvh_depth", 2)
+    assert r._lib.neb_gi_build_bvh(r._ctx, C.c_void_p(0)) == -5            # NEB_ERR_OUT_OF_RANGE
+    assert b"depth" in r._lib.neb_last_error(r._ctx)
+    assert r.bvh_depth() == depth and np.array_equal(frame(), first)       # the old tree still answers
+    r.svgf.set_option("gi_max_bvh_depth", 21)
+    r._check(r._lib.neb_gi_build_bvh(r._ctx, C.c_void_p(0)), "rebuild")
+    assert np.array_equal(frame(), first)
+    with pytest.raises(NebError):
+        r.svgf.set_option("gi_max_bvh_depth", 22)
+    r.destroy()
