@@ -83,7 +83,9 @@ class Scene:
         self.materials = []   # dicts: textures[3] (-1 = none), albedo[4], rm[2]
         self.textures = []    # uint8 [h, w, 4]
 
-    def add_geometry(self, positions, normals, uvs, indices, material, M=None, tangents=None):
+    def add_geometry(self, positions, normals, uvs, indices, material, M=None, tangents=None, omit=()):
+        """omit: attribute streams to leave out of the submesh ("normals", "uvs", "tangents"): their bindless index is
+        then invalid and hits on the submesh end the path (pathtracer.hlsl:313-318)."""
         positions = np.ascontiguousarray(positions, F)
         normals = np.ascontiguousarray(normals, F)
         uvs = np.ascontiguousarray(uvs, F)
@@ -91,9 +93,13 @@ class Scene:
         idx = idx.astype(np.uint16 if positions.shape[0] <= 65535 else np.uint32)
         if tangents is None:
             tangents = generate_tangents(positions, normals, uvs, idx)
-        self.geometries.append(dict(M=np.eye(4, dtype=F) if M is None else np.ascontiguousarray(M, F), material=material,
-                                    indices=idx, positions=positions, normals=normals, uvs=uvs,
-                                    tangents=np.ascontiguousarray(tangents, F)))
+        gm = dict(M=np.eye(4, dtype=F) if M is None else np.ascontiguousarray(M, F), material=material,
+                  indices=idx, positions=positions, normals=normals, uvs=uvs, tangents=np.ascontiguousarray(tangents, F))
+        for key in omit:
+            if key not in ("normals", "uvs", "tangents"):
+                raise ValueError(f"cannot omit {key!r}")
+            gm[key] = None
+        self.geometries.append(gm)
 
     def add_material(self, albedo=(0, 0, 0, 1), rm=(1.0, 0.0), textures=(-1, -1, -1)):
         self.materials.append(dict(textures=tuple(int(t) for t in textures), albedo=tuple(float(a) for a in albedo),
@@ -168,7 +174,7 @@ def generate_tangents(positions, normals, uvs, indices):
 
 
 # ---------------------------------------------------------------------------------------------
-# glTF (ASCII .gltf + .bin) -- what the reference gets from TinyGLTF
+# glTF (ASCII .gltf + .bin, or binary .glb) -- what the reference gets from TinyGLTF
 # ---------------------------------------------------------------------------------------------
 _COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
 _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
@@ -190,13 +196,60 @@ def _node_matrix(node):
     return (S @ R @ T).astype(F)
 
 
-def load_gltf(path, first_mesh_only=True):
-    """first_mesh_only mirrors InitRTAccelerationStructures, which builds the BLAS from the first
-    StaticMesh only (src/DeferredRenderer.cpp:992-995)."""
+_GLB_MAGIC, _GLB_JSON, _GLB_BIN = 0x46546C67, 0x4E4F534A, 0x004E4942  # 'glTF', 'JSON', 'BIN\0'
+
+
+def _read_container(path):
+    """-> (json dict, embedded BIN chunk or None).  EGLTFType::AsciiFile / ::Binary of
+    GLTFSceneImporter::ImportScenesFromFile (src/core/GLTFSceneImporter.cpp:20-34); the reference's default scene is a
+    .glb (src/Nebulae.cpp:36).  GLB 2.0: 12-byte header {magic, version, length}, then chunks {length, type, data}, the
+    first one JSON, an optional second one BIN (the buffer without a uri)."""
+    raw = open(path, "rb").read()
+    if len(raw) >= 12 and int.from_bytes(raw[:4], "little") == _GLB_MAGIC:
+        version, length = int.from_bytes(raw[4:8], "little"), int.from_bytes(raw[8:12], "little")
+        if version != 2 or length > len(raw):
+            raise ValueError(f"{path}: unsupported or truncated GLB (version {version}, length {length} of {len(raw)})")
+        off, doc, blob = 12, None, None
+        while off + 8 <= length:
+            n, kind = int.from_bytes(raw[off:off + 4], "little"), int.from_bytes(raw[off + 4:off + 8], "little")
+            data = raw[off + 8:off + 8 + n]
+            if len(data) != n:
+                raise ValueError(f"{path}: truncated GLB chunk")
+            if kind == _GLB_JSON and doc is None:
+                doc = json.loads(data.decode("utf-8"))
+            elif kind == _GLB_BIN and blob is None:
+                blob = np.frombuffer(data, np.uint8)
+            off += 8 + ((n + 3) & ~3)
+        if doc is None:
+            raise ValueError(f"{path}: GLB without a JSON chunk")
+        return doc, blob
+    return json.loads(raw.decode("utf-8")), None
+
+
+def _read_uri(base, uri):
+    if uri.startswith("data:"):
+        import base64
+        return np.frombuffer(base64.b64decode(uri.split(",", 1)[1]), np.uint8)
+    return np.fromfile(os.path.join(base, uri), np.uint8)
+
+
+def load_gltf(path, first_mesh_only=True, tex_upscale=1):
+    """ASCII .gltf (+ .bin / image files) or binary .glb.  Nodes are visited as ImportScene / ImportGLTFNode do
+    (GLTFSceneImporter.cpp:86,442-474): the scene's root nodes in order, then children, each mesh node with its OWN
+    local transform (the reference does not concatenate parents).  first_mesh_only mirrors InitRTAccelerationStructures,
+    which builds the BLAS from the first StaticMesh only (src/DeferredRenderer.cpp:992-995).  tex_upscale > 1 repeats
+    every texel k x k times (fixtures that carry down-sampled maps get their original working-set size back)."""
+    import io
+
     from PIL import Image
     base = os.path.dirname(path)
-    g = json.load(open(path))
-    buffers = [np.fromfile(os.path.join(base, b["uri"]), np.uint8) for b in g["buffers"]]
+    g, blob = _read_container(path)
+    buffers = [(_read_uri(base, b["uri"]) if "uri" in b else blob) for b in g.get("buffers", [])]
+
+    def view_bytes(i):
+        bv = g["bufferViews"][i]
+        off = bv.get("byteOffset", 0)
+        return buffers[bv["buffer"]][off:off + bv["byteLength"]]
 
     def accessor(i):
         a = g["accessors"][i]
@@ -216,12 +269,27 @@ def load_gltf(path, first_mesh_only=True):
             return -1
         src = g["textures"][ref["index"]]["source"]
         if src not in tex_cache:
-            img = Image.open(os.path.join(base, g["images"][src]["uri"])).convert("RGBA")
-            tex_cache[src] = sc.add_texture(np.asarray(img))
+            im = g["images"][src]
+            data = view_bytes(im["bufferView"]) if "bufferView" in im else _read_uri(base, im["uri"])
+            px = np.asarray(Image.open(io.BytesIO(data.tobytes())).convert("RGBA"))  # RGBA8, no sRGB decode (:156)
+            if tex_upscale > 1:
+                px = np.repeat(np.repeat(px, tex_upscale, axis=0), tex_upscale, axis=1)
+            tex_cache[src] = sc.add_texture(px)
         return tex_cache[src]
 
     mat_map = {}
-    for node in g["nodes"]:
+    order = []
+
+    def visit(ni):
+        order.append(ni)
+        for c in g["nodes"][ni].get("children", []):
+            visit(c)
+
+    scenes = g.get("scenes") or [{"nodes": list(range(len(g["nodes"])))}]
+    for root in scenes[g.get("scene", 0)].get("nodes", []):
+        visit(root)
+    for ni in order:
+        node = g["nodes"][ni]
         if "mesh" not in node:
             continue
         M = _node_matrix(node)
@@ -243,6 +311,84 @@ def load_gltf(path, first_mesh_only=True):
         if first_mesh_only:
             break
     return sc
+
+
+def save_glb(scene, path, with_tangents=False):
+    """Writes a Scene as one binary glTF 2.0 file: one mesh node (matrix = the geometries' shared instance transform), one
+    primitive per geometry, textures as embedded PNGs.  The fixtures under tests/golden/ are written with it; tangents
+    are left out by default so the loader regenerates them exactly as it does for a file that has none."""
+    import io
+
+    from PIL import Image
+    M0 = scene.geometries[0]["M"]
+    if any(not np.array_equal(g["M"], M0) for g in scene.geometries):
+        raise ValueError("save_glb: all geometries must share one instance transform (one mesh node)")
+    blob = bytearray()
+    views, accs = [], []
+
+    def add_view(data):
+        while len(blob) % 4:
+            blob.append(0)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
+        blob.extend(data)
+        return len(views) - 1
+
+    def add_acc(arr, ctype, kind, minmax=False):
+        a = {"bufferView": add_view(np.ascontiguousarray(arr).tobytes()), "componentType": ctype, "count": int(arr.shape[0]), "type": kind}
+        if minmax:
+            a["min"], a["max"] = [float(v) for v in arr.min(0)], [float(v) for v in arr.max(0)]
+        accs.append(a)
+        return len(accs) - 1
+
+    prims = []
+    for gm in scene.geometries:
+        at = {"POSITION": add_acc(gm["positions"], 5126, "VEC3", True), "NORMAL": add_acc(gm["normals"], 5126, "VEC3"),
+              "TEXCOORD_0": add_acc(gm["uvs"], 5126, "VEC2")}
+        if with_tangents and gm["tangents"] is not None:
+            at["TANGENT"] = add_acc(gm["tangents"], 5126, "VEC4")
+        idx = gm["indices"]
+        pr = {"attributes": at, "indices": add_acc(idx.reshape(-1, 1), 5123 if idx.dtype == np.uint16 else 5125, "SCALAR")}
+        if gm["material"] >= 0:
+            pr["material"] = int(gm["material"])
+        prims.append(pr)
+    images, textures = [], []
+    for t in scene.textures:
+        buf = io.BytesIO()
+        Image.fromarray(t, "RGBA").save(buf, format="PNG", optimize=True)
+        images.append({"bufferView": add_view(buf.getvalue()), "mimeType": "image/png"})
+        textures.append({"source": len(images) - 1})
+    mats = []
+    for m in scene.materials:
+        pbr = {}
+        ta, tn, tr = m["textures"]
+        if ta >= 0:
+            pbr["baseColorTexture"] = {"index": ta}
+        else:
+            pbr["baseColorFactor"] = [float(v) for v in m["albedo"]]
+        if tr >= 0:
+            pbr["metallicRoughnessTexture"] = {"index": tr}
+        else:
+            pbr["roughnessFactor"], pbr["metallicFactor"] = float(m["rm"][0]), float(m["rm"][1])
+        d = {"pbrMetallicRoughness": pbr}
+        if tn >= 0:
+            d["normalTexture"] = {"index": tn}
+        mats.append(d)
+    doc = {"asset": {"version": "2.0", "generator": "nebulae_amd.scene.save_glb"}, "scene": 0, "scenes": [{"nodes": [0]}],
+           "nodes": [{"mesh": 0, "name": scene.name, "matrix": [float(v) for v in M0.reshape(-1)]}],
+           "meshes": [{"primitives": prims}], "accessors": accs, "bufferViews": views, "buffers": [{"byteLength": len(blob)}]}
+    if mats:
+        doc["materials"] = mats
+    if images:
+        doc["images"], doc["textures"] = images, textures
+    js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
+    js += b" " * (-len(js) % 4)
+    while len(blob) % 4:
+        blob.append(0)
+    total = 12 + 8 + len(js) + 8 + len(blob)
+    with open(path, "wb") as f:
+        f.write(_GLB_MAGIC.to_bytes(4, "little") + (2).to_bytes(4, "little") + total.to_bytes(4, "little"))
+        f.write(len(js).to_bytes(4, "little") + _GLB_JSON.to_bytes(4, "little") + js)
+        f.write(len(blob).to_bytes(4, "little") + _GLB_BIN.to_bytes(4, "little") + bytes(blob))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,208 @@
+"""Every BASELINE.json config at its own shape, on the GPU, through the C ABI.
+
+  config 1  cornell_box 256x256, 1 spp, L=4            -- the real scene (tests/golden/cornell_box.glb), GI + SVGF vs the oracle
+  config 2  DamagedHelmet 1280x720, 1 spp, L=3         -- the real geometry, maps restored to 2048^2, odd-L chain (quirk 5)
+  config 3  sponza 1920x1080, 1 spp, L=5               -- tests/test_gi_gpu.py::test_gi_matches_oracle_at_the_bench_size + test_svgf_gpu.py
+  config 4  sponza 3840x2160, 1 spp, 4 row strips      -- four strip contexts on one device == the full 4K frame, bit for bit
+  config 5  sponza 3840x2160, 4 spp, 8 strips x 270 rows, camera moving then still -- faithful skip/reset and always-on
+
+(sponza = the documented stand-in: the Sponza geometry blobs are stripped from the reference checkout.)
+The scene fixtures are glTF binaries written by tests/golden/make_scene_fixtures.py from the reference's assets."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nebulae_amd import scene as S
+from nebulae_amd import strips
+from nebulae_amd.renderer import DeferredRenderer, RenderInfo
+from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE, SLOT_CURRENT
+from oracle_lib import OracleSVGF, OracleTracer, oracle_pbr_direct
+from strip_harness import LockstepStrips
+from svgf_cases import rel_l2
+from test_gi_gpu import upload_gbuffer
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _pipeline_vs_oracle(sc, cam, W, H, L, frames, hit_tol, albedo_override=None):
+    """PBR direct + GI + SVGF over `frames` static-camera frames, the reference's pass order and frame policy; every
+    GI frame is compared with oracle/trace_ref.cpp and the denoised result with oracle/svgf_ref.c fed the same noisy frames."""
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    if albedo_override is not None:  # (the reference's G-buffer albedo is 0 for a material without an albedo map)
+        import ctypes as C
+        packed = o.L.trace_ref_pack_r11g11b10((C.c_float * 3)(*albedo_override))
+        gb["albedo"] = np.where((gb["depth"] >> 24) == 0xFF, np.uint32(packed), np.uint32(0)).astype(np.uint32)
+    osv = OracleSVGF(W, H, L, threads=o.threads)
+    r = DeferredRenderer()
+    r.init(W, H, atrous_levels=L)
+    worst_hits = worst_rad = 0.0
+    for f in range(1, frames + 1):
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f))
+        if f == 1:
+            r.set_debug_hits(True)
+            assert r.scene_info()[0] == sc.num_triangles == o.triangles and 3 * r.bvh_depth() <= 64
+        osv.begin_frame(f)
+        upload_gbuffer(r, gb)
+        r.submit_commands_pbr_lighting()
+        r.submit_commands_gi_pathtrace()
+        noisy = r.svgf.download(PLANE_RADIANCE)
+        hits = r.download_hits()
+        direct, _ = oracle_pbr_direct(o, gb, r.global_constants())
+        want, ohits, _ = o.gi(gb, r.global_constants(), radiance=direct.copy())
+        same = (hits["geometry"] == ohits["geometry"]) & (hits["primitive"] == ohits["primitive"]) & \
+               ((hits["flags"] & 1) == (ohits["flags"] & 1)) & ((noisy[..., 0] > 0) == (want[..., 0] > 0))
+        worst_hits = max(worst_hits, 1.0 - float(same.mean()))
+        worst_rad = max(worst_rad, rel_l2(noisy[same][:, :3], want[same][:, :3]))
+        c = osv.cur
+        osv.depth[c][...] = gb["depth"]
+        osv.normal[c][...] = gb["normal"]
+        osv.radiance[c][...] = noisy  # the denoiser check is fed the GPU's own noisy frame
+        ran = r.submit_commands_svgf_denoising()
+        assert ran == (f >= 2)  # frame 1: "camera moved" (first eye position), SVGF skipped; frame 2 resets the history
+        if ran:
+            if f == 2:
+                osv.reset_history()
+            osv.temporal_pass()
+            osv.atrous_pass()
+        r.end_frame()
+    got = r.svgf.download(PLANE_RADIANCE)
+    want = osv.radiance[osv.cur]
+    assert worst_hits <= hit_tol, f"hit / visibility mismatch fraction {worst_hits:.2e}"
+    assert worst_rad <= 2e-5, worst_rad
+    assert np.isfinite(got).all() and float(np.abs(got[..., :3]).max()) > 0
+    assert rel_l2(got, want) <= 1e-4  # north_star bar: 1e-3
+    r.destroy()
+    osv.close()
+    o.close()
+
+
+@pytest.mark.parametrize("albedo", [None, (0.725, 0.71, 0.68)])
+def test_config1_cornell_box_256(albedo):
+    """albedo None = reference-faithful: cornell_box has factor-only materials, for which deferred_gbuffers.hlsl:72-76
+    writes albedo 0, so the path throughput is 0 and only the specular direct term survives (a plumbing config, as
+    BASELINE.json says).  The second case puts the white material's factor into the G-buffer so that the indirect term
+    is exercised on the real geometry too."""
+    sc = S.load_gltf(os.path.join(GOLDEN, "cornell_box.glb"))
+    assert sc.num_triangles == 34 and len(sc.geometries) == 3 and len(sc.textures) == 0
+    cam = S.orbit_camera(origin=(0.0, 1.0, 0.0), distance=3.5)  # the file's own camera node: translation (0, 1, 3.5)
+    _pipeline_vs_oracle(sc, cam, 256, 256, 4, frames=8, hit_tol=3e-4, albedo_override=albedo)
+
+
+def test_config2_damaged_helmet_720p_three_levels():
+    sc = S.load_gltf(os.path.join(GOLDEN, "DamagedHelmet_256.glb"), tex_upscale=8)
+    assert sc.num_triangles == 15452 and len(sc.geometries) == 1 and [t.shape for t in sc.textures] == [(2048, 2048, 4)] * 3
+    assert sc.geometries[0]["indices"].dtype == np.uint16
+    cam = S.orbit_camera()  # reference defaults (InspectCamera.h:52-55): eye (0, 0, 3)
+    _pipeline_vs_oracle(sc, cam, 1280, 720, 3, frames=4, hit_tol=3e-4)
+
+
+def test_helmet_gbuffer_producer_matches_oracle():
+    sc = S.load_gltf(os.path.join(GOLDEN, "DamagedHelmet_256.glb"), tex_upscale=2)
+    cam, W, H = S.orbit_camera(yaw_deg=20.0, pitch_deg=70.0, distance=2.6), 640, 360
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    r.submit_commands_gbuffer()
+    d = r.svgf.download(PLANE_DEPTH)
+    covered = (d >> 24) == (gb["depth"] >> 24)
+    assert covered.mean() >= 1.0 - 5e-4 and 0.2 < (d >> 24 == 0xFF).mean() < 0.9
+    n = r.svgf.download(PLANE_NORMAL).astype(np.float32)
+    assert np.percentile(np.abs(n - gb["normal"].astype(np.float32)), 99.0) <= 4e-3
+    r.destroy()
+
+
+_ATRIUM = []
+
+
+def _atrium():
+    if not _ATRIUM:
+        _ATRIUM.append(S.atrium_standin())
+    return _ATRIUM[0]
+
+
+def _strips_vs_full(W, H, N, L, spp, cams, always_on=False, scheme="once"):
+    sc = _atrium()
+    full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
+    ls = LockstepStrips(W, H, N, L, scheme)
+    assert all(ls.part.owned(k)[1] - ls.part.owned(k)[0] == H // N for k in range(N))
+    flags = []
+    for r in [full] + ls.rs:
+        r.gi_ui.gi_samples_per_pixel = spp
+        r.denoise_while_moving = always_on
+    for f, cam in enumerate(cams, start=1):
+        info = RenderInfo(scene=sc, camera=cam, frame_index=f)
+        for r in [full] + ls.rs:
+            r.begin_frame(info)
+            r.submit_commands_gbuffer()
+            r.submit_commands_pbr_lighting()
+            r.submit_commands_gi_pathtrace()
+        torch.cuda.synchronize()
+        ran_full = full.submit_commands_svgf_denoising()
+        ran = ls.denoise()
+        assert all(x == ran_full for x in ran)
+        flags.append(ran_full)
+        torch.cuda.synchronize()
+        if f == len(cams) // 2 or f == len(cams):  # mid-sequence and final frame: strips == full image, bit for bit
+            want = full.svgf.download(PLANE_RADIANCE)
+            assert np.isfinite(want).all() and float(np.abs(want[..., :3]).max()) > 0.0
+            assert np.array_equal(ls.image(), want), f"frame {f}"
+    full.destroy()
+    ls.destroy()
+    return flags
+
+
+def test_config4_4k_in_four_strips_equals_full_frame():
+    cam = S.sponza_camera()
+    flags = _strips_vs_full(3840, 2160, 4, 5, 1, [cam] * 4)
+    assert flags == [False, True, True, True]
+
+
+@pytest.mark.parametrize("always_on", [False, True])
+def test_config5_4k_eight_strips_4spp_moving_then_still(always_on):
+    """8 strips of 270 rows, 4 spp, yaw += 0.5 deg per frame, then a still camera.  Faithful
+    mode skips SVGF while the camera moves and resets the history on the first still frame
+    (src/DeferredRenderer.cpp:133-146,593-614); always-on (beyond the reference) denoises every frame."""
+    def cam(k):
+        return S.orbit_camera(origin=(0.0, 2.0, 0.0), yaw_deg=12.0 + 0.5 * k, pitch_deg=60.0, distance=9.0)
+    cams = [cam(k) for k in (1, 2, 3)] + [cam(3)] * 3
+    flags = _strips_vs_full(3840, 2160, 8, 5, 4, cams, always_on=always_on)
+    assert flags == ([True] * 6 if always_on else [False, False, False, True, True, True])
+
+
+def test_missing_attribute_submesh_terminates_the_path():
+    """A submesh without one of its attribute streams has an invalid bindless index: ReconstructSurfaceData returns
+    valid == false and the path ends at that hit with nothing added (pathtracer.hlsl:313-318,513-518)."""
+    W, H = 200, 152
+    cam = S.orbit_camera(yaw_deg=10.0, pitch_deg=80.0, distance=2.6)
+    base = S.cornell_standin(textured=True)
+    sc = S.Scene("cornell-missing-attributes")
+    sc.materials, sc.textures = base.materials, base.textures
+    for k, g in enumerate(base.geometries):
+        sc.add_geometry(g["positions"], g["normals"], g["uvs"], g["indices"], g["material"], M=g["M"], tangents=g["tangents"],
+                        omit=(("tangents",) if k == 0 else ("normals", "uvs") if k == 1 else ()))
+    o = OracleTracer(sc)
+    gb = OracleTracer(base).gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.gi_ui.max_path_vertices = 3
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=4))
+    upload_gbuffer(r, gb)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    r.set_debug_hits(True)
+    r.ray_count(reset=True)
+    r.submit_commands_gi_pathtrace()
+    got, hits, rays = r.svgf.download(PLANE_RADIANCE), r.download_hits(), r.ray_count()
+    want, ohits, orays = o.gi(gb, r.global_constants())
+    invalid = (ohits["t"] > 0) & (ohits["geometry"] <= 1)
+    assert invalid.mean() > 0.1                                   # a good share of the first hits land on the two crippled submeshes
+    same = (hits["geometry"] == ohits["geometry"]) & (hits["primitive"] == ohits["primitive"])
+    assert same.mean() >= 1.0 - 3e-4 and abs(rays - orays) <= max(8, 1e-3 * orays)
+    assert float(np.abs(got[invalid & same][:, :3]).max()) == 0.0  # nothing is added on those paths
+    assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 2e-4
+    r.destroy()
