@@ -103,6 +103,9 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (default on),
  *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
  *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it;
+ *   "gi_exact_shade":   1 = hit shading in the C arithmetic of the CPU oracle (IEEE division, sqrt, powf, sinf / cosf) instead of
+ *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
+ *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3). */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
@@ -204,6 +207,8 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
  * state (unbuilt, or the previous valid tree); calling it again rebuilds. */
 int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream);
 int neb_gi_scene_info(const neb_ctx* ctx, uint32_t* n_triangles, uint32_t* n_nodes);
+/* Device bytes of the scene: {texture footprint tables + material bundles, triangles + shading records, BVH nodes}. */
+int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3]);
 /* Inner-node levels of the BVH4 of the last successful build.  neb_gi_build_bvh returns NEB_ERR_OUT_OF_RANGE (and keeps the
  * previous tree, if any) when the depth exceeds what the traversal stack covers: 21, or "gi_max_bvh_depth". */
 int neb_gi_bvh_depth(const neb_ctx* ctx, uint32_t* depth);

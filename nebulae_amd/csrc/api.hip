@@ -223,6 +223,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_defer_resolve needs a scene (neb_gi_set_scene)");
         return NEB_OK;
     }
+    if (!strcmp(key, "gi_exact_shade")) {
+        if (gi_set_exact_shade(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_exact_shade needs a scene (neb_gi_set_scene)");
+        return NEB_OK;
+    }
     if (!strcmp(key, "gi_max_bvh_depth")) {
         if (gi_set_max_bvh_depth(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_max_bvh_depth needs a scene and a depth in 1..21");

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_bounce_trace_kernel(Gi
         count_rays(a.bounce_counts, rays);
 }
 
+// FAST: the arithmetic policy of gi_device.h (1-ulp hardware rcp / rsq / sqrt / sin / cos, the forms an HLSL compiler emits);
+// FAST = false is the C arithmetic of the oracle (option "gi_exact_shade", see neb_set_option).
+template <bool FAST>
 __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
 {
     uint32_t x, y;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
             const uint32_t tri = __float_as_uint(h.w);
             Surface surf;
             uint32_t geom;
-            const bool shaded = reconstruct_surface<kFastShade>(a.S, tri, h.y, h.z, surf, geom);
+            const bool shaded = reconstruct_surface<FAST>(a.S, tri, h.y, h.z, surf, geom);
             dbg.t = h.x;
             dbg.geometry = geom;
             if (a.hits)
@@ -236,22 +239,22 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
                 const float4 ro = a.R.ray_o[i];
                 const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
                 const float3 hitP = org + dir * h.x;
-                const float3 V = normalize3<kFastShade>(-dir); // :522
+                const float3 V = normalize3<FAST>(-dir); // :522
                 uint32_t rng = __float_as_uint(pth.w);
                 const float a0 = rand01(rng), a1 = rand01(rng);
-                const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<kFastShade>(a1);
+                const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<FAST>(a1);
                 const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
                 const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
-                const float3 L = normalize3<kFastShade>(-sun_dir);
-                const float3 Bv = normalize3<kFastShade>(perpendicular(L));
+                const float3 L = normalize3<FAST>(-sun_dir);
+                const float3 Bv = normalize3<FAST>(perpendicular(L));
                 const float3 T = cross3(Bv, L);
                 // (the disk offset is scaled by tan(0.29 deg) = 0.005: the ~1e-6 error of v_sin / v_cos moves the direction by
                 // less than an ulp, so the hardware forms are safe here; the hemisphere sampler keeps sinf / cosf)
-                const float sn_a = kFastShade ? __sinf(angle) : sinf(angle), cs_a = kFastShade ? __cosf(angle) : cosf(angle);
-                const float3 inc = normalize3<kFastShade>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
+                const float sn_a = FAST ? __sinf(angle) : sinf(angle), cs_a = FAST ? __cosf(angle) : cosf(angle);
+                const float3 inc = normalize3<FAST>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
                 const bool transition = dot3(surf.GN, inc) <= 0.0f;
                 const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
-                const float3 O = evaluate_direct_brdf<kFastShade>(surf, V, L) * sun_rad * throughput; // :573-574
+                const float3 O = evaluate_direct_brdf<FAST>(surf, V, L) * sun_rad * throughput; // :573-574
                 rec_o = make_float4(so.x, so.y, so.z, 0.001f);
                 shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
                 rec_c = make_float4(O.x, O.y, O.z, 0.f);
@@ -260,14 +263,14 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
                     // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
                     // so the Rand(rng) of :614 returns the same number as the first of them.
                     uint32_t rng_copy = rng;
-                    const float3 SNn = normalize3<kFastShade>(surf.SN);
+                    const float3 SNn = normalize3<FAST>(surf.SN);
                     const float e0 = rand01(rng_copy), e1 = rand01(rng_copy);
-                    const float3 Ld = cosine_hemisphere_aligned<kFastShade>(e0, e1, SNn);
-                    const float pdiff = 1.0f - specular_probability<kFastShade>(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
+                    const float3 Ld = cosine_hemisphere_aligned<FAST>(e0, e1, SNn);
+                    const float pdiff = 1.0f - specular_probability<FAST>(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
                     const float3 no = hitP + surf.GN * 1e-2f; // :607
                     throughput = throughput * (surf.albedo * (1.0f - surf.metalness)); // :613
                     if (rand01(rng) < pdiff)
-                        throughput = f3(fdiv<kFastShade>(throughput.x, pdiff), fdiv<kFastShade>(throughput.y, pdiff), fdiv<kFastShade>(throughput.z, pdiff)); // :614-618
+                        throughput = f3(fdiv<FAST>(throughput.x, pdiff), fdiv<FAST>(throughput.y, pdiff), fdiv<FAST>(throughput.z, pdiff)); // :614-618
                     a.R.ray_o[i] = make_float4(no.x, no.y, no.z, 0.001f);
                     next_d = make_float4(Ld.x, Ld.y, Ld.z, 1.0f);
                     a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
@@ -436,8 +439,10 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
             const float v = ts.uv0.y * b0 + ts.uv1.y * b1 + ts.uv2.y * b2;
             if (g.material >= 0) {
                 const DevMat m = a.S.mats[g.material];
+                MapSamples maps;
+                sample_material_maps(a.S, m, u, v, maps);
                 if (m.tex[0] >= 0) {
-                    const float4 t = sample_texture(a.S, m.tex[0], u, v);
+                    const float4 t = maps.albedo;
                     alb = f3(t.x, t.y, t.z);
                 }
                 if (m.tex[1] >= 0) {
@@ -447,12 +452,12 @@ __global__ __launch_bounds__(64) void gbuffer_kernel(GbufArgs a)
                     const float3 bt2 = normalize3(cross3(normalize3(n2), tg2) * ts.t2.w);
                     const float3 T = normalize3(tg0 * b0 + tg1 * b1 + tg2 * b2);
                     const float3 B = normalize3(bt0 * b0 + bt1 * b1 + bt2 * b2);
-                    const float4 t = sample_texture(a.S, m.tex[1], u, v);
+                    const float4 t = maps.normal;
                     const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
                     SN = normalize3(T * N.x + B * N.y + GN * N.z);
                 }
                 if (m.tex[2] >= 0) {
-                    const float4 t = sample_texture(a.S, m.tex[2], u, v);
+                    const float4 t = maps.rm;
                     rm0 = t.y;
                     rm1 = t.z;
                 }
@@ -690,7 +695,10 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             } else if (b > 1) {
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             }
-            hipLaunchKernelGGL(gi_shade_kernel, grid, block, 0, (hipStream_t)stream, a);
+            if (kFastShade && !g->exact_shade)
+                hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
             if (g->sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the
                 // sorted pixel indices land back in vals
@@ -898,6 +906,13 @@ int gi_set_max_bvh_depth(neb_ctx* ctx, int depth)
     if (!ctx->gi || depth < 1 || depth > (kLdsStack + kSpillStack) / 3)
         return NEB_ERR_STATE;
     ctx->gi->max_bvh_depth = (uint32_t)depth;
+    return NEB_OK;
+}
+int gi_set_exact_shade(neb_ctx* ctx, int on)
+{
+    if (!ctx->gi)
+        return NEB_ERR_STATE;
+    ctx->gi->exact_shade = on != 0;
     return NEB_OK;
 }
 int gi_set_defer_resolve(neb_ctx* ctx, int on)

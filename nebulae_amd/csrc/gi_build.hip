@@ -76,6 +76,19 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
         out[8 * (size_t)ti + k] = r[k];
 }
 
+// Bilinear-footprint table of one RGBA8 image: entry (x, y) = the texels {(x,y), (x+1,y), (x,y+1), (x+1,y+1)} with the wrap
+// addressing applied, so a filtered fetch is one 16-byte load.  `stride` (in uint4) = 1 for a standalone table, 4 for one
+// slot of a material's interleaved 64-byte entries.
+__global__ void texture_footprints_kernel(const uint32_t* __restrict__ px, uint32_t w, uint32_t h, uint4* out, uint32_t stride)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)w * h)
+        return;
+    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
+    const uint32_t x1 = (x + 1) % w, y1 = (y + 1) % h;
+    out[i * stride] = make_uint4(px[(size_t)y * w + x], px[(size_t)y * w + x1], px[(size_t)y1 * w + x], px[(size_t)y1 * w + x1]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LBVH build (Karras 2012): Morton keys -> radix sort -> hierarchy -> bottom-up refit
 // ------------------------------------------------------------------------------------------------
@@ -248,7 +261,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
     std::vector<DevGeom> dgeoms(n_geoms);
     std::vector<DevMat> dmats(n_mats);
     std::vector<DevTex> dtexs(n_texs);
-    std::vector<uint32_t> indices, texels;
+    std::vector<uint32_t> indices;
     std::vector<float> normals, uvs, tangents;
     uint32_t vertex_base = 0;
     float smin[3] = {3.4e38f, 3.4e38f, 3.4e38f}, smax[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
@@ -337,62 +350,105 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         d.rough = mats[i].roughnessMetalness[0];
         d.metal = mats[i].roughnessMetalness[1];
     }
+    // ---- textures: the raw RGBA8 images go up once; the bilinear-footprint tables are built from them on the device ----
+    // (a footprint entry holds the 4 texels of a bilinear fetch, wrap applied: 16 B per texel position and map.  Sponza's
+    // 69 maps of 1024^2 make 1.2 GB of per-map tables / 1.6 GB of material bundles -- nothing to assemble on the host.)
+    std::vector<size_t> raw_off(n_texs);
+    size_t raw_total = 0;
     for (uint32_t i = 0; i < n_texs; ++i) {
         if (!texs[i].rgba8 || !texs[i].width || !texs[i].height) {
             delete g;
             return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_set_scene: empty texture");
         }
-        dtexs[i].offset = (uint32_t)(texels.size() / 4); // in footprint entries (uint4)
+        dtexs[i].offset = 0xffffffffu; // no standalone table unless a material needs one (below)
         dtexs[i].w = texs[i].width;
         dtexs[i].h = texs[i].height;
         dtexs[i].pad = 0;
-        const uint32_t* px = (const uint32_t*)texs[i].rgba8;
-        const uint32_t tw = texs[i].width, th = texs[i].height;
-        const size_t base = texels.size();
-        texels.resize(base + (size_t)tw * th * 4);
-        for (uint32_t y = 0; y < th; ++y) {
-            const uint32_t y1 = (y + 1) % th;
-            for (uint32_t x = 0; x < tw; ++x) {
-                const uint32_t x1 = (x + 1) % tw;
-                uint32_t* q = &texels[base + ((size_t)y * tw + x) * 4];
-                q[0] = px[(size_t)y * tw + x];
-                q[1] = px[(size_t)y * tw + x1];
-                q[2] = px[(size_t)y1 * tw + x];
-                q[3] = px[(size_t)y1 * tw + x1];
-            }
-        }
+        raw_off[i] = raw_total;
+        raw_total += (size_t)texs[i].width * texs[i].height;
     }
-    // interleaved footprints of the materials whose three maps share one size (DevMat::bundle); 64 B per texel position
-    std::vector<uint4> bundles;
+    // materials whose three maps share one size keep their footprints interleaved (DevMat::bundle, 64 B per texel position);
+    // every other map a material uses gets a standalone table
     constexpr size_t kBundleBudget = (size_t)4 << 30; // bytes; beyond it the remaining materials sample their maps separately
+    size_t bundle_entries = 0, table_entries = 0;     // in 64-byte / 16-byte units
+    std::vector<char> standalone(n_texs, 0);
     for (uint32_t i = 0; i < n_mats; ++i) {
         DevMat& d = dmats[i];
         d.bundle = d.bundle_w = d.bundle_h = d.pad = 0;
-        if (d.tex[0] < 0 || d.tex[1] < 0 || d.tex[2] < 0)
-            continue;
-        const DevTex &ta = dtexs[d.tex[0]], &tn = dtexs[d.tex[1]], &tr = dtexs[d.tex[2]];
-        if (ta.w != tn.w || ta.w != tr.w || ta.h != tn.h || ta.h != tr.h)
-            continue;
-        const size_t n_pos = (size_t)ta.w * ta.h;
-        if ((bundles.size() + 4 * n_pos) * sizeof(uint4) > kBundleBudget || bundles.size() / 4 + n_pos > 0xffffffffull)
-            continue;
-        d.bundle = (uint32_t)(bundles.size() / 4);
-        d.bundle_w = ta.w;
-        d.bundle_h = ta.h;
-        const size_t base = bundles.size();
-        bundles.resize(base + 4 * n_pos);
-        const uint4* fa = reinterpret_cast<const uint4*>(texels.data()) + ta.offset;
-        const uint4* fn = reinterpret_cast<const uint4*>(texels.data()) + tn.offset;
-        const uint4* fr = reinterpret_cast<const uint4*>(texels.data()) + tr.offset;
-        for (size_t k = 0; k < n_pos; ++k) {
-            bundles[base + 4 * k] = fa[k];
-            bundles[base + 4 * k + 1] = fn[k];
-            bundles[base + 4 * k + 2] = fr[k];
-            bundles[base + 4 * k + 3] = make_uint4(0, 0, 0, 0);
+        bool bundled = false;
+        if (d.tex[0] >= 0 && d.tex[1] >= 0 && d.tex[2] >= 0) {
+            const DevTex &ta = dtexs[d.tex[0]], &tn = dtexs[d.tex[1]], &tr = dtexs[d.tex[2]];
+            const size_t n_pos = (size_t)ta.w * ta.h;
+            if (ta.w == tn.w && ta.w == tr.w && ta.h == tn.h && ta.h == tr.h && (bundle_entries + n_pos) * 64 <= kBundleBudget &&
+                bundle_entries + n_pos <= 0xffffffffull) {
+                d.bundle = (uint32_t)bundle_entries;
+                d.bundle_w = ta.w;
+                d.bundle_h = ta.h;
+                bundle_entries += n_pos;
+                bundled = true;
+            }
         }
+        if (!bundled)
+            for (int k = 0; k < 3; ++k)
+                if (d.tex[k] >= 0)
+                    standalone[d.tex[k]] = 1;
     }
-    if (bundles.empty())
-        bundles.push_back(make_uint4(0, 0, 0, 0));
+    for (uint32_t i = 0; i < n_texs; ++i)
+        if (standalone[i]) {
+            if (table_entries + (size_t)dtexs[i].w * dtexs[i].h > 0xfffffffeull) {
+                delete g;
+                return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_gi_set_scene: more than 2^32 texels in standalone texture tables");
+            }
+            dtexs[i].offset = (uint32_t)table_entries;
+            table_entries += (size_t)dtexs[i].w * dtexs[i].h;
+        }
+    g->texture_table_bytes = table_entries * 16 + bundle_entries * 64;
+    {
+        uint32_t* d_raw = nullptr;
+        uint4* d_tables = nullptr;
+        uint4* d_bundles = nullptr;
+        hipError_t te = hipSuccess;
+        auto talloc = [&](void** p, size_t bytes, bool keep) {
+            if (te != hipSuccess)
+                return;
+            te = hipMalloc(p, bytes ? bytes : 16);
+            if (te == hipSuccess && keep)
+                g->allocs.push_back(*p);
+        };
+        talloc((void**)&d_raw, raw_total * 4, false);
+        talloc((void**)&d_tables, table_entries * 16, true);
+        talloc((void**)&d_bundles, bundle_entries * 64, true);
+        for (uint32_t i = 0; i < n_texs && te == hipSuccess; ++i)
+            te = hipMemcpy(d_raw + raw_off[i], texs[i].rgba8, (size_t)texs[i].width * texs[i].height * 4, hipMemcpyHostToDevice);
+        for (uint32_t i = 0; i < n_texs && te == hipSuccess; ++i)
+            if (standalone[i]) {
+                const size_t n_pos = (size_t)dtexs[i].w * dtexs[i].h;
+                hipLaunchKernelGGL(texture_footprints_kernel, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, nullptr, d_raw + raw_off[i],
+                                   dtexs[i].w, dtexs[i].h, d_tables + dtexs[i].offset, 1u);
+                te = hipGetLastError();
+            }
+        for (uint32_t i = 0; i < n_mats && te == hipSuccess; ++i) {
+            const DevMat& d = dmats[i];
+            if (!d.bundle_w)
+                continue;
+            const size_t n_pos = (size_t)d.bundle_w * d.bundle_h;
+            for (int k = 0; k < 3 && te == hipSuccess; ++k) { // slot k of every 64-byte entry
+                hipLaunchKernelGGL(texture_footprints_kernel, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, nullptr, d_raw + raw_off[d.tex[k]],
+                                   d.bundle_w, d.bundle_h, d_bundles + 4 * (size_t)d.bundle + k, 4u);
+                te = hipGetLastError();
+            }
+        }
+        if (te == hipSuccess)
+            te = hipDeviceSynchronize();
+        if (d_raw)
+            (void)hipFree(d_raw);
+        if (te != hipSuccess) {
+            gi_destroy(g);
+            return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: texture tables", te);
+        }
+        g->view.texels = reinterpret_cast<const uint32_t*>(d_tables);
+        g->view.bundles = d_bundles;
+    }
     g->n_tris = (uint32_t)(g->h_tris.size() / 12);
     memcpy(g->scene_min, smin, sizeof(smin));
     memcpy(g->scene_max, smax, sizeof(smax));
@@ -400,8 +456,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
     if ((e = upload(g, dgeoms, &g->view.geoms)) != hipSuccess || (e = upload(g, dmats, &g->view.mats)) != hipSuccess ||
         (e = upload(g, dtexs, &g->view.texs)) != hipSuccess || (e = upload(g, indices, &g->view.indices)) != hipSuccess ||
         (e = upload(g, normals, &g->view.normals)) != hipSuccess || (e = upload(g, uvs, &g->view.uvs)) != hipSuccess ||
-        (e = upload(g, tangents, &g->view.tangents)) != hipSuccess || (e = upload(g, texels, &g->view.texels)) != hipSuccess ||
-        (e = upload(g, bundles, &g->view.bundles)) != hipSuccess) {
+        (e = upload(g, tangents, &g->view.tangents)) != hipSuccess) {
         gi_destroy(g);
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: upload", e);
     }
@@ -842,6 +897,17 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     g->n_nodes = (uint32_t)wide.size();
     g->bvh_depth = (uint32_t)max_depth;
     g->built = true; // (h_tris stays: the scene can be rebuilt)
+    return NEB_OK;
+}
+
+int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3])
+{
+    if (!ctx || !ctx->gi || !out)
+        return NEB_ERR_STATE;
+    const neb::GiState* g = ctx->gi;
+    out[0] = g->texture_table_bytes;
+    out[1] = g->built ? (uint64_t)g->n_tris * (48 + 128) : 0;
+    out[2] = (uint64_t)g->n_nodes * sizeof(neb::Bvh4Node);
     return NEB_OK;
 }
 

@@ -486,6 +486,33 @@ template <bool FAST = false> __device__ float4 sample_texture(const SceneView& S
     return filter_footprint<FAST>(fp, fx, fy);
 }
 
+// The (up to) three filtered map fetches of a material at one uv.  A material whose three maps share one size keeps
+// their bilinear footprints interleaved, one 64-byte entry per texel position (DevMat::bundle): one line per hit
+// instead of three.  Maps a material does not have are left untouched (the caller uses the factors).
+struct MapSamples {
+    float4 albedo = {0.f, 0.f, 0.f, 0.f}, normal = {0.f, 0.f, 0.f, 0.f}, rm = {0.f, 0.f, 0.f, 0.f};
+};
+template <bool FAST = false> __device__ __forceinline__ void sample_material_maps(const SceneView& S, const DevMat& m, float u, float v, MapSamples& out)
+{
+    if (m.bundle_w != 0) { // then all three maps exist
+        int x0, y0;
+        float fx, fy;
+        texel_position(m.bundle_w, m.bundle_h, u, v, x0, y0, fx, fy);
+        const uint4* e = S.bundles + 4 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
+        const uint4 fa = e[0], fn = e[1], fr = e[2]; // one 64-byte line
+        out.albedo = filter_footprint<FAST>(fa, fx, fy);
+        out.normal = filter_footprint<FAST>(fn, fx, fy);
+        out.rm = filter_footprint<FAST>(fr, fx, fy);
+        return;
+    }
+    if (m.tex[0] >= 0)
+        out.albedo = sample_texture<FAST>(S, m.tex[0], u, v);
+    if (m.tex[1] >= 0)
+        out.normal = sample_texture<FAST>(S, m.tex[1], u, v);
+    if (m.tex[2] >= 0)
+        out.rm = sample_texture<FAST>(S, m.tex[2], u, v);
+}
+
 __device__ __forceinline__ float3 load3(const float* p, uint32_t i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 __device__ __forceinline__ float3 xform_dir(const float* m, float3 p) // (p,0) * M, row-vector convention
 {
@@ -539,22 +566,12 @@ template <bool FAST = false> __device__ bool reconstruct_surface(const SceneView
     if (g.material < 0)
         return false; // :349
     const DevMat m = S.mats[g.material];
-    float4 t_albedo, t_normal, t_rm;
-    const bool bundled = m.bundle_w != 0; // then all three maps exist
-    if (bundled) {
-        int x0, y0;
-        float fx, fy;
-        texel_position(m.bundle_w, m.bundle_h, u, v, x0, y0, fx, fy);
-        const uint4* e = S.bundles + 4 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
-        const uint4 fa = e[0], fn = e[1], fr = e[2]; // one 64-byte line
-        t_albedo = filter_footprint<FAST>(fa, fx, fy);
-        t_normal = filter_footprint<FAST>(fn, fx, fy);
-        t_rm = filter_footprint<FAST>(fr, fx, fy);
-    }
+    MapSamples maps;
+    sample_material_maps<FAST>(S, m, u, v, maps);
     if (m.tex[0] < 0) {
         out.albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
     } else {
-        const float4 t = bundled ? t_albedo : sample_texture<FAST>(S, m.tex[0], u, v);
+        const float4 t = maps.albedo;
         out.albedo = f3(t.x, t.y, t.z);
     }
     if (m.tex[1] < 0) {
@@ -571,7 +588,7 @@ template <bool FAST = false> __device__ bool reconstruct_surface(const SceneView
             tg[k] = fdiv<FAST>(tg[k], l4);
         const float3 T = f3(tg[0], tg[1], tg[2]);
         const float3 B = normalize3<FAST>(cross3(out.GN, T) * tg[3]);
-        const float4 t = bundled ? t_normal : sample_texture<FAST>(S, m.tex[1], u, v);
+        const float4 t = maps.normal;
         const float3 N = f3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
         out.SN = normalize3<FAST>(T * N.x + B * N.y + out.GN * N.z); // mul(N, float3x3(T, B, GN))
     }
@@ -579,7 +596,7 @@ template <bool FAST = false> __device__ bool reconstruct_surface(const SceneView
         out.roughness = m.rough;
         out.metalness = m.metal;
     } else {
-        const float4 t = bundled ? t_rm : sample_texture<FAST>(S, m.tex[2], u, v);
+        const float4 t = maps.rm;
         out.roughness = t.y; // .g
         out.metalness = t.z; // .b
     }

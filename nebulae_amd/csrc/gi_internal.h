@@ -108,6 +108,7 @@ struct GiState {
     std::vector<float> h_tris; // 12 floats per triangle
     float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
     uint32_t n_tris = 0, n_nodes = 0, bvh_depth = 0;
+    size_t texture_table_bytes = 0; // footprint tables + material bundles on the device
     uint32_t max_bvh_depth = 21; // (kLdsStack + kSpillStack) / 3: deeper trees are refused by neb_gi_build_bvh ("gi_max_bvh_depth" lowers it)
     bool built = false;
     unsigned long long* d_ray_counter = nullptr;
@@ -116,6 +117,7 @@ struct GiState {
     float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
     unsigned long long last_stats[8] = {};
     bool defer_resolve = false;
+    bool exact_shade = false; // "gi_exact_shade": gi_shade_kernel<false>, the oracle's C arithmetic
     bool sort_shadow = true;  // "gi_sort_rays" bit 0
     bool sort_bounce = false; // "gi_sort_rays" bit 1
     uint32_t* d_sort = nullptr;      // 4 x npx uint32: keys, vals, keys_out, vals_out

@@ -88,6 +88,12 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_scene_info(self._ctx, C.byref(t), C.byref(n)), "neb_gi_scene_info")
         return t.value, n.value
 
+    def scene_bytes(self):
+        """device bytes of {texture tables, triangles + shading records, BVH nodes}"""
+        v = (C.c_uint64 * 3)()
+        self._check(self._lib.neb_gi_scene_bytes(self._ctx, v), "neb_gi_scene_bytes")
+        return dict(zip(("texture_tables", "triangles", "bvh_nodes"), [int(x) for x in v]))
+
     def bvh_depth(self):
         d = C.c_uint32()
         self._check(self._lib.neb_gi_bvh_depth(self._ctx, C.byref(d)), "neb_gi_bvh_depth")

@@ -9,8 +9,8 @@
   ``StaticMeshGeometryData`` / ``StaticMeshMaterialData`` (src/nri/GIProcessedScene.h:17-39).
 * ``cornell_standin`` / ``atrium_standin`` are procedural scenes.  The Sponza geometry blobs are
   stripped from the reference checkout (.MISSING_LARGE_BLOBS); ``atrium_standin`` matches the
-  statistics of assets/sponza/Sponza.gltf (103 submeshes, ~262 k triangles, 25 materials, node
-  scale 0.008, same world AABB) and every number measured on it is labelled "sponza-standin".
+  statistics of assets/sponza/Sponza.gltf (103 submeshes, ~262 k triangles, 25 materials with its
+  69-image texture topology at 1024^2, node scale 0.008, same world AABB) and every number measured on it is labelled "sponza-standin".
 """
 import ctypes as C
 import json
@@ -448,30 +448,40 @@ def _grid_surface(fn, nu, nv, uv_scale=(1.0, 1.0)):
 
 def _proc_texture(kind, seed, size=256):
     """Deterministic RGBA8 textures: 'albedo' (tinted value noise + grout lines), 'normal'
-    (tangent-space bumps), 'rm' (G = roughness, B = metalness)."""
+    (tangent-space bumps), 'rm' (G = roughness, B = metalness).  The height field is a sum of separable waves, so a
+    1024^2 map costs a few outer products (69 of them make the Sponza-sized bench scene)."""
     rng = np.random.default_rng(seed)
-    y, x = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
-    fx, fy = x / size * 2 * np.pi, y / size * 2 * np.pi
+    ax = (np.arange(size, dtype=np.float64) / size * 2 * np.pi)
     ph = rng.uniform(0, 2 * np.pi, 8)
     k = rng.integers(1, 7, 8)
-    h = (np.sin(k[0] * fx + ph[0]) * np.cos(k[1] * fy + ph[1]) + 0.5 * np.sin(k[2] * fx + k[3] * fy + ph[2])
-         + 0.25 * np.cos(k[4] * fx - k[5] * fy + ph[3]))
-    h = (h - h.min()) / (h.max() - h.min())
+    sx, cy = np.sin(k[0] * ax + ph[0]).astype(F), np.cos(k[1] * ax + ph[1]).astype(F)
+    s2, c2 = np.sin(k[2] * ax + ph[2]).astype(F), np.cos(k[2] * ax + ph[2]).astype(F)
+    s3, c3 = np.sin(k[3] * ax).astype(F), np.cos(k[3] * ax).astype(F)
+    c4, s4 = np.cos(k[4] * ax + ph[3]).astype(F), np.sin(k[4] * ax + ph[3]).astype(F)
+    c5, s5 = np.cos(k[5] * ax).astype(F), np.sin(k[5] * ax).astype(F)
+    # h[y, x] = sin(k0 x + p0) cos(k1 y + p1) + 0.5 sin(k2 x + k3 y + p2) + 0.25 cos(k4 x - k5 y + p3)
+    h = np.outer(cy, sx) + F(0.5) * (np.outer(c3, s2) + np.outer(s3, c2)) + F(0.25) * (np.outer(c5, c4) + np.outer(s5, s4))
+    lo, hi = float(h.min()), float(h.max())
+    h = (h - F(lo)) * F(1.0 / (hi - lo))
     out = np.zeros((size, size, 4), np.uint8)
     out[..., 3] = 255
     if kind == "albedo":
-        tint = rng.uniform(0.25, 0.95, 3)
-        grout = ((x % (size // 4) < 2) | (y % (size // 8) < 2)).astype(np.float64)
-        val = (0.55 + 0.45 * h) * (1.0 - 0.5 * grout)
-        out[..., :3] = np.clip(val[..., None] * tint * 255.0, 0, 255).astype(np.uint8)
+        tint = rng.uniform(0.25, 0.95, 3).astype(F)
+        i = np.arange(size)
+        gx, gy = (i % max(1, size // 4) < 2), (i % max(1, size // 8) < 2)
+        grout = (gx[None, :] | gy[:, None])
+        val = (F(0.55) + F(0.45) * h) * np.where(grout, F(0.5), F(1.0))
+        for c in range(3):
+            out[..., c] = np.clip(val * (tint[c] * F(255.0)), 0, 255).astype(np.uint8)
     elif kind == "normal":
-        gx = np.roll(h, -1, 1) - np.roll(h, 1, 1)
-        gy = np.roll(h, -1, 0) - np.roll(h, 1, 0)
-        n = np.stack([-gx * 6.0, -gy * 6.0, np.ones_like(h)], -1)
-        n /= np.linalg.norm(n, axis=-1, keepdims=True)
-        out[..., :3] = np.clip((n * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
+        gx = (np.roll(h, -1, 1) - np.roll(h, 1, 1)) * F(-6.0)
+        gy = (np.roll(h, -1, 0) - np.roll(h, 1, 0)) * F(-6.0)
+        inv = F(1.0) / np.sqrt(gx * gx + gy * gy + F(1.0))
+        out[..., 0] = np.clip((gx * inv * F(0.5) + F(0.5)) * F(255.0), 0, 255).astype(np.uint8)
+        out[..., 1] = np.clip((gy * inv * F(0.5) + F(0.5)) * F(255.0), 0, 255).astype(np.uint8)
+        out[..., 2] = np.clip((inv * F(0.5) + F(0.5)) * F(255.0), 0, 255).astype(np.uint8)
     else:
-        out[..., 1] = np.clip((0.35 + 0.6 * h) * 255.0, 0, 255).astype(np.uint8)
+        out[..., 1] = np.clip((F(0.35) + F(0.6) * h) * F(255.0), 0, 255).astype(np.uint8)
         out[..., 2] = 255 if seed % 7 == 0 else 0
     return out
 
@@ -510,7 +520,7 @@ def cornell_standin(textured=False):
     return sc
 
 
-def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex_size=256, seed=2025):
+def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex_size=1024, seed=2025):
     """'sponza-standin': a colonnaded two-storey atrium with arches, drapes and clutter, in Sponza's
     local units under the node scale 0.00800000038 and inside its local AABB
     (assets/sponza/Sponza.gltf accessor min/max: [-1921,-126,-1183] .. [1800,1429,1105])."""
@@ -520,15 +530,24 @@ def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex
     M = np.diag([S, S, S, 1.0]).astype(F)
     lo = np.array([-1920.9, -126.4, -1182.8])
     hi = np.array([1799.9, 1429.4, 1105.4])
-    mats = []
+    # Material / texture topology of assets/sponza/Sponza.gltf: 25 materials, 24 of them with all three maps, material 2
+    # with an albedo map only (the one 4x4 image); materials 14-16 and 17-19 each share one roughness-metalness map:
+    # 24 + 24 + 20 + 1 = 69 images (68 of them 1024^2 in the original; `tex_size` here).
+    mats, shared_rm = [], {}
     for m in range(n_materials):
-        tex = [-1, -1, -1]
-        if m % 5 != 4:  # most Sponza materials are fully textured; a few are factor-only
+        fac = dict(albedo=tuple(rng.uniform(0.2, 0.9, 3)) + (1.0,), rm=(float(rng.uniform(0.3, 1.0)), 0.0))
+        if m == 2:
+            tex = [sc.add_texture(_proc_texture("albedo", 100 + m, 4)), -1, -1]
+        else:
+            group = 14 if 14 <= m <= 16 else 17 if 17 <= m <= 19 else m
+            if group not in shared_rm:
+                shared_rm[group] = None
             tex = [sc.add_texture(_proc_texture("albedo", 100 + m, tex_size)),
-                   sc.add_texture(_proc_texture("normal", 200 + m, tex_size)),
-                   sc.add_texture(_proc_texture("rm", 300 + m, tex_size))]
-        mats.append(sc.add_material(albedo=tuple(rng.uniform(0.2, 0.9, 3)) + (1.0,), rm=(float(rng.uniform(0.3, 1.0)), 0.0),
-                                    textures=tex))
+                   sc.add_texture(_proc_texture("normal", 200 + m, tex_size)), -1]
+            if shared_rm[group] is None:
+                shared_rm[group] = sc.add_texture(_proc_texture("rm", 300 + m, tex_size))
+            tex[2] = shared_rm[group]
+        mats.append(sc.add_material(textures=tex, **fac))
     parts = []  # (P, N, UV, I) per submesh
 
     def plane(x0, x1, z0, z1, y, nu, nv, up=True, bump=0.0):
