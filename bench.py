@@ -4,18 +4,23 @@
 One "step" = one frame of the hot path on device-resident inputs, in the order of
 Renderer::RenderSceneDeferred (/root/reference/src/Renderer.cpp:123-133): radiance[cur] <- the
 direct-light term (device-to-device copy of the plane neb_pbr_direct produced once for the static
-view; stands in for the per-frame PBR pass that overwrites it), the GI dispatch (one-bounce indirect diffuse, adds into radiance[cur]), SVGF temporal
-accumulation and the a-trous wavelet levels.  Workload at N=1: BASELINE.json configs[2] --
-1920x1080, 1 spp, 5 a-trous levels on "sponza-standin" (the Sponza geometry blobs are stripped from
-the reference checkout; nebulae_amd/scene.py:atrium_standin matches Sponza.gltf's statistics).
+view; stands in for the per-frame PBR pass that overwrites it), the GI dispatch (one-bounce indirect
+diffuse, adds into radiance[cur]), SVGF temporal accumulation and the a-trous wavelet levels.
+Workload at N=1: BASELINE.json configs[2] -- 1920x1080, 1 spp, 5 a-trous levels on "sponza-standin"
+(the Sponza geometry blobs are stripped from the reference checkout; nebulae_amd/scene.py:atrium_standin
+matches Sponza.gltf's statistics: 103 submeshes, 262 k triangles, 25 materials, 69 textures of 1024^2).
 The G-buffer is produced once, outside the timed region, by neb_gbuffer_raycast (static camera).
 
-N > 1 (weak scaling): the frame grows with N -- rank r owns a 1080p-equivalent row strip of a
+N > 1 (`value`, weak scaling): the frame grows with N -- rank r owns a 1080p-equivalent row strip of a
 (1920*a) x (1080*b) image, a*b = N (N=4 is BASELINE.json configs[3], 3840x2160) -- and the strips
 exchange a-trous halo rows over RCCL (nebulae_amd/strips.py).  `value` is in 1080p-frame
-equivalents per second: N x (global frames/s).
+equivalents per second: N x (global frames/s).  Two more legs ride in the same JSON line for N > 1:
+  "strong_1080p_frames_per_s"  the metric's own curve: ONE 1920x1080 frame cut into N strips;
+  "config5"                    (N = 8, or --config5) BASELINE.json configs[4]: 3840x2160 in N strips, 4 spp, the camera
+                               orbiting for half the frames and still for the rest -- the reference's policy (SVGF
+                               skipped while moving, history reset on the first still frame) and "always-on".
 
-Prints ONE JSON line (rank 0) with "roofline" (dominant kernel = a-trous level, HBM bound,
+Prints ONE JSON line (rank 0) with "roofline" (dominant SVGF kernel = a-trous level, HBM bound,
 algorithmic 46 B/px/level) and "cpu_baseline" (the scalar C/C++ oracle on the host cores).
 """
 import argparse
@@ -30,6 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TEMPORAL_BYTES_PX = 82  # 60 B read + 22 B written
 ATROUS_BYTES_PX = 46    # per level: 30 B read + 16 B written
+GI_STREAM_BYTES_PX = 56  # 24 B G-buffer read + 32 B radiance read-modify-write
+PROFILE_ROUND = "r02"   # only PMC summaries of this round's kernels are quoted (profiles/r02*_*.json)
 
 
 def parse():
@@ -43,51 +50,60 @@ def parse():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--atrous-variant", type=int, default=1)
     ap.add_argument("--triangles", type=int, default=262267)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="SVGF frames of the CPU oracle to time (0 = skip the CPU leg)")
+    ap.add_argument("--tex-size", type=int, default=1024, help="edge of the stand-in's 68 large textures (Sponza: 1024)")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the CPU oracle to time (0 = skip the CPU leg)")
     ap.add_argument("--svgf-only", action="store_true", help="skip the GI dispatch (synthetic noisy radiance instead)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the loop with the final gather of all strips to rank 0 after every frame")
     ap.add_argument("--sort-rays", type=int, default=-1, help="GI ray sorting mask: bit 0 shadow rays, bit 1 bounce rays (-1 = library default)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the GI stages of frame f+1 on a side stream while frame f is denoised (measured: +1 %%, off by default)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg (one 1080p frame in N strips)")
+    ap.add_argument("--config5", action="store_true", help="also run BASELINE.json configs[4] (default: only when N = 8)")
+    ap.add_argument("--config5-frames", type=int, default=32, help="frames of the config-5 sequence (half moving, half still)")
     return ap.parse_args()
 
 
-def measured_traffic(width, height, levels):
-    """HBM bytes per a-trous launch from the newest committed PMC summary (tools/traffic_from_pmc.py): PMC counters need
-    their own rocprofv3 passes, so bench.py reports the value measured on this workload, or None if there is none."""
+def committed_profile(pattern):
+    """Newest committed profile summary of THIS round matching profiles/<round>*<pattern>, or None: PMC counters need their
+    own rocprofv3 passes (one counter group per pass), so bench.py quotes the committed summary of the same workload."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}*{pattern}"))):
         try:
-            d = json.load(open(f))
+            best = (json.load(open(f)), os.path.basename(f))
         except Exception:
             continue
-        if d.get("width") == width and d.get("height") == height:
-            per = [v["total"] for k, v in d["kernels"].items() if "svgf_atrous_lds_kernel" in k]
-            if len(per) == levels:
-                best = (sum(per) / len(per), os.path.basename(f))
     return best
+
+
+def measured_traffic(width, height, levels):
+    """HBM bytes per a-trous launch (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections, tools/traffic_from_pmc.py)."""
+    got = committed_profile("hbm_traffic.json")
+    if not got:
+        return None
+    d, name = got
+    if d.get("width") != width or d.get("height") != height:
+        return None
+    per = [v["total"] for k, v in d["kernels"].items() if "svgf_atrous" in k]
+    if len(per) != levels:
+        return None
+    return sum(per) / len(per), name
 
 
 def measured_valu(width, height, levels):
-    """f32 VALU occupancy of the a-trous launches from the newest committed SQ counter summary (profiles/*sq_counters.json):
-    {"lane_instructions_per_pixel", "issue_us_per_launch"} averaged over the levels, or None.  The kernel is bound by
-    vector-instruction issue, not by HBM; the HBM roofline above is the one the contract asks for."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        per = [v for k, v in d.get("kernels", {}).items() if "svgf_atrous_lds_kernel" in k]
-        if len(per) == levels:
-            insts = sum(v["SQ_INSTS_VALU"] for v in per) / len(per)
-            quad = sum(v["SQ_ACTIVE_INST_VALU"] for v in per) / len(per)
-            best = {"lane_instructions_per_pixel": insts * 64.0 / (width * height),
-                    "issue_us_per_launch": quad / 1024.0 * 4.0 / 2.4e3,  # quad-cycles per SIMD at the 2.4 GHz peak clock
-                    "source": os.path.basename(f)}
-    return best
+    """f32 VALU occupancy of the a-trous launches (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU), or None."""
+    got = committed_profile("sq_counters.json")
+    if not got:
+        return None
+    d, name = got
+    per = [v for k, v in d.get("kernels", {}).items() if "svgf_atrous" in k]
+    if len(per) != levels:
+        return None
+    insts = sum(v["SQ_INSTS_VALU"] for v in per) / len(per)
+    quad = sum(v["SQ_ACTIVE_INST_VALU"] for v in per) / len(per)
+    return {"lane_instructions_per_pixel": insts * 64.0 / (width * height),
+            "issue_us_per_launch": quad / 1024.0 * 4.0 / 2.4e3,  # quad-cycles per SIMD at the 2.4 GHz peak clock
+            "source": name}
 
 
 def host_cores():
@@ -96,20 +112,26 @@ def host_cores():
 
 
 def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
-    """Times the oracle (kind "port": oracle/svgf_ref.c + oracle/trace_ref.cpp) on the host cores."""
+    """Times the oracle (kind "port": oracle/svgf_ref.c + oracle/trace_ref.cpp) on the host cores: all of this job's cores
+    (whole frames, median) and ONE thread (a 128-row band of the same frame, scaled to the frame -- a scalar 1080p frame
+    takes about a minute)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
     import numpy as np
-    from oracle_lib import OracleSVGF, OracleTracer
+    from oracle_lib import OracleSVGF, OracleTracer, SvgfParams, lib
     cores = host_cores()
-    t_gi, rays = 0.0, 0
+    med = lambda v: float(np.median(v))  # noqa: E731
+    # ---- all cores: `frames` GI frames + `frames` SVGF frames, median of each ----
+    t_gi, rays = [], 0
     if do_gi:
         tr = OracleTracer(scene, threads=cores)
-        t0 = time.perf_counter()
-        noisy, _, rays = tr.gi(gb, consts, radiance=np.zeros((H, W, 4), np.float32), want_hits=False)
-        t_gi = time.perf_counter() - t0
-        tr.close()
+        for _ in range(frames):
+            t0 = time.perf_counter()
+            noisy, _, rays = tr.gi(gb, consts, radiance=np.zeros((H, W, 4), np.float32), want_hits=False)
+            t_gi.append(time.perf_counter() - t0)
     o = OracleSVGF(W, H, L, threads=cores)
-    times = []
+    t_svgf = []
     for f in range(1, frames + 2):  # frame 1 (all-history, quirk 2) is warm-up
         o.begin_frame(f)
         c = o.cur
@@ -120,15 +142,197 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
         o.temporal_pass()
         o.atrous_pass()
         if f > 1:
-            times.append(time.perf_counter() - t0)
+            t_svgf.append(time.perf_counter() - t0)
+    dt_all = (med(t_gi) if do_gi else 0.0) + med(t_svgf)
+    # ---- one thread: rows [b0, b1) of the same frame ----
+    b0 = max(0, (H // 2 - 64) // 8 * 8)
+    b1 = min(H, b0 + 128)
+    scale = H / float(b1 - b0)
+    t1_gi = 0.0
+    if do_gi:
+        tr1 = OracleTracer(scene, threads=1)
+        t0 = time.perf_counter()
+        tr1.gi(gb, consts, radiance=np.zeros((H, W, 4), np.float32), rows=(b0, b1), want_hits=False)
+        t1_gi = time.perf_counter() - t0
+        tr1.close()
+        tr.close()
+    Lb = lib()
+    Lb.svgf_ref_temporal.argtypes = [C.c_int] * 4 + [C.c_void_p] * 9 + [C.POINTER(SvgfParams)]
+    Lb.svgf_ref_atrous.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_int, C.POINTER(SvgfParams)]
+    prm = SvgfParams(0.002, 0.9, 1e-4, 4.0 / 255.0, 128.0, 0.002)
+    c, h = o.cur, o.hist
+    src, dst = o.radiance[c].copy(), np.zeros((H, W, 4), np.float32)
+    t0 = time.perf_counter()
+    Lb.svgf_ref_temporal(W, H, b0, b1, src.ctypes.data, o.radiance[h].ctypes.data, o.depth[c].ctypes.data, o.depth[h].ctypes.data,
+                         o.normal[c].ctypes.data, o.normal[h].ctypes.data, o.moments[h].ctypes.data, o.moments[c].ctypes.data,
+                         o.variance.ctypes.data, C.byref(prm))
+    for lvl in range(L):
+        Lb.svgf_ref_atrous(W, H, b0, b1, src.ctypes.data, dst.ctypes.data, o.variance.ctypes.data, o.depth[c].ctypes.data,
+                           o.normal[c].ctypes.data, 1 << lvl, C.byref(prm))
+    t1_svgf = time.perf_counter() - t0
     o.close()
-    t_svgf = sum(times) / len(times)
-    dt = t_gi + t_svgf
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "gi_mrays_per_s": (rays / t_gi / 1e6) if do_gi else None,
-            "sample": (f"1 full {W}x{H} GI frame ({rays} rays, {t_gi * 1e3:.0f} ms) of oracle/trace_ref.cpp + " if do_gi else "")
-                      + f"{len(times)} full {W}x{H} SVGF frames (temporal + {L} a-trous levels, mean {t_svgf * 1e3:.0f} ms) of "
-                        f"oracle/svgf_ref.c; OpenMP row-parallel on {cores} threads"}
+    dt_one = (t1_gi + t1_svgf) * scale
+    return {"value": 1.0 / dt_all, "unit": "frames/s", "cores": cores, "kind": "port",
+            "gi_mrays_per_s": (rays / med(t_gi) / 1e6) if do_gi else None,
+            "sample": (f"median of {frames} full {W}x{H} GI frames ({rays} rays, {med(t_gi) * 1e3:.0f} ms) of oracle/trace_ref.cpp + " if do_gi else "")
+                      + f"median of {len(t_svgf)} full {W}x{H} SVGF frames (temporal + {L} a-trous levels, {med(t_svgf) * 1e3:.0f} ms) of "
+                        f"oracle/svgf_ref.c; OpenMP row-parallel on {cores} threads",
+            "single_thread": {"value": 1.0 / dt_one, "unit": "frames/s", "cores": 1,
+                              "sample": f"rows [{b0},{b1}) of the same {W}x{H} frame on one thread (GI {t1_gi:.1f} s + SVGF {t1_svgf:.1f} s), "
+                                        f"scaled by {scale:.2f} to the whole frame"}}
+
+
+class Workload:
+    """One strip renderer of a GW x GH frame cut into `world` row strips, its static G-buffer and direct-light term."""
+
+    def __init__(self, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True):
+        import torch
+        from nebulae_amd import strips, synth
+        from nebulae_amd.renderer import RenderInfo
+        from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE
+        self.torch, self.RenderInfo = torch, RenderInfo
+        self.args, self.GW, self.GH, self.L, self.sc, self.cam, self.rank, self.world, self.do_gi = args, GW, GH, L, sc, cam, rank, world, do_gi
+        self.part = strips.StripPartition(GW, GH, world, L)
+        self.r = r = strips.StripRenderer(self.part, rank, device=local_rank, group=group)
+        r.svgf.set_option("atrous_variant", args.atrous_variant)
+        r.gi_ui.gi_samples_per_pixel = spp
+        self.own = self.part.owned(rank)
+        self.res = self.part.resident(rank)
+        self.stream = torch.cuda.current_stream()
+        self.sh = self.stream.cuda_stream
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=self.sh))
+        r.submit_commands_gbuffer()          # G-buffer of this rank's resident rows, slot "current" of frame 1
+        torch.cuda.synchronize()
+        for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: the other slot holds the same G-buffer
+            r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
+        self.rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
+        if args.sort_rays >= 0:
+            r.svgf.set_option("gi_sort_rays", args.sort_rays)
+        r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
+        torch.cuda.synchronize()
+        self.direct = self.rad_view[r.svgf.get_current_resource_index()].clone()
+        self.noisy_dev = None
+        if do_gi:
+            r.ray_count(reset=True)
+        else:
+            g = synth.synth_gbuffer(GW, GH)
+            self.noisy_dev = [torch.from_numpy(synth.synth_radiance(g["base"][self.res[0]:self.res[1]], f + 1)).cuda() for f in range(4)]
+        self.frame = 1
+        self.ran_svgf = []
+        # Optional frames in flight (the reference keeps 3, src/nri/Swapchain.h:15): the GI stages of frame f+1 touch only
+        # the G-buffer and the GI records, so they can run on a side stream while frame f is resolved and denoised on the
+        # main stream; the two meet at neb_gi_resolve (the reference's separate nrc Resolve step, DeferredRenderer.cpp:586).
+        # Measured on MI355X: +1 % (the GI kernels already occupy every wave slot), so it is off by default.
+        self.overlap = do_gi and args.overlap
+        self.side = torch.cuda.Stream() if self.overlap else None
+        self.resolved = None
+        if self.overlap:
+            r.set_defer_resolve(True)
+
+    def step(self, timed_events=None, cam=None, regen_gbuffer=False):
+        torch, r, stream = self.torch, self.r, self.stream
+        self.frame += 1
+        f = self.frame
+        r.begin_frame(self.RenderInfo(scene=self.sc, camera=cam or self.cam, frame_index=f, stream=self.sh))
+        cur = r.svgf.get_current_resource_index()
+        if regen_gbuffer:  # a camera that moved: the raster pass re-renders the G-buffer and the PBR pass its direct term
+            r.submit_commands_gbuffer()
+            r.submit_commands_pbr_lighting()
+            self.direct.copy_(self.rad_view[cur], non_blocking=True)  # (kept for the still frames that follow)
+        pipelined = self.overlap and timed_events is None
+        gi_stream = self.side if pipelined else stream
+        if not self.overlap and not regen_gbuffer:  # PBR pass stand-in (overwrites radiance[cur]); the GI dispatch then adds into it
+            self.rad_view[cur].copy_(self.direct if self.do_gi else self.noisy_dev[f % 4], non_blocking=True)
+        if timed_events is not None:
+            timed_events["gi0"].record(stream)
+        if self.do_gi:
+            if pipelined and self.resolved is not None:
+                self.side.wait_event(self.resolved)  # the previous frame's resolve has consumed the GI records
+            r.submit_commands_gi_pathtrace(stream=gi_stream.cuda_stream)
+        if timed_events is not None:
+            timed_events["gi1"].record(stream)
+        if self.overlap:
+            self.rad_view[cur].copy_(self.direct, non_blocking=True)
+            if pipelined:
+                done = torch.cuda.Event()
+                done.record(self.side)
+                stream.wait_event(done)
+            r.submit_commands_gi_resolve()
+            if pipelined:
+                self.resolved = torch.cuda.Event()
+                self.resolved.record(stream)
+        self.ran_svgf.append(r.submit_commands_svgf_denoising(timed_events))
+        r.end_frame()
+
+    def barrier(self):
+        import torch.distributed as dist
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce_max_sum(self, dt, rays):
+        """-> (max over ranks of dt, sum over ranks of rays)"""
+        import torch.distributed as dist
+        torch = self.torch
+        if self.world == 1:
+            return dt, float(rays)
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        mx = torch.tensor([dt], dtype=torch.float64, device=dev)
+        sm = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        return float(mx[0].item()), float(sm[0].item())
+
+    def timed(self, steps, warmup, step_fn=None):
+        """warm-up, barrier, EXACTLY `steps` steps, barrier -> (seconds: max over ranks, rays: sum over ranks)"""
+        step_fn = step_fn or (lambda k: self.step())
+        for k in range(warmup):
+            step_fn(k - warmup)
+        self.barrier()
+        del self.ran_svgf[:]
+        if self.do_gi:
+            self.r.ray_count(reset=True)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step_fn(k)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        rays = self.r.ray_count(reset=True) if self.do_gi else 0
+        return self.reduce_max_sum(dt, rays)
+
+    def destroy(self):
+        self.r.destroy()
+
+
+def run_config5(args, sc, rank, world, local_rank, group):
+    """BASELINE.json configs[4]: 3840x2160 in `world` strips, 4 spp, 5 levels; the camera orbits
+    (yaw += 0.5 deg per frame) for the first half of the sequence and stands still for the second.  Two runs: the
+    reference's policy (SVGF skipped while moving, history reset on the first still frame) and always-on (beyond the
+    reference: the temporal pass runs every frame, no reprojection)."""
+    from nebulae_amd import scene as S
+    n = max(2, args.config5_frames)
+    half = n // 2
+
+    def cam_at(k):
+        return S.orbit_camera(origin=(0.0, 2.0, 0.0), yaw_deg=12.0 + 0.5 * min(k + 1, half), pitch_deg=60.0, distance=9.0)
+    out = {"workload": f"sponza-standin 3840x2160, 4 spp one-bounce GI + SVGF temporal + 5 a-trous levels, {world} row strips of {2160 // world} rows, "
+                       f"{half} frames with the camera orbiting (yaw += 0.5 deg per frame; G-buffer and direct term re-rendered) then {n - half} still frames"}
+    for mode in ("reference_policy", "always_on"):
+        w = Workload(args, 3840, 2160, 5, 4, sc, cam_at(-1), rank, world, local_rank, group)
+        w.r.denoise_while_moving = mode == "always_on"
+        w.step()  # one still frame first, so that the sequence starts from a settled state
+        w.step()
+
+        def fn(k, w=w):
+            # the G-buffer slot of the first still frame (k == half) still holds an older view: it is rendered once more
+            w.step(cam=cam_at(k) if k >= 0 else None, regen_gbuffer=0 <= k <= half)
+        dt, rays = w.timed(n, 0, fn)
+        denoised = sum(1 for x in w.ran_svgf if x)
+        out[mode] = {"frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3, "mrays_per_s": rays / dt / 1e6, "frames": n,
+                     "frames_denoised": denoised}
+        w.destroy()
+    return out
 
 
 def main():
@@ -150,136 +354,39 @@ def main():
     if world > 1:
         backend = os.environ.get("NEB_BENCH_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+    group = dist.group.WORLD if world > 1 else None
 
     from nebulae_amd import scene as S
-    from nebulae_amd import strips, synth
-    from nebulae_amd.renderer import RenderInfo
-    from nebulae_amd.svgf import PLANE_ALBEDO, PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE, PLANE_ROUGH_METAL, PLANE_WORLDPOS
+    from nebulae_amd import strips
+    from nebulae_amd.svgf import PLANE_ALBEDO, PLANE_DEPTH, PLANE_NORMAL, PLANE_ROUGH_METAL, PLANE_WORLDPOS
 
     L = args.levels
+    do_gi = not args.svgf_only
     # weak scaling: the global frame is (W*a) x (H*b) with a*b = world; every rank owns W*H pixels of it
     a, b = strips.frame_factors(world)
     GW, GH = args.width * a, args.height * b
-    part = strips.StripPartition(GW, GH, world, L)
-    r = strips.StripRenderer(part, rank, device=local_rank, group=dist.group.WORLD if world > 1 else None)
-    r.svgf.set_option("atrous_variant", args.atrous_variant)
-    r.gi_ui.gi_samples_per_pixel = args.spp
-    own0, own1 = part.owned(rank)
-    res0, res1 = part.resident(rank)
-
-    stream = torch.cuda.current_stream()
-    sh = stream.cuda_stream
-    do_gi = not args.svgf_only
-    sc = S.atrium_standin(target_triangles=args.triangles)
+    sc = S.atrium_standin(target_triangles=args.triangles, tex_size=args.tex_size)
     cam = S.sponza_camera()
-    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=sh))
-    r.submit_commands_gbuffer()          # G-buffer of this rank's resident rows, slot "current" of frame 1
-    torch.cuda.synchronize()
-    for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: the other slot holds the same G-buffer
-        r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
-    rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
-    if args.sort_rays >= 0:
-        r.svgf.set_option("gi_sort_rays", args.sort_rays)
-    r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
-    torch.cuda.synchronize()
-    direct = rad_view[r.svgf.get_current_resource_index()].clone()
-    if do_gi:
-        r.ray_count(reset=True)
-    noisy_dev = None
-    if not do_gi:
-        g = synth.synth_gbuffer(GW, GH)
-        noisy_dev = [torch.from_numpy(synth.synth_radiance(g["base"][res0:res1], f + 1)).cuda() for f in range(4)]
-    frame = [1]
-    ran_svgf = []
-    # Optional frames in flight (the reference keeps 3, src/nri/Swapchain.h:15): the GI stages of frame f+1 touch only
-    # the G-buffer and the GI records, so they can run on a side stream while frame f is resolved and denoised on the
-    # main stream; the two meet at neb_gi_resolve (the reference's separate nrc Resolve step, DeferredRenderer.cpp:586).
-    # Measured on MI355X: +1 % (the GI kernels already occupy every wave slot), so it is off by default.
-    overlap = do_gi and args.overlap
-    side = torch.cuda.Stream() if overlap else None
-    resolved = [None]
-    if overlap:
-        r.set_defer_resolve(True)
+    w = Workload(args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi)
+    r, part = w.r, w.part
+    scene_bytes = r.scene_bytes() if do_gi else None
+    bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth()} if do_gi else None
 
-    def step(timed_events=None):
-        frame[0] += 1
-        f = frame[0]
-        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=sh))
-        cur = r.svgf.get_current_resource_index()
-        pipelined = overlap and timed_events is None
-        gi_stream = side if pipelined else stream
-        if not overlap:  # PBR pass stand-in (overwrites radiance[cur]); the fused GI dispatch then adds into it
-            rad_view[cur].copy_(direct if do_gi else noisy_dev[f % 4], non_blocking=True)
-        if timed_events is not None:
-            timed_events["gi0"].record(stream)
-        if do_gi:
-            if pipelined and resolved[0] is not None:
-                side.wait_event(resolved[0])  # the previous frame's resolve has consumed the GI records
-            r.submit_commands_gi_pathtrace(stream=gi_stream.cuda_stream)
-        if timed_events is not None:
-            timed_events["gi1"].record(stream)
-        if overlap:
-            rad_view[cur].copy_(direct, non_blocking=True)
-        if overlap:
-            if pipelined:
-                done = torch.cuda.Event()
-                done.record(side)
-                stream.wait_event(done)
-            r.submit_commands_gi_resolve()
-            if pipelined:
-                resolved[0] = torch.cuda.Event()
-                resolved[0].record(stream)
-        ran_svgf.append(r.submit_commands_svgf_denoising(timed_events))
-        r.end_frame()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 2)):  # >= 2: frame 2 is "camera moved", frame 3 resets history
-        step()
-    barrier()
-    del ran_svgf[:]
-    if do_gi:
-        r.ray_count(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    rays_timed = r.ray_count(reset=True) if do_gi else 0
-    assert all(ran_svgf), "SVGF was skipped inside the timed region"
-    stats = torch.tensor([dt, float(rays_timed)], dtype=torch.float64,
-                         device="cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu")
-    if world > 1:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        dt, rays_total = float(mx[0].item()), float(stats[1].item())
-    else:
-        rays_total = float(rays_timed)
+    dt, rays_total = w.timed(args.steps, max(args.warmup, 2))  # >= 2 warm-ups: frame 2 is "camera moved", frame 3 resets history
+    assert all(w.ran_svgf), "SVGF was skipped inside the timed region"
 
     # ---- optional: the same loop with SURVEY.md 8e's final gather of the strips to rank 0 after every frame ----
     fps_with_gather = None
     if args.gather and world > 1:
-        barrier()
-        tg = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            r.gather_frame(dst=0)
-        barrier()
-        dtg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=stats.device)
-        dist.all_reduce(dtg, op=dist.ReduceOp.MAX)
-        fps_with_gather = args.steps / float(dtg[0].item()) * world
+        dtg, _ = w.timed(args.steps, 0, lambda k: (w.step(), r.gather_frame(dst=0)))
+        fps_with_gather = args.steps / dtg * world
 
     # ---- per-kernel durations: HIP events on the launch stream, 8 extra frames ----
     ev = []
     for _ in range(8):
         e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1")}
         e["levels"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
-        step(e)
+        w.step(e)
         ev.append(e)
     torch.cuda.synchronize()
     rays_ev = r.ray_count(reset=True) if do_gi else 0
@@ -289,52 +396,83 @@ def main():
     # (with N > 1 the first level's interval also holds the halo exchange it overlaps with, and every level but the last
     # filters a few extra rows: the roofline line is then taken over the levels after the first)
     t_atrous = float(np.mean(per_level if (world == 1 or L == 1) else per_level[1:]))
+    own_px = (w.own[1] - w.own[0]) * GW                      # pixels a rank owns (= one 1080p frame)
+    gb = noisy = consts = None
+    if rank == 0 and args.cpu_frames > 0 and world == 1:
+        gb = {"albedo": r.svgf.download(PLANE_ALBEDO, 0), "rough_metal": r.svgf.download(PLANE_ROUGH_METAL, 0),
+              "world_pos": r.svgf.download(PLANE_WORLDPOS, 0), "normal": r.svgf.download(PLANE_NORMAL, 0),
+              "depth": r.svgf.download(PLANE_DEPTH, 0)}
+        noisy = w.noisy_dev[0].cpu().numpy() if not do_gi else None
+        consts = r.global_constants()
+    exchanged = part.exchanged_bytes_per_frame()
+    scheme = part.scheme
+    w.destroy()
+
+    # ---- N > 1: the metric's own curve (strong scaling of ONE 1080p frame) and BASELINE.json configs[4] ----
+    strong = None
+    if world > 1 and not args.no_strong and do_gi:
+        ws = Workload(args, args.width, args.height, L, args.spp, sc, cam, rank, world, local_rank, group)
+        dts, rays_s = ws.timed(args.steps, max(args.warmup, 2))
+        strong = {"frames_per_s": args.steps / dts, "ms_per_frame": dts / args.steps * 1e3, "mrays_per_s": rays_s / dts / 1e6,
+                  "rows_per_strip": args.height // world, "halo_rows": ws.part.halo}
+        ws.destroy()
+    config5 = None
+    if do_gi and (args.config5 or world == 8):
+        config5 = run_config5(args, sc, rank, world, local_rank, group)
 
     if rank == 0:
-        own_px = (own1 - own0) * GW                       # pixels a rank owns (= one 1080p frame)
         fps_equiv = args.steps / dt * world               # 1080p-frame equivalents per second, whole job
         achieved = ATROUS_BYTES_PX * own_px / t_atrous / 1e9
         traffic = measured_traffic(GW, GH, L) if world == 1 else None
         valu = measured_valu(GW, GH, L) if world == 1 else None
         if valu:
             valu["busy_frac"] = valu["issue_us_per_launch"] / (sum(per_level) / len(per_level) * 1e6)
+        t_svgf = t_temporal + sum(per_level)
+        svgf_bytes = (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L) * own_px
+        frame_gbps = svgf_bytes * world * (args.steps / dt) / 1e9
         out = {
             "metric": "denoised frames/s (1920x1080-frame equivalents: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
                       "denoised frames/s (1920x1080-frame equivalents: SVGF temporal + a-trous only)",
             "value": fps_equiv, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"sponza-standin {GW}x{GH} ({sc.num_triangles} triangles, {len(sc.geometries)} submeshes), "
+            "config": {"workload": f"sponza-standin {GW}x{GH} ({sc.num_triangles} triangles, {len(sc.geometries)} submeshes, {len(sc.materials)} materials, "
+                                   f"{len(sc.textures)} textures of {args.tex_size}^2), "
                                    f"{args.spp} spp one-bounce GI + SVGF temporal + {L} a-trous levels"
                                    + ("" if do_gi else " [GI skipped: --svgf-only]"),
                        "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
-                       "parallelism": (f"row-strips x{world} + RCCL halo exchange ({'one per frame' if part.scheme == 'once' else 'one per a-trous level'}, "
-                                       f"{part.exchanged_bytes_per_frame() / 1e6:.1f} MB sent per rank and frame)") if world > 1 else "single GPU",
-                       "frames_in_flight": 2 if overlap else 1},
+                       "parallelism": (f"row-strips x{world} + RCCL halo exchange ({'one per frame' if scheme == 'once' else 'one per a-trous level'}, "
+                                       f"{exchanged / 1e6:.1f} MB sent per rank and frame)") if world > 1 else "single GPU",
+                       "frames_in_flight": 2 if (do_gi and args.overlap) else 1,
+                       "scene_device_bytes": scene_bytes, "bvh": bvh},
             "frames_per_s_with_final_gather": fps_with_gather,
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
             "gi_kernel_mrays_per_s": (rays_ev / 8 / t_gi / 1e6) if do_gi else None,
-            "frame_algorithmic_GBps": (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L) * own_px * world * (args.steps / dt) / 1e9,
+            "strong_1080p_frames_per_s": strong["frames_per_s"] if strong else (fps_equiv if world == 1 else None),
+            "strong_1080p": strong,
+            "config5": config5,
             "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": t_temporal * 1e6, "atrous_levels": [t * 1e6 for t in per_level]},
             "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
-                         "valu": valu},
-            "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS,
-                                  "unit": "GB/s"},
+                         # the contract prices this kernel against HBM; what limits it in fact is vector-instruction issue
+                         "limiter": "valu-issue" if (valu and valu["busy_frac"] > 0.6) else None, "valu": valu},
+            "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9 / HBM_PEAK_GBPS},
+            # the same byte model over longer intervals: all of SVGF (temporal + L levels, kernel time), and the whole frame
+            # (GI included in the time, SVGF's algorithmic bytes only -- the GI stage is not HBM-priced)
+            "svgf_roofline": {"achieved": svgf_bytes / t_svgf / 1e9, "frac": svgf_bytes / t_svgf / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s"},
+            "frame_roofline": {"achieved": frame_gbps, "frac": frame_gbps / HBM_PEAK_GBPS, "unit": "GB/s",
+                               "note": "SVGF algorithmic bytes / whole-frame time (GI included)"},
+            "frame_algorithmic_GBps": frame_gbps,
         }
-        if args.cpu_frames > 0 and world == 1:
-            gb = {"albedo": r.svgf.download(PLANE_ALBEDO, 0), "rough_metal": r.svgf.download(PLANE_ROUGH_METAL, 0),
-                  "world_pos": r.svgf.download(PLANE_WORLDPOS, 0), "normal": r.svgf.download(PLANE_NORMAL, 0),
-                  "depth": r.svgf.download(PLANE_DEPTH, 0)}
-            noisy = noisy_dev[0].cpu().numpy() if not do_gi else None
-            out["cpu_baseline"] = cpu_baseline(GW, GH, L, args.cpu_frames, gb, r.global_constants(), sc, noisy, do_gi)
+        if gb is not None:
+            out["cpu_baseline"] = cpu_baseline(GW, GH, L, args.cpu_frames, gb, consts, sc, noisy, do_gi)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    r.destroy()
 
 
 if __name__ == "__main__":

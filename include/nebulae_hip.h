@@ -86,6 +86,13 @@ int neb_destroy(neb_ctx* ctx);
 const char* neb_last_error(const neb_ctx* ctx); /* ctx may be NULL: last creation error */
 const char* neb_version(void);
 
+/* ---- profiler ranges: NEB_PIX_SCOPED_EVENT (src/nri/PIXRuntime.h:115-117) becomes a roctx range.  Every submit call below
+ * brackets itself with the reference's event name ("SVGF: Temporal Accumulation", "SVGF: A-Trous compute i (step s)", ...);
+ * these two let the host add its own enclosing ranges ("SVGF Denoising", DeferredRenderer.cpp:599).  No-ops without a
+ * ROCm marker library; rocprofv3 --marker-trace records them. ---- */
+int neb_marker_push(const char* name);
+int neb_marker_pop(void);
+
 /* ---- per-frame bracket: SVGFDenoiser::BeginFrame/EndFrame (SVGFDenoiser.cpp:39-47) ---- */
 int neb_begin_frame(neb_ctx* ctx, uint32_t frame_index); /* cur = f & 1, hist = cur ^ 1 */
 int neb_end_frame(neb_ctx* ctx);

@@ -34,6 +34,8 @@ _SIGS = {
     "neb_destroy": (C.c_int, [C.c_void_p]),
     "neb_last_error": (C.c_char_p, [C.c_void_p]),
     "neb_version": (C.c_char_p, []),
+    "neb_marker_push": (C.c_int, [C.c_char_p]),
+    "neb_marker_pop": (C.c_int, []),
     "neb_begin_frame": (C.c_int, [C.c_void_p, C.c_uint32]),
     "neb_end_frame": (C.c_int, [C.c_void_p]),
     "neb_current_index": (C.c_int, [C.c_void_p]),

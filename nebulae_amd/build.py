@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     extra = os.environ.get("NEB_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds only (e.g. -DNEB_SORT_BITS=16)
-    cmd = [_hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    cmd = [_hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

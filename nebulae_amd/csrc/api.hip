@@ -1,6 +1,9 @@
 // api.hip -- the C ABI of libnebulae_hip.so (include/nebulae_hip.h): context, planes, SVGF frame logic.
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "neb_internal.h"
@@ -18,6 +21,41 @@ const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT] = {
     {8, 1},  // WORLDPOS     R16G16B16A16_FLOAT
     {4, 1},  // LDR          R8G8B8A8_UNORM
 };
+} // namespace neb
+
+namespace neb {
+namespace {
+using PushFn = int (*)(const char*);
+using PopFn = int (*)();
+PushFn g_range_push = nullptr;
+PopFn g_range_pop = nullptr;
+std::once_flag g_range_once;
+void resolve_markers()
+{
+    for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            continue;
+        g_range_push = reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+        g_range_pop = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
+        if (g_range_push && g_range_pop)
+            return;
+        g_range_push = nullptr;
+        g_range_pop = nullptr;
+    }
+}
+} // namespace
+void marker_push(const char* name)
+{
+    std::call_once(g_range_once, resolve_markers);
+    if (g_range_push)
+        (void)g_range_push(name);
+}
+void marker_pop()
+{
+    if (g_range_pop)
+        (void)g_range_pop();
+}
 } // namespace neb
 
 using namespace neb;
@@ -155,6 +193,20 @@ int neb_destroy(neb_ctx* ctx)
     free_planes(ctx);
     gi_destroy(ctx->gi);
     delete ctx;
+    return NEB_OK;
+}
+
+int neb_marker_push(const char* name)
+{
+    if (!name)
+        return NEB_ERR_INVALID_ARG;
+    marker_push(name);
+    return NEB_OK;
+}
+
+int neb_marker_pop(void)
+{
+    marker_pop();
     return NEB_OK;
 }
 
@@ -345,6 +397,7 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
         return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_temporal_rows: rows not resident");
     const int c = ctx->cur, h = ctx->hist;
     NEB_GUARD(ctx);
+    ScopedRange range("SVGF: Temporal Accumulation"); // SVGFDenoiser.cpp:69
     hipError_t e = launch_temporal(make_launch(ctx, row0, row1), (float4*)ctx->planes[NEB_PLANE_RADIANCE][c],
                                    (const float4*)ctx->planes[NEB_PLANE_RADIANCE][h],
                                    (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][c],
@@ -427,6 +480,9 @@ int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint
     int sp, ss, dp, ds;
     chain_link(ctx, level, &sp, &ss, &dp, &ds);
     NEB_GUARD(ctx);
+    char range_name[64];
+    snprintf(range_name, sizeof(range_name), "SVGF: A-Trous compute %u (step %u)", level, step); // SVGFDenoiser.cpp:155
+    ScopedRange range(range_name);
     hipError_t e = launch_atrous(make_launch(ctx, row0, row1), ctx->atrous_variant, step,
                                  (const float4*)ctx->planes[sp][ss], (float4*)ctx->planes[dp][ds],
                                  (const uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0],
@@ -443,6 +499,7 @@ int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream)
         return NEB_ERR_INVALID_ARG;
     if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
         return fail(ctx, NEB_ERR_STATE, "neb_svgf_atrous: context holds a row strip; use neb_svgf_atrous_level_rows");
+    ScopedRange range("SVGF: A-Trous Wavelet"); // SVGFDenoiser.cpp:136
     for (uint32_t i = 0; i < ctx->levels; ++i) {
         int rc = neb_svgf_atrous_level_rows(ctx, i, 0, ctx->H, stream);
         if (rc != NEB_OK)

@@ -593,6 +593,7 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     if (row0 == row1)
         return NEB_OK;
     GI_GUARD(ctx);
+    ScopedRange range("GI: Query Pass"); // "GI: NRC Query Pass", DeferredRenderer.cpp:434 (the NRC calls are stubbed here)
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     if (g->debug_hits && !g->d_hits) {
         void* p = nullptr;
@@ -727,6 +728,7 @@ int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
     if (g->pending_row1 <= g->pending_row0)
         return NEB_OK;
     GI_GUARD(ctx);
+    ScopedRange range("GI: Resolve query data"); // "GI: Resolve NRC query data", DeferredRenderer.cpp:567
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     const size_t first = (size_t)(g->pending_row0 - ctx->row_begin) * ctx->W, n = (size_t)(g->pending_row1 - g->pending_row0) * ctx->W;
     hipLaunchKernelGGL(gi_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -743,6 +745,7 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_pbr_direct: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
     GI_GUARD(ctx);
+    ScopedRange range("PBR Direct Lighting + Shadows"); // DeferredRenderer.cpp:338
     GiArgs a{};
     a.S = g->view;
     a.c = *c;
@@ -852,6 +855,7 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gbuffer_raycast: scene/BVH not ready");
     GI_GUARD(ctx);
+    ScopedRange range("Deferred G-Buffers (geometry)"); // DeferredRenderer.cpp:267
     auto norm = [](float* v) {
         const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         v[0] /= l;

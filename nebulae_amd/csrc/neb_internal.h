@@ -37,6 +37,18 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// Per-pass profiler ranges with the reference's PIX event names (NEB_PIX_SCOPED_EVENT, src/nri/PIXRuntime.h:115-117;
+// uses at src/DeferredRenderer.cpp:267,338,434,567,599 and src/SVGFDenoiser.cpp:69,136,155): roctx ranges, resolved at
+// run time from the ROCm profiler's marker library (no-ops when it is absent); rocprofv3 --marker-trace shows them.
+void marker_push(const char* name);
+void marker_pop();
+struct ScopedRange {
+    explicit ScopedRange(const char* name) { marker_push(name); }
+    ~ScopedRange() { marker_pop(); }
+    ScopedRange(const ScopedRange&) = delete;
+    ScopedRange& operator=(const ScopedRange&) = delete;
+};
+
 struct SvgfLaunch {
     int device;            // HIP device ordinal of the context (per-device kernel attributes)
     uint32_t W, H;         // full image size (global clamp uses these)

@@ -168,11 +168,15 @@ class DeferredRenderer:
     def submit_commands_svgf_denoising(self):
         if self.dynamic_scene_this_frame and not self.denoise_while_moving:  # :595
             return False
-        if self.reset_history:
-            self.reset_history = False
-            self.svgf.reset_history(self.info.stream)
-        self.svgf.submit_temporal_accumulation(self.info.stream)
-        self.svgf.submit_atrous_compute_wavelet(self.info.stream)
+        self._lib.neb_marker_push(b"SVGF Denoising")  # NEB_PIX_SCOPED_EVENT, src/DeferredRenderer.cpp:599
+        try:
+            if self.reset_history:
+                self.reset_history = False
+                self.svgf.reset_history(self.info.stream)
+            self.svgf.submit_temporal_accumulation(self.info.stream)
+            self.svgf.submit_atrous_compute_wavelet(self.info.stream)
+        finally:
+            self._lib.neb_marker_pop()
         return True
 
     # ---- introspection ----

@@ -23,12 +23,16 @@ def test_single_gpu_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _last_json(p.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "svgf_roofline", "frame_roofline", "strong_1080p_frames_per_s"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
-    assert "workload" in d["config"]
+    one = d["cpu_baseline"]["single_thread"]
+    assert one["cores"] == 1 and 0 < one["value"] <= d["cpu_baseline"]["value"] * 1.5
+    assert "workload" in d["config"] and "69 textures of 1024^2" in d["config"]["workload"]
+    assert d["config"]["scene_device_bytes"]["texture_tables"] > 1.5e9  # 24 material bundles of 1024^2 x 64 B
+    assert 0 < d["frame_roofline"]["frac"] < d["svgf_roofline"]["frac"] < 1
 
 
 @pytest.mark.parametrize("scheme", ["once", "per_level"])
@@ -36,10 +40,15 @@ def test_two_rank_rehearsal(scheme):
     env = dict(os.environ, NEB_BENCH_SHARE_DEVICE="1", NEB_BENCH_BACKEND="gloo", NEB_STRIPS_SCHEME=scheme)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29650 + (os.getpid() % 200)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--cpu-frames", "0", "--gather"]
+           "--cpu-frames", "0", "--gather", "--tex-size", "256"] + (["--config5", "--config5-frames", "4"] if scheme == "once" else [])
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_height"] == 2160
     assert ("one per frame" if scheme == "once" else "one per a-trous level") in d["config"]["parallelism"]
     assert d["frames_per_s_with_final_gather"] > 0
+    assert d["strong_1080p"]["rows_per_strip"] == 540 and d["strong_1080p_frames_per_s"] > 0
+    if scheme == "once":
+        c5 = d["config5"]
+        assert c5["reference_policy"]["frames_denoised"] == 2 and c5["always_on"]["frames_denoised"] == 4
+        assert c5["reference_policy"]["mrays_per_s"] > 0
