@@ -365,3 +365,40 @@ def test_rebuild_and_refused_build_keep_a_valid_tree():
     with pytest.raises(NebError):
         r.svgf.set_option("gi_max_bvh_depth", 22)
     r.destroy()
+
+
+@pytest.mark.parametrize("name", ["gi_cornell_tex_40x32", "gi_cornell_tex_multibounce_32x24", "gi_cornell_box_real_32x32",
+                                  "gi_damaged_helmet_48x32"])
+def test_hip_matches_the_numpy_restatement_golden(name):
+    """The HIP path against the committed vectors of oracle/gi_np.py (tests/golden/make_gi_golden.py): an independent
+    reading of the shaders with brute-force intersection -- not the C++ oracle the kernels were developed against."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_gi_golden as mk
+    d = np.load(os.path.join(mk.HERE, name + ".npz"))
+    sc = mk.case_scene(str(d["scene"]))
+    H, W = d["albedo"].shape
+    c = mk.case_constants(d)
+    cam = S.orbit_camera()
+    cam.eye[:] = [float(v) for v in d["eye"]]
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.gi_ui.gi_samples_per_pixel = int(d["spp"])
+    r.gi_ui.max_path_vertices = int(d["max_path_vertices"])
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=int(d["frame_index"])))
+    upload_gbuffer(r, {k: d[k] for k in mk.GB_KEYS})
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, d["radiance_in"])
+    r.set_debug_hits(True)
+    r.ray_count(reset=True)
+    gc = r.global_constants()
+    assert (gc.frameIndex, gc.samplesPerPixel, gc.maxPathVertices) == (c.frameIndex, c.samplesPerPixel, c.maxPathVertices)
+    assert list(gc.cameraWorldPos) == list(c.cameraWorldPos) and gc.sunTanHalfAngle == c.sunTanHalfAngle
+    r.submit_commands_gi_pathtrace()
+    got, hits, rays = r.svgf.download(PLANE_RADIANCE), r.download_hits(), r.ray_count()
+    same = (hits["geometry"] == d["geometry"]) & (hits["primitive"] == d["primitive"]) & (((hits["flags"] & 1) == 1) == d["unoccluded"])
+    assert same.mean() >= 0.998, f"hit / sun-visibility mismatch on {(~same).sum()} of {same.size} pixels"
+    assert abs(rays - int(d["rays"])) <= 2
+    assert np.array_equal(got[..., 3], d["radiance_in"][..., 3])
+    assert rel_l2(got[same][:, :3], d["radiance"][same]) <= 2e-5
+    r.destroy()

@@ -145,3 +145,43 @@ def test_reference_assets_load_and_trace(asset, tris, geoms):
     if "cornell" in asset:
         # factor-only materials write albedo 0 into the G-buffer (deferred_gbuffers.hlsl:74-78): no indirect light
         assert float(rad[..., :3].max()) == 0.0
+
+
+# ---- golden vectors of the independent numpy restatement (oracle/gi_np.py, tests/golden/make_gi_golden.py) ----
+def _gi_golden_cases():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_gi_golden as mk
+    return mk
+
+
+@pytest.mark.parametrize("name", ["gi_cornell_tex_40x32", "gi_cornell_tex_multibounce_32x24", "gi_cornell_box_real_32x32",
+                                  "gi_damaged_helmet_48x32"])
+def test_trace_ref_matches_the_numpy_restatement_golden(name):
+    """oracle/trace_ref.cpp (own SAH BVH, float32 Moeller-Trumbore) against vectors produced by a second, independent
+    reading of the shaders with brute-force float64 intersection: same hits, same sun visibility, same radiance."""
+    mk = _gi_golden_cases()
+    d = np.load(os.path.join(mk.HERE, name + ".npz"))
+    sc = mk.case_scene(str(d["scene"]))
+    o = OracleTracer(sc)
+    gb = {k: d[k] for k in mk.GB_KEYS}
+    got, hits, rays = o.gi(gb, mk.case_constants(d), radiance=d["radiance_in"].copy())
+    same = (hits["geometry"] == d["geometry"]) & (hits["primitive"] == d["primitive"]) & (((hits["flags"] & 1) == 1) == d["unoccluded"])
+    assert same.mean() >= 0.998, f"hit / sun-visibility mismatch on {(~same).sum()} of {same.size} pixels"
+    assert abs(rays - int(d["rays"])) <= 2
+    assert np.array_equal(got[..., 3], d["radiance_in"][..., 3])
+    err = np.linalg.norm(got[same][:, :3] - d["radiance"][same]) / np.linalg.norm(d["radiance"][same])
+    assert err <= 2e-5, err
+    hit = same & (d["t"] > 0)
+    assert np.abs(hits["t"][hit] - d["t"][hit]).max() <= 1e-4 * np.abs(d["t"][hit]).max()
+
+
+@pytest.mark.parametrize("name", ["gi_cornell_tex_40x32", "gi_cornell_tex_multibounce_32x24"])
+def test_committed_gi_golden_is_what_the_numpy_restatement_produces(name):
+    from oracle import gi_np
+    mk = _gi_golden_cases()
+    d = np.load(os.path.join(mk.HERE, name + ".npz"))
+    out = gi_np.trace(mk.case_scene(str(d["scene"])), {k: d[k] for k in mk.GB_KEYS}, mk.case_constants(d), radiance_in=d["radiance_in"])
+    assert np.array_equal(out["geometry"], d["geometry"]) and np.array_equal(out["primitive"], d["primitive"])
+    assert np.array_equal(out["unoccluded"], d["unoccluded"]) and int(out["rays"]) == int(d["rays"])
+    assert np.allclose(out["radiance"], d["radiance"], rtol=1e-6, atol=1e-7)
