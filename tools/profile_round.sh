@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box call that produces a round's evidence under gpurun_out/<tag>/ and the reduced summaries under profiles/<tag>_*:
+#   bench line, rocprofv3 --kernel-trace --stats, and three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ counters).
+# usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r02a [extra bench.py flags]
+set -o pipefail
+tag=$1; shift
+extra="$@"
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+out=gpurun_out/$tag
+rm -rf "$out" && mkdir -p "$out" profiles
+python bench.py $extra > "$out/bench.json" 2> "$out/bench.err" || { tail -20 "$out/bench.err"; exit 1; }
+echo "[profile_round] bench done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python bench.py --steps 32 --warmup 8 --cpu-frames 0 $extra > "$out/stats.log" 2>&1 || { tail -20 "$out/stats.log"; exit 1; }
+echo "[profile_round] kernel trace done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_$c" -- python bench.py --steps 4 --warmup 2 --cpu-frames 0 $extra > "$out/pmc_$c.log" 2>&1 || { tail -20 "$out/pmc_$c.log"; exit 1; }
+  echo "[profile_round] pmc $c done"
+done
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d "$out/pmc_sq" -- python bench.py --steps 4 --warmup 2 --cpu-frames 0 $extra > "$out/pmc_sq.log" 2>&1 || { tail -20 "$out/pmc_sq.log"; exit 1; }
+echo "[profile_round] pmc SQ done"
+cp "$out/bench.json" "profiles/${tag}_bench.json"
+cp $(ls "$out"/stats/*/*kernel_stats.csv | head -1) "profiles/${tag}_kernel_stats.csv"
+python tools/traffic_from_pmc.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "profiles/${tag}_hbm_traffic.json" 1920 1080 > /dev/null
+python tools/sq_from_pmc.py "$out/pmc_sq" "profiles/${tag}_sq_counters.json" > /dev/null
+mkdir -p "$out/profiles" && cp profiles/${tag}_* "$out/profiles/"
+python - "$tag" <<'PY'
+import csv, sys
+tag = sys.argv[1]
+rows = sorted(csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")), key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:16]:
+    print(f'{float(r["AverageNs"]) / 1e3:9.1f} us x{r["Calls"]:>5}  {r["Name"][:110]}')
+PY
