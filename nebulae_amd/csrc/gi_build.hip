@@ -1,8 +1,8 @@
 // gi_build.hip -- scene upload and acceleration structure of the GI path (one-time setup).
 //
 // Reference: src/nri/GIProcessedScene.cpp:16-137 (scene tables); RTAccelerationStructureBuilder.cpp:14-130 (driver
-// BVH -> replaced by a Karras LBVH built on the device, its upper levels re-linked by SAH and collapsed to a 4-wide
-// tree in a host pass).
+// BVH, built on the GPU once -> replaced by an own device build: Morton sort, PLOC clustering, collapse to a 4-wide
+// tree, all in HIP kernels).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -90,7 +90,7 @@ __global__ void texture_footprints_kernel(const uint32_t* __restrict__ px, uint3
 }
 
 // ------------------------------------------------------------------------------------------------
-// LBVH build (Karras 2012): Morton keys -> radix sort -> hierarchy -> bottom-up refit
+// Spatial order: 64-bit Morton keys of the triangle centroids -> radix sort -> gather
 // ------------------------------------------------------------------------------------------------
 // spreads the low 21 bits of v to every third bit
 __device__ __forceinline__ uint64_t expand_bits21(uint64_t v)
@@ -138,106 +138,273 @@ __global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint6
     out[3 * i + 2] = make_float4(t[8], t[9], t[10], t[11]);
 }
 
-__device__ __forceinline__ int lbvh_delta(const uint64_t* keys, int n, int i, int j)
-{
-    if (j < 0 || j >= n)
-        return -1;
-    return __clzll(keys[i] ^ keys[j]);
-}
+// ------------------------------------------------------------------------------------------------
+// Topology: PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) over the Morton-sorted triangles, on
+// the device.  Clusters live in an array in Morton order; every iteration each cluster finds, within +-kPlocRadius
+// positions, the neighbour whose merged box has the smallest surface area; mutual pairs merge into a new binary node;
+// the array is compacted (prefix sum) and the loop repeats until one cluster -- the root -- is left.  Unlike the Morton
+// splits of an LBVH this is driven by box area throughout (near the root too, where every ray pays), and unlike a
+// top-down SAH sweep it is a few dozen data-parallel passes.
+// Binary nodes: [0, n) = the sorted triangles, [n, 2n - 1) = merges in creation order.
+// ------------------------------------------------------------------------------------------------
+#ifndef NEB_PLOC_RADIUS
+#define NEB_PLOC_RADIUS 16
+#endif
+constexpr int kPlocRadius = NEB_PLOC_RADIUS;
 
-// one thread per inner node i in [0, n-2]
-__global__ void lbvh_hierarchy_kernel(const uint64_t* __restrict__ keys, int n, int2* children, int* parent_inner, int* parent_leaf)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1)
-        return;
-    const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-    const int dmin = lbvh_delta(keys, n, i, i - d);
-    int lmax = 2;
-    while (lbvh_delta(keys, n, i, i + lmax * d) > dmin)
-        lmax *= 2;
-    int l = 0;
-    for (int t = lmax / 2; t >= 1; t /= 2)
-        if (lbvh_delta(keys, n, i, i + (l + t) * d) > dmin)
-            l += t;
-    const int j = i + l * d;
-    const int dnode = lbvh_delta(keys, n, i, j);
-    int s = 0;
-    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
-        if (lbvh_delta(keys, n, i, i + (s + t) * d) > dnode)
-            s += t;
-        if (t <= 1)
-            break;
-    }
-    const int gamma = i + s * d + min(d, 0);
-    const int lo = min(i, j), hi = max(i, j);
-    const int c0 = (lo == gamma) ? ~gamma : gamma;             // leaf codes are ~index
-    const int c1 = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
-    children[i] = make_int2(c0, c1);
-    if (c0 < 0)
-        parent_leaf[gamma] = i;
-    else
-        parent_inner[gamma] = i;
-    if (c1 < 0)
-        parent_leaf[gamma + 1] = i;
-    else
-        parent_inner[gamma + 1] = i;
-}
+struct PlocNodes {
+    float4* lo;      // {min.xyz, left child as int bits}   (leaves: children = -1)
+    float4* hi;      // {max.xyz, right child as int bits}
+    uint32_t* size;  // triangles below the node
+};
 
-// one thread per leaf: walk up; the second arrival at a node owns it (boxes of both children are then visible)
-__global__ void lbvh_refit_kernel(const float4* __restrict__ tris, int n, const int2* __restrict__ children, const int* __restrict__ parent_inner,
-                                  const int* __restrict__ parent_leaf, float* node_min, float* node_max, uint32_t* visit, BvhNode* nodes)
+__global__ void ploc_init_kernel(const float4* __restrict__ tris, uint32_t n, PlocNodes N, uint32_t* clusters)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    int node = parent_leaf[i];
-    while (true) {
-        __threadfence();
-        if (atomicAdd(&visit[node], 1u) == 0u)
-            return; // first arrival: the sibling subtree is not finished yet
-        __threadfence();
-        const int2 ch = children[node];
-        float bmin[2][3], bmax[2][3];
-        const int cc[2] = {ch.x, ch.y};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (cc[k] < 0) {
-                const uint32_t ti = (uint32_t)~cc[k];
-                const float4 a = tris[3 * ti], b = tris[3 * ti + 1], c = tris[3 * ti + 2];
-                const float3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.x + a.w, a.y + b.x, a.z + b.y), v2 = f3(a.x + b.z, a.y + b.w, a.z + c.x);
-                bmin[k][0] = fminf(v0.x, fminf(v1.x, v2.x));
-                bmin[k][1] = fminf(v0.y, fminf(v1.y, v2.y));
-                bmin[k][2] = fminf(v0.z, fminf(v1.z, v2.z));
-                bmax[k][0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
-                bmax[k][1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
-                bmax[k][2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));
-            } else {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    bmin[k][q] = __hip_atomic_load(&node_min[3 * cc[k] + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bmax[k][q] = __hip_atomic_load(&node_max[3 * cc[k] + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+    const float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
+    const float3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.x + a.w, a.y + b.x, a.z + b.y), v2 = f3(a.x + b.z, a.y + b.w, a.z + c.x);
+    N.lo[i] = make_float4(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)), __int_as_float(-1));
+    N.hi[i] = make_float4(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)), __int_as_float(-1));
+    N.size[i] = 1u;
+    clusters[i] = i;
+}
+
+__device__ __forceinline__ float box_half_area(float3 lo, float3 hi)
+{
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// state[0] = live clusters, state[1] = next free node id (read side of the iteration; the apply kernel writes the other half)
+__global__ __launch_bounds__(256) void ploc_nearest_kernel(PlocNodes N, const uint32_t* __restrict__ clusters, const uint32_t* __restrict__ state,
+                                                           uint32_t* nearest)
+{
+    __shared__ float3 s_lo[256 + 2 * kPlocRadius], s_hi[256 + 2 * kPlocRadius];
+    const uint32_t m = state[0];
+    const int base = (int)(blockIdx.x * 256u) - kPlocRadius;
+    if (blockIdx.x * 256u >= m)
+        return;
+    for (int k = threadIdx.x; k < 256 + 2 * kPlocRadius; k += 256) {
+        const int j = base + k;
+        if (j >= 0 && j < (int)m) {
+            const uint32_t c = clusters[j];
+            const float4 lo = N.lo[c], hi = N.hi[c];
+            s_lo[k] = f3(lo.x, lo.y, lo.z);
+            s_hi[k] = f3(hi.x, hi.y, hi.z);
+        }
+    }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= (int)m)
+        return;
+    const float3 lo = s_lo[threadIdx.x + kPlocRadius], hi = s_hi[threadIdx.x + kPlocRadius];
+    // The partner minimises a key that is a SYMMETRIC function of the unordered pair -- (merged area, not an aligned pair
+    // {2k, 2k+1}, index distance, smaller index) -- so the globally smallest pair always picks each other and every
+    // iteration makes progress; the "aligned pair" term makes a field of identical boxes halve per iteration instead of
+    // losing one pair at a time.
+    float best = INFINITY;
+    uint32_t best_key = 0xffffffffu;
+    int best_j = -1, best_mn = 0x7fffffff;
+    for (int d = -kPlocRadius; d <= kPlocRadius; ++d) {
+        const int j = i + d;
+        if (d == 0 || j < 0 || j >= (int)m)
+            continue;
+        const float3 l2 = s_lo[threadIdx.x + kPlocRadius + d], h2 = s_hi[threadIdx.x + kPlocRadius + d];
+        const float area = box_half_area(f3(fminf(lo.x, l2.x), fminf(lo.y, l2.y), fminf(lo.z, l2.z)), f3(fmaxf(hi.x, h2.x), fmaxf(hi.y, h2.y), fmaxf(hi.z, h2.z)));
+        const int mn = min(i, j);
+        const uint32_t dist = (uint32_t)abs(d);
+        const uint32_t key = ((((mn & 1) == 0 && dist == 1u) ? 0u : 1u) << 8) | dist;
+        if (area < best || (area == best && (key < best_key || (key == best_key && mn < best_mn)))) {
+            best = area;
+            best_key = key;
+            best_j = j;
+            best_mn = mn;
+        }
+    }
+    nearest[i] = (uint32_t)best_j; // (m >= 2 here, so a partner exists)
+}
+
+// flags: low 32 bits = 1 if position i survives into the next cluster array, high 32 bits = 1 if it creates a node
+__global__ void ploc_flags_kernel(const uint32_t* __restrict__ nearest, const uint32_t* __restrict__ state, uint32_t n_max, unsigned long long* flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max)
+        return;
+    const uint32_t m = state[0];
+    unsigned long long f = 0ull;
+    if (i < m) {
+        const uint32_t j = nearest[i];
+        const bool mutual = nearest[j] == i;
+        if (!mutual)
+            f = 1ull;
+        else if (i < j)
+            f = 1ull | (1ull << 32);
+    }
+    flags[i] = f;
+}
+
+__global__ void ploc_apply_kernel(PlocNodes N, const uint32_t* __restrict__ clusters, uint32_t* __restrict__ clusters_out, const uint32_t* __restrict__ nearest,
+                                  const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ scan, const uint32_t* __restrict__ state,
+                                  uint32_t* __restrict__ state_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t m = state[0];
+    if (i >= m)
+        return;
+    const unsigned long long f = flags[i], sc = scan[i];
+    if (i == m - 1) {
+        const unsigned long long tot = sc + f;
+        state_out[0] = (uint32_t)tot;
+        state_out[1] = state[1] + (uint32_t)(tot >> 32);
+    }
+    if (!(f & 1ull))
+        return;
+    const uint32_t pos = (uint32_t)sc;
+    const uint32_t ci = clusters[i];
+    if (f >> 32) {
+        const uint32_t cj = clusters[nearest[i]];
+        const uint32_t node = state[1] + (uint32_t)(sc >> 32);
+        const float4 l1 = N.lo[ci], h1 = N.hi[ci], l2 = N.lo[cj], h2 = N.hi[cj];
+        N.lo[node] = make_float4(fminf(l1.x, l2.x), fminf(l1.y, l2.y), fminf(l1.z, l2.z), __int_as_float((int)ci));
+        N.hi[node] = make_float4(fmaxf(h1.x, h2.x), fmaxf(h1.y, h2.y), fmaxf(h1.z, h2.z), __int_as_float((int)cj));
+        N.size[node] = N.size[ci] + N.size[cj];
+        clusters_out[pos] = node;
+    } else {
+        clusters_out[pos] = ci;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Collapse of the binary tree into the 128-byte BVH4 nodes the traverser walks, level by level on the device.
+// A queue entry = (binary node that becomes a wide node, first slot of its triangles in the final order); a level's
+// entries are consecutive, and an entry's position in the queue IS its wide node index (breadth-first layout: the
+// children of a node are neighbours).  Per level: `open` picks the (up to) four children -- repeatedly opening the inner
+// child with the largest box -- and counts the inner ones; a prefix sum places them in the next level; `emit` writes
+// the node, copies leaf triangles into their final (leaf-order) slots and appends the next level's entries.
+// The number of levels is the depth of the BVH4.
+// ------------------------------------------------------------------------------------------------
+struct CollapseArgs {
+    PlocNodes N;
+    uint32_t n_tris;
+    const float4* tris_in;  // Morton order
+    float4* tris_out;       // leaf order of the final tree
+    Bvh4Node* wide;
+    uint32_t* q_node;       // per wide node: its binary node
+    uint32_t* q_off;        // per wide node: first final triangle slot of its subtree
+    int4* opened;           // per wide node: the chosen children (binary node ids, -1 = unused)
+    uint32_t* inner_count;  // per wide node of the current level
+    uint32_t* inner_scan;   // exclusive prefix sum of inner_count over the level
+    uint32_t* level_state;  // [0] = entries of the next level
+    uint32_t level_start, level_count;
+};
+
+__device__ __forceinline__ bool collapse_is_leaf(const PlocNodes& N, int node) { return N.size[node] <= (uint32_t)kMaxLeafTris; }
+
+__global__ void collapse_open_kernel(CollapseArgs a)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.level_count)
+        return;
+    const uint32_t e = a.level_start + k;
+    const int bn = (int)a.q_node[e];
+    int c[4] = {__float_as_int(a.N.lo[bn].w), __float_as_int(a.N.hi[bn].w), -1, -1};
+    int nc = 2;
+    while (nc < 4) { // open the inner child with the largest surface area
+        int best = -1;
+        float best_area = -1.0f;
+        for (int q = 0; q < nc; ++q) {
+            if (collapse_is_leaf(a.N, c[q]))
+                continue;
+            const float4 lo = a.N.lo[c[q]], hi = a.N.hi[c[q]];
+            const float ar = box_half_area(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z));
+            if (ar > best_area) {
+                best_area = ar;
+                best = q;
             }
         }
-        BvhNode out;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            out.c0min[q] = bmin[0][q];
-            out.c0max[q] = bmax[0][q];
-            out.c1min[q] = bmin[1][q];
-            out.c1max[q] = bmax[1][q];
-            __hip_atomic_store(&node_min[3 * node + q], fminf(bmin[0][q], bmin[1][q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&node_max[3 * node + q], fmaxf(bmax[0][q], bmax[1][q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        out.c0 = ch.x;
-        out.c1 = ch.y;
-        out.pad0 = out.pad1 = 0;
-        nodes[node] = out;
-        if (node == 0)
-            return; // root
-        node = parent_inner[node];
+        if (best < 0)
+            break;
+        const int o = c[best];
+        c[best] = __float_as_int(a.N.lo[o].w);
+        c[nc++] = __float_as_int(a.N.hi[o].w);
     }
+    uint32_t inner = 0;
+    for (int q = 0; q < nc; ++q)
+        inner += collapse_is_leaf(a.N, c[q]) ? 0u : 1u;
+    a.opened[e] = make_int4(c[0], c[1], c[2], c[3]);
+    a.inner_count[k] = inner;
+}
+
+// copies the (<= 4) triangles below binary node `node` into consecutive final slots starting at `slot`
+__device__ void collapse_copy_leaf(const CollapseArgs& a, int node, uint32_t slot)
+{
+    int stack[8];
+    int sp = 0;
+    stack[sp++] = node;
+    while (sp) {
+        const int x = stack[--sp];
+        if (x < (int)a.n_tris) {
+            a.tris_out[3 * slot] = a.tris_in[3 * x];
+            a.tris_out[3 * slot + 1] = a.tris_in[3 * x + 1];
+            a.tris_out[3 * slot + 2] = a.tris_in[3 * x + 2];
+            ++slot;
+        } else {
+            stack[sp++] = __float_as_int(a.N.hi[x].w); // right below left: the left subtree comes out first
+            stack[sp++] = __float_as_int(a.N.lo[x].w);
+        }
+    }
+}
+
+__global__ void collapse_emit_kernel(CollapseArgs a)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.level_count)
+        return;
+    const uint32_t e = a.level_start + k;
+    const int4 o = a.opened[e];
+    const int c[4] = {o.x, o.y, o.z, o.w};
+    uint32_t off = a.q_off[e];
+    uint32_t next = a.level_start + a.level_count + a.inner_scan[k]; // wide index of this entry's first inner child
+    float lo[3][4], hi[3][4];
+    int ch[4];
+    for (int q = 0; q < 4; ++q) {
+        if (c[q] < 0) {
+            for (int ax = 0; ax < 3; ++ax) {
+                lo[ax][q] = INFINITY; // inverted box: never hit
+                hi[ax][q] = -INFINITY;
+            }
+            ch[q] = ~0;
+            continue;
+        }
+        const float4 l = a.N.lo[c[q]], h = a.N.hi[c[q]];
+        lo[0][q] = l.x, lo[1][q] = l.y, lo[2][q] = l.z;
+        hi[0][q] = h.x, hi[1][q] = h.y, hi[2][q] = h.z;
+        const uint32_t cnt = a.N.size[c[q]];
+        if (cnt <= (uint32_t)kMaxLeafTris) {
+            collapse_copy_leaf(a, c[q], off);
+            ch[q] = ~(int)((off << 2) | (cnt - 1u));
+        } else {
+            ch[q] = (int)next;
+            a.q_node[next] = (uint32_t)c[q];
+            a.q_off[next] = off;
+            ++next;
+        }
+        off += cnt;
+    }
+    Bvh4Node nd;
+    nd.lox = make_float4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+    nd.loy = make_float4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    nd.loz = make_float4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
+    nd.hix = make_float4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]);
+    nd.hiy = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
+    nd.hiz = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
+    nd.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+    nd.pad = make_int4(0, 0, 0, 0);
+    a.wide[e] = nd;
+    if (k == a.level_count - 1)
+        a.level_state[0] = a.inner_scan[k] + a.inner_count[k];
 }
 
 } // namespace neb
@@ -485,50 +652,77 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     if (n == 0) { // empty scene: every ray misses
         g->built = true;
         g->n_nodes = 0;
+        g->bvh_depth = 0;
         g->view.root = -1;
         return NEB_OK;
     }
     // Everything is built into locals and committed to g->view only at the very end, on success: a failed (re)build
     // leaves the scene exactly as it was -- still unbuilt, or still holding the previous, valid tree.
-    std::vector<void*> fresh; // device arrays of THIS build that outlive it (freed again on failure)
+    // The whole build runs on the device: Morton keys -> radix sort -> PLOC merges -> BVH4 collapse + leaf-order triangle
+    // permutation -> shading records.  The host only reads back one counter per pass (live clusters / level size).
+    std::vector<void*> temps, fresh; // freed at the end / device arrays that outlive the build (freed again on failure)
+    bool oom = false;
     auto dalloc = [&](size_t bytes, bool keep) -> void* {
         void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess)
+        if (oom || hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            oom = true;
             return nullptr;
-        if (keep)
-            fresh.push_back(p);
+        }
+        (keep ? fresh : temps).push_back(p);
         return p;
     };
-    auto drop_fresh = [&]() {
-        for (void* p : fresh)
+    auto release = [&](std::vector<void*>& v) {
+        for (void* p : v)
             (void)hipFree(p);
-        fresh.clear();
+        v.clear();
     };
+    const size_t n2 = 2 * (size_t)n;
     float* d_tris12 = (float*)dalloc((size_t)n * 48, false);
-    float4* d_sorted = (float4*)dalloc((size_t)n * 48, true);
+    float4* d_sorted = (float4*)dalloc((size_t)n * 48, false); // Morton order
+    float4* d_final = (float4*)dalloc((size_t)n * 48, true);   // leaf order of the final tree
     uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8, false);
     uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8, false);
-    const uint32_t n_inner = n > 1 ? n - 1 : 1;
-    BvhNode* d_nodes = (BvhNode*)dalloc((size_t)n_inner * sizeof(BvhNode), false);
-    int2* d_children = (int2*)dalloc((size_t)n_inner * sizeof(int2), false);
-    int* d_parent_inner = (int*)dalloc((size_t)n_inner * 4, false);
-    int* d_parent_leaf = (int*)dalloc((size_t)n * 4, false);
-    float* d_nmin = (float*)dalloc((size_t)n_inner * 12, false);
-    float* d_nmax = (float*)dalloc((size_t)n_inner * 12, false);
-    uint32_t* d_visit = (uint32_t*)dalloc((size_t)n_inner * 4, false);
-    void* temps[] = {d_tris12, d_keys, d_keys2, d_nodes, d_children, d_parent_inner, d_parent_leaf, d_nmin, d_nmax, d_visit};
-    auto free_temps = [&]() {
-        for (void* p : temps)
-            if (p)
-                (void)hipFree(p);
-    };
-    if (!d_tris12 || !d_sorted || !d_keys || !d_keys2 || !d_nodes || !d_children || !d_parent_inner || !d_parent_leaf || !d_nmin ||
-        !d_nmax || !d_visit) {
-        free_temps();
-        drop_fresh();
+    PlocNodes N;
+    N.lo = (float4*)dalloc(n2 * 16, false);
+    N.hi = (float4*)dalloc(n2 * 16, false);
+    N.size = (uint32_t*)dalloc(n2 * 4, false);
+    uint32_t* d_clusters[2] = {(uint32_t*)dalloc((size_t)n * 4, false), (uint32_t*)dalloc((size_t)n * 4, false)};
+    uint32_t* d_nearest = (uint32_t*)dalloc((size_t)n * 4, false);
+    unsigned long long* d_flags = (unsigned long long*)dalloc((size_t)n * 8, false);
+    unsigned long long* d_scan = (unsigned long long*)dalloc((size_t)n * 8, false);
+    uint32_t* d_state = (uint32_t*)dalloc(8 * 4, false); // two {live clusters, next node id} pairs + the collapse's level counter
+    Bvh4Node* d_wide_tmp = (Bvh4Node*)dalloc((size_t)n * sizeof(Bvh4Node), false); // (at most n - 1 wide nodes)
+    uint32_t* d_qnode = (uint32_t*)dalloc((size_t)n * 4, false);
+    uint32_t* d_qoff = (uint32_t*)dalloc((size_t)n * 4, false);
+    int4* d_opened = (int4*)dalloc((size_t)n * 16, false);
+    uint32_t* d_icount = (uint32_t*)dalloc((size_t)n * 4, false);
+    uint32_t* d_iscan = (uint32_t*)dalloc((size_t)n * 4, false);
+    float4* d_shade = (float4*)dalloc((size_t)n * 128, true);
+    size_t cub_bytes = 0, cub_b2 = 0, cub_b3 = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b2, d_flags, d_scan, (int)n, stream);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b3, d_icount, d_iscan, (int)n, stream);
+    cub_bytes = std::max(cub_bytes, std::max(cub_b2, cub_b3));
+    void* d_cub = dalloc(cub_bytes, false);
+    if (oom) {
+        release(temps);
+        release(fresh);
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh: out of device memory");
     }
-    hipError_t e = hipMemcpyAsync(d_tris12, g->h_tris.data(), (size_t)n * 48, hipMemcpyHostToDevice, stream);
+    auto bail = [&](int code, const char* what, hipError_t e = hipSuccess) {
+        (void)hipStreamSynchronize(stream);
+        release(temps);
+        release(fresh);
+        return gi_fail(ctx, code, what, e);
+    };
+#define BUILD_HIP(call)                                   \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess)                             \
+            return bail(NEB_ERR_HIP, #call, e_);          \
+    } while (0)
+    // ---- Morton order ----
+    BUILD_HIP(hipMemcpyAsync(d_tris12, g->h_tris.data(), (size_t)n * 48, hipMemcpyHostToDevice, stream));
     const float3 smin = make_float3(g->scene_min[0], g->scene_min[1], g->scene_min[2]);
     // (per-axis normalisation: cubic cells -- all axes scaled by the longest extent -- traversed 12 % slower on the bench scene)
     const float3 sinv = make_float3(1.0f / fmaxf(g->scene_max[0] - g->scene_min[0], 1e-20f), 1.0f / fmaxf(g->scene_max[1] - g->scene_min[1], 1e-20f),
@@ -542,334 +736,101 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
 #else
     const uint32_t axis_bits = (64 - index_bits) / 3 < 21 ? (64 - index_bits) / 3 : 21;
 #endif
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, n, smin, sinv, axis_bits, index_bits, d_keys);
-        e = hipGetLastError();
+    hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, n, smin, sinv, axis_bits, index_bits, d_keys);
+    BUILD_HIP(hipGetLastError());
+    BUILD_HIP(hipcub::DeviceRadixSort::SortKeys(d_cub, cub_bytes, d_keys, d_keys2, (int)n, 0, 64, stream));
+    hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, d_keys2, n, (1ull << index_bits) - 1ull, d_sorted);
+    BUILD_HIP(hipGetLastError());
+    // ---- PLOC ----
+    hipLaunchKernelGGL(ploc_init_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)d_sorted, n, N, d_clusters[0]);
+    BUILD_HIP(hipGetLastError());
+    uint32_t h_state[2] = {n, n};
+    BUILD_HIP(hipMemcpyAsync(d_state, h_state, sizeof(h_state), hipMemcpyHostToDevice, stream));
+    uint32_t m = n, iter = 0;
+    while (m > 1) {
+        const uint32_t* rs = d_state + 2 * (iter & 1u);
+        uint32_t* ws = d_state + 2 * ((iter + 1u) & 1u);
+        const uint32_t* cin = d_clusters[iter & 1u];
+        uint32_t* cout = d_clusters[(iter + 1u) & 1u];
+        const dim3 grid((m + 255) / 256);
+        hipLaunchKernelGGL(ploc_nearest_kernel, grid, dim3(256), 0, stream, N, cin, rs, d_nearest);
+        hipLaunchKernelGGL(ploc_flags_kernel, grid, dim3(256), 0, stream, (const uint32_t*)d_nearest, rs, m, d_flags);
+        BUILD_HIP(hipGetLastError());
+        BUILD_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_flags, d_scan, (int)m, stream));
+        hipLaunchKernelGGL(ploc_apply_kernel, grid, dim3(256), 0, stream, N, cin, cout, (const uint32_t*)d_nearest, (const unsigned long long*)d_flags,
+                           (const unsigned long long*)d_scan, rs, ws);
+        BUILD_HIP(hipGetLastError());
+        uint32_t m_new = 0;
+        BUILD_HIP(hipMemcpyAsync(&m_new, ws, 4, hipMemcpyDeviceToHost, stream));
+        BUILD_HIP(hipStreamSynchronize(stream));
+        if (m_new == 0 || m_new >= m)
+            return bail(NEB_ERR_HIP, "neb_gi_build_bvh: PLOC made no progress (internal error)");
+        m = m_new;
+        ++iter;
     }
-    size_t temp_bytes = 0;
-    void* d_temp = nullptr;
-    if (e == hipSuccess)
-        e = hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
-    if (e == hipSuccess)
-        e = hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16);
-    if (e == hipSuccess)
-        e = hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, d_keys2, n, (1ull << index_bits) - 1ull, d_sorted);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && n > 1) {
-        e = hipMemsetAsync(d_visit, 0, (size_t)n_inner * 4, stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, stream, d_keys2, (int)n, d_children,
-                               d_parent_inner, d_parent_leaf);
-            hipLaunchKernelGGL(lbvh_refit_kernel, dim3(nb), dim3(256), 0, stream, d_sorted, (int)n, d_children, d_parent_inner, d_parent_leaf,
-                               d_nmin, d_nmax, d_visit, d_nodes);
-            e = hipGetLastError();
+    g->build_passes = iter;
+    // ---- collapse to BVH4, triangles into leaf order ----
+    int root_code = 0, max_depth = 0;
+    uint32_t n_wide = 0;
+    if (n <= (uint32_t)kMaxLeafTris) { // the whole scene is one leaf
+        BUILD_HIP(hipMemcpyAsync(d_final, d_sorted, (size_t)n * 48, hipMemcpyDeviceToDevice, stream));
+        root_code = ~(int)((0u << 2) | (n - 1u));
+    } else {
+        CollapseArgs a;
+        a.N = N;
+        a.n_tris = n;
+        a.tris_in = d_sorted;
+        a.tris_out = d_final;
+        a.wide = d_wide_tmp;
+        a.q_node = d_qnode;
+        a.q_off = d_qoff;
+        a.opened = d_opened;
+        a.inner_count = d_icount;
+        a.inner_scan = d_iscan;
+        a.level_state = d_state + 4;
+        BUILD_HIP(hipMemcpyAsync(d_qnode, d_clusters[iter & 1u], 4, hipMemcpyDeviceToDevice, stream)); // the root = the last cluster
+        BUILD_HIP(hipMemsetAsync(d_qoff, 0, 4, stream));
+        uint32_t level_start = 0, level_count = 1;
+        while (level_count > 0) {
+            ++max_depth;
+            if ((size_t)level_start + level_count > (size_t)n)
+                return bail(NEB_ERR_HIP, "neb_gi_build_bvh: wide-node bound exceeded (internal error)");
+            a.level_start = level_start;
+            a.level_count = level_count;
+            const dim3 grid((level_count + 127) / 128);
+            hipLaunchKernelGGL(collapse_open_kernel, grid, dim3(128), 0, stream, a);
+            BUILD_HIP(hipGetLastError());
+            BUILD_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_icount, d_iscan, (int)level_count, stream));
+            hipLaunchKernelGGL(collapse_emit_kernel, grid, dim3(128), 0, stream, a);
+            BUILD_HIP(hipGetLastError());
+            uint32_t next = 0;
+            BUILD_HIP(hipMemcpyAsync(&next, d_state + 4, 4, hipMemcpyDeviceToHost, stream));
+            BUILD_HIP(hipStreamSynchronize(stream));
+            level_start += level_count;
+            level_count = next;
         }
-    }
-    float4* d_shade = nullptr;
-    if (e == hipSuccess) {
-        d_shade = (float4*)dalloc((size_t)n * 128, true);
-        if (!d_shade) {
-            e = hipErrorOutOfMemory;
-        } else {
-            SceneView sv = g->view;
-            sv.tris = d_sorted;
-            hipLaunchKernelGGL(pack_shade_records_kernel, dim3(nb), dim3(256), 0, stream, sv, n, d_shade);
-            e = hipGetLastError();
-        }
-    }
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(stream); // the temporaries are freed below; the build is a one-time setup step
-    // ---- collapse the binary LBVH into BVH4 nodes with leaves of up to kMaxLeafTris triangles ----
-    // (host pass over the device-built hierarchy: topology and boxes are the LBVH's; one-time setup)
-    std::vector<Bvh4Node> wide;
-    int root_code = ~0; // leaf {first 0, count 1}
-    int max_depth = 0;  // inner-node levels of the BVH4
-    if (e == hipSuccess && n > 1) {
-        std::vector<BvhNode> bin(n - 1);
-        e = hipMemcpy(bin.data(), d_nodes, (size_t)(n - 1) * sizeof(BvhNode), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) {
-            // triangle range of every binary inner node (LBVH subtrees cover contiguous sorted ranges)
-            std::vector<uint32_t> first(n - 1), count(n - 1);
-            {
-                std::vector<int> order; // children before parents
-                order.reserve(n - 1);
-                std::vector<int> stk{0};
-                while (!stk.empty()) {
-                    const int i = stk.back();
-                    stk.pop_back();
-                    order.push_back(i);
-                    if (bin[i].c0 >= 0)
-                        stk.push_back(bin[i].c0);
-                    if (bin[i].c1 >= 0)
-                        stk.push_back(bin[i].c1);
-                }
-                for (size_t k = order.size(); k-- > 0;) {
-                    const int i = order[k];
-                    const uint32_t f0 = bin[i].c0 >= 0 ? first[bin[i].c0] : (uint32_t)~bin[i].c0;
-                    const uint32_t n0 = bin[i].c0 >= 0 ? count[bin[i].c0] : 1u;
-                    const uint32_t f1 = bin[i].c1 >= 0 ? first[bin[i].c1] : (uint32_t)~bin[i].c1;
-                    const uint32_t n1 = bin[i].c1 >= 0 ? count[bin[i].c1] : 1u;
-                    first[i] = f0 < f1 ? f0 : f1;
-                    count[i] = n0 + n1;
-                }
-            }
-            struct Ref {
-                int id;        // binary child code: >= 0 inner, < 0 ~triangle
-                float lo[3], hi[3];
-            };
-            int bin_root = 0;
-#if NEB_TOP_SAH
-            // ---- HLBVH-style top level: the LBVH subtrees of at most NEB_TOP_SAH triangles stay as built on the device;
-            // the levels above them are re-linked here by a sweep-SAH build over those subtrees' boxes.  Morton splits
-            // are blind to box overlap and hurt most near the root, where every ray pays for them. ----
-            {
-                struct Cluster {
-                    Ref ref;
-                    uint32_t cnt;
-                    float c[3];
-                };
-                std::vector<Cluster> cl;
-                {
-                    std::vector<Ref> stk;
-                    Ref root{0, {0, 0, 0}, {0, 0, 0}};
-                    for (int q = 0; q < 3; ++q) {
-                        root.lo[q] = fminf(bin[0].c0min[q], bin[0].c1min[q]);
-                        root.hi[q] = fmaxf(bin[0].c0max[q], bin[0].c1max[q]);
-                    }
-                    stk.push_back(root);
-                    while (!stk.empty()) {
-                        const Ref r = stk.back();
-                        stk.pop_back();
-                        const uint32_t c = r.id >= 0 ? count[r.id] : 1u;
-                        if (r.id < 0 || c <= (uint32_t)NEB_TOP_SAH) {
-                            Cluster k{r, c, {0.5f * (r.lo[0] + r.hi[0]), 0.5f * (r.lo[1] + r.hi[1]), 0.5f * (r.lo[2] + r.hi[2])}};
-                            cl.push_back(k);
-                            continue;
-                        }
-                        Ref a, b;
-                        a.id = bin[r.id].c0;
-                        b.id = bin[r.id].c1;
-                        memcpy(a.lo, bin[r.id].c0min, 12);
-                        memcpy(a.hi, bin[r.id].c0max, 12);
-                        memcpy(b.lo, bin[r.id].c1min, 12);
-                        memcpy(b.hi, bin[r.id].c1max, 12);
-                        stk.push_back(a);
-                        stk.push_back(b);
-                    }
-                }
-                if (cl.size() > 1) {
-                    auto area = [](const float* lo, const float* hi) {
-                        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-                        return dx * dy + dy * dz + dz * dx;
-                    };
-                    std::vector<uint32_t> idx(cl.size());
-                    for (size_t k = 0; k < idx.size(); ++k)
-                        idx[k] = (uint32_t)k;
-                    std::vector<float> suffix_area;
-                    std::vector<uint32_t> suffix_cnt;
-                    // explicit work stack: {l, r, slot to patch}; a patch slot is (node index << 1 | child) or -1 for the root
-                    struct Job {
-                        size_t l, r;
-                        long patch;
-                    };
-                    std::vector<Job> jobs{{0, cl.size(), -1}};
-                    auto set_child = [&](long patch, const Ref& rf) {
-                        if (patch < 0) {
-                            bin_root = rf.id;
-                            return;
-                        }
-                        BvhNode& nd = bin[(size_t)(patch >> 1)];
-                        if (patch & 1) {
-                            nd.c1 = rf.id;
-                            memcpy(nd.c1min, rf.lo, 12);
-                            memcpy(nd.c1max, rf.hi, 12);
-                        } else {
-                            nd.c0 = rf.id;
-                            memcpy(nd.c0min, rf.lo, 12);
-                            memcpy(nd.c0max, rf.hi, 12);
-                        }
-                    };
-                    while (!jobs.empty()) {
-                        const Job jb = jobs.back();
-                        jobs.pop_back();
-                        const size_t m = jb.r - jb.l;
-                        if (m == 1) {
-                            set_child(jb.patch, cl[idx[jb.l]].ref);
-                            continue;
-                        }
-                        int best_axis = 0;
-                        size_t best_k = jb.l + m / 2;
-                        float best_cost = INFINITY;
-                        for (int ax = 0; ax < 3; ++ax) {
-                            std::sort(idx.begin() + (long)jb.l, idx.begin() + (long)jb.r,
-                                      [&](uint32_t a, uint32_t b) { return cl[a].c[ax] < cl[b].c[ax] || (cl[a].c[ax] == cl[b].c[ax] && a < b); });
-                            suffix_area.assign(m + 1, 0.f);
-                            suffix_cnt.assign(m + 1, 0u);
-                            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                            for (size_t k = m; k-- > 0;) {
-                                const Cluster& c = cl[idx[jb.l + k]];
-                                for (int q = 0; q < 3; ++q) {
-                                    lo[q] = fminf(lo[q], c.ref.lo[q]);
-                                    hi[q] = fmaxf(hi[q], c.ref.hi[q]);
-                                }
-                                suffix_area[k] = area(lo, hi);
-                                suffix_cnt[k] = suffix_cnt[k + 1] + c.cnt;
-                            }
-                            float plo[3] = {INFINITY, INFINITY, INFINITY}, phi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                            uint32_t pc = 0;
-                            for (size_t k = 1; k < m; ++k) { // split before element k
-                                const Cluster& c = cl[idx[jb.l + k - 1]];
-                                for (int q = 0; q < 3; ++q) {
-                                    plo[q] = fminf(plo[q], c.ref.lo[q]);
-                                    phi[q] = fmaxf(phi[q], c.ref.hi[q]);
-                                }
-                                pc += c.cnt;
-                                const float cost = area(plo, phi) * (float)pc + suffix_area[k] * (float)suffix_cnt[k];
-                                if (cost < best_cost) {
-                                    best_cost = cost;
-                                    best_axis = ax;
-                                    best_k = jb.l + k;
-                                }
-                            }
-                        }
-                        if (best_axis != 2)
-                            std::sort(idx.begin() + (long)jb.l, idx.begin() + (long)jb.r, [&](uint32_t a, uint32_t b) {
-                                return cl[a].c[best_axis] < cl[b].c[best_axis] || (cl[a].c[best_axis] == cl[b].c[best_axis] && a < b);
-                            });
-                        // new inner node over [l, best_k) and [best_k, r)
-                        Ref self;
-                        self.id = (int)bin.size();
-                        for (int q = 0; q < 3; ++q) {
-                            self.lo[q] = INFINITY;
-                            self.hi[q] = -INFINITY;
-                        }
-                        uint32_t total = 0;
-                        for (size_t k = jb.l; k < jb.r; ++k) {
-                            const Cluster& c = cl[idx[k]];
-                            for (int q = 0; q < 3; ++q) {
-                                self.lo[q] = fminf(self.lo[q], c.ref.lo[q]);
-                                self.hi[q] = fmaxf(self.hi[q], c.ref.hi[q]);
-                            }
-                            total += c.cnt;
-                        }
-                        bin.emplace_back();
-                        count.push_back(total);
-                        first.push_back(0); // (never a leaf: it spans more than one cluster)
-                        set_child(jb.patch, self);
-                        jobs.push_back({jb.l, best_k, ((long)self.id << 1) | 0});
-                        jobs.push_back({best_k, jb.r, ((long)self.id << 1) | 1});
-                    }
-                }
-            }
-#endif
-            auto leaf_code = [&](const Ref& r) -> int {
-                const uint32_t f = r.id >= 0 ? first[r.id] : (uint32_t)~r.id;
-                const uint32_t c = r.id >= 0 ? count[r.id] : 1u;
-                return ~(int)((f << 2) | (c - 1u));
-            };
-            // (only a device-built LBVH subtree covers a contiguous run of the sorted triangles; the top nodes linked
-            // above never do, however few triangles they hold)
-            auto is_leaf = [&](const Ref& r) { return r.id < 0 || (r.id < (int)(n - 1) && count[r.id] <= (uint32_t)kMaxLeafTris); };
-            auto area = [](const Ref& r) {
-                const float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
-                return dx * dy + dy * dz + dz * dx;
-            };
-            auto children_of = [&](int i, Ref* out) {
-                out[0].id = bin[i].c0;
-                out[1].id = bin[i].c1;
-                memcpy(out[0].lo, bin[i].c0min, 12);
-                memcpy(out[0].hi, bin[i].c0max, 12);
-                memcpy(out[1].lo, bin[i].c1min, 12);
-                memcpy(out[1].hi, bin[i].c1max, 12);
-            };
-            if (count[0] <= (uint32_t)kMaxLeafTris) {
-                root_code = ~(int)((0u << 2) | (count[0] - 1u));
-            } else {
-                root_code = 0;
-                // work list of (binary node, wide slot index); wide nodes are emitted in DFS order
-                struct Work {
-                    int bi, wi, depth;
-                };
-                std::vector<Work> work{{bin_root, 0, 1}};
-                wide.emplace_back();
-                while (!work.empty()) {
-                    const auto [bi, wi, depth] = work.back();
-                    work.pop_back();
-                    max_depth = std::max(max_depth, depth);
-                    Ref c[4];
-                    int nc = 2;
-                    children_of(bi, c);
-                    while (nc < 4) { // open the inner child with the largest surface area
-                        int best = -1;
-                        float best_area = -1.0f;
-                        for (int k = 0; k < nc; ++k)
-                            if (!is_leaf(c[k]) && area(c[k]) > best_area) {
-                                best_area = area(c[k]);
-                                best = k;
-                            }
-                        if (best < 0)
-                            break;
-                        Ref two[2];
-                        children_of(c[best].id, two);
-                        c[best] = two[0];
-                        c[nc++] = two[1];
-                    }
-                    Bvh4Node nd;
-                    float lo[3][4], hi[3][4];
-                    int ch[4];
-                    for (int k = 0; k < 4; ++k) {
-                        if (k < nc) {
-                            for (int q = 0; q < 3; ++q) {
-                                lo[q][k] = c[k].lo[q];
-                                hi[q][k] = c[k].hi[q];
-                            }
-                            if (is_leaf(c[k])) {
-                                ch[k] = leaf_code(c[k]);
-                            } else {
-                                ch[k] = (int)wide.size();
-                                wide.emplace_back();
-                                work.push_back({c[k].id, ch[k], depth + 1});
-                            }
-                        } else {
-                            for (int q = 0; q < 3; ++q) {
-                                lo[q][k] = INFINITY;
-                                hi[q][k] = -INFINITY;
-                            }
-                            ch[k] = ~0;
-                        }
-                    }
-                    nd.lox = make_float4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
-                    nd.loy = make_float4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
-                    nd.loz = make_float4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
-                    nd.hix = make_float4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]);
-                    nd.hiy = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
-                    nd.hiz = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
-                    nd.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
-                    nd.pad = make_int4(0, 0, 0, 0);
-                    wide[wi] = nd;
-                }
-            }
-        }
+        n_wide = level_start;
     }
     Bvh4Node* d_wide = nullptr;
-    if (e == hipSuccess && !wide.empty()) {
-        d_wide = (Bvh4Node*)dalloc(wide.size() * sizeof(Bvh4Node), true);
-        e = d_wide ? hipMemcpy(d_wide, wide.data(), wide.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice) : hipErrorOutOfMemory;
+    if (n_wide) {
+        d_wide = (Bvh4Node*)dalloc((size_t)n_wide * sizeof(Bvh4Node), true);
+        if (!d_wide)
+            return bail(NEB_ERR_HIP, "neb_gi_build_bvh: out of device memory");
+        BUILD_HIP(hipMemcpyAsync(d_wide, d_wide_tmp, (size_t)n_wide * sizeof(Bvh4Node), hipMemcpyDeviceToDevice, stream));
     }
-    if (d_temp)
-        (void)hipFree(d_temp);
-    free_temps();
-    if (e != hipSuccess) {
-        drop_fresh();
-        return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_build_bvh", e);
+    {
+        SceneView sv = g->view;
+        sv.tris = d_final;
+        hipLaunchKernelGGL(pack_shade_records_kernel, dim3(nb), dim3(256), 0, stream, sv, n, d_shade);
+        BUILD_HIP(hipGetLastError());
     }
+    BUILD_HIP(hipStreamSynchronize(stream)); // the temporaries are freed below; the build is a one-time setup step
+#undef BUILD_HIP
+    release(temps);
     // The traverser keeps at most kLdsStack + kSpillStack pending nodes per ray; a closest-hit descent stacks up to 3
     // siblings per level, so a tree deeper than that bound could lose hits.  Refuse it here instead.
     if ((uint32_t)max_depth > g->max_bvh_depth) {
-        drop_fresh();
+        release(fresh);
         char msg[200];
         snprintf(msg, sizeof(msg), "neb_gi_build_bvh: BVH4 depth %d exceeds the limit %u (the traversal stack holds %d entries, 3 per level)",
                  max_depth, g->max_bvh_depth, kLdsStack + kSpillStack);
@@ -890,11 +851,11 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             }
     }
     g->allocs.insert(g->allocs.end(), fresh.begin(), fresh.end());
-    g->view.tris = d_sorted;
+    g->view.tris = d_final;
     g->view.shade = d_shade;
     g->view.nodes = d_wide;
     g->view.root = root_code;
-    g->n_nodes = (uint32_t)wide.size();
+    g->n_nodes = n_wide;
     g->bvh_depth = (uint32_t)max_depth;
     g->built = true; // (h_tris stays: the scene can be rebuilt)
     return NEB_OK;
@@ -916,6 +877,14 @@ int neb_gi_bvh_depth(const neb_ctx* ctx, uint32_t* depth)
     if (!ctx || !ctx->gi || !depth)
         return NEB_ERR_STATE;
     *depth = ctx->gi->bvh_depth;
+    return NEB_OK;
+}
+
+int neb_gi_build_passes(const neb_ctx* ctx, uint32_t* passes)
+{
+    if (!ctx || !ctx->gi || !passes)
+        return NEB_ERR_STATE;
+    *passes = ctx->gi->build_passes;
     return NEB_OK;
 }
 

@@ -99,6 +99,11 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_bvh_depth(self._ctx, C.byref(d)), "neb_gi_bvh_depth")
         return d.value
 
+    def build_passes(self):
+        d = C.c_uint32()
+        self._check(self._lib.neb_gi_build_passes(self._ctx, C.byref(d)), "neb_gi_build_passes")
+        return d.value
+
     # ---- DeferredRenderer::BeginFrame (src/DeferredRenderer.cpp:89-149) ----
     def begin_frame(self, info):
         self.info = info

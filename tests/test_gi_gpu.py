@@ -402,3 +402,42 @@ def test_hip_matches_the_numpy_restatement_golden(name):
     assert np.array_equal(got[..., 3], d["radiance_in"][..., 3])
     assert rel_l2(got[same][:, :3], d["radiance"][same]) <= 2e-5
     r.destroy()
+
+
+def test_device_build_handles_degenerate_inputs():
+    """The PLOC build on scenes where every merge cost ties: thousands of IDENTICAL triangles (the symmetric tie-break
+    pairs neighbours, so the cluster count still halves per pass) and a long row of equal quads.  Which of the coincident
+    triangles a ray reports is arbitrary, so distances and radiance are compared, not primitive ids."""
+    W, H = 96, 64
+    cam = S.orbit_camera()
+    gb = OracleTracer(S.cornell_standin(textured=True)).gbuffer(W, H, cam)
+    for kind in ("identical", "row"):
+        sc = S.Scene(kind)
+        m = sc.add_material(albedo=(0.6, 0.5, 0.4, 1))
+        if kind == "identical":
+            n = 3000
+            P = np.tile(np.array([[-6, 1.8, -6], [6, 1.8, -6], [0, 1.8, 6]], np.float32), (n, 1))
+            I = np.arange(3 * n)
+        else:
+            n = 4096
+            x = np.arange(n, dtype=np.float32)[:, None] * 0.01 - 20.0
+            q = np.array([[0, 1.8, -3], [0.01, 1.8, -3], [0.01, 1.8, 3], [0, 1.8, 3]], np.float32)
+            P = (q[None] + np.concatenate([x, np.zeros((n, 2), np.float32)], 1)[:, None, :]).reshape(-1, 3)
+            I = (np.arange(n)[:, None] * 4 + np.array([0, 1, 2, 0, 2, 3])[None]).reshape(-1)
+        sc.add_geometry(P, np.tile(np.array([[0, -1, 0]], np.float32), (len(P), 1)), np.zeros((len(P), 2), np.float32), I, m)
+        r = DeferredRenderer()
+        r.init(W, H)
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=2))
+        assert r.scene_info()[0] == len(I) // 3
+        assert 3 * r.bvh_depth() <= 64 and r.build_passes() <= 40, (r.bvh_depth(), r.build_passes())
+        upload_gbuffer(r, gb)
+        r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+        r.set_debug_hits(True)
+        r.submit_commands_gi_pathtrace()
+        got, hits = r.svgf.download(PLANE_RADIANCE), r.download_hits()
+        want, ohits, _ = OracleTracer(sc).gi(gb, r.global_constants())
+        assert np.array_equal(hits["t"] > 0, ohits["t"] > 0) and (hits["t"] > 0).mean() > 0.05
+        hit = hits["t"] > 0
+        assert np.abs(hits["t"][hit] - ohits["t"][hit]).max() <= 1e-4 * np.abs(ohits["t"][hit]).max()
+        assert rel_l2(got[..., :3], want[..., :3]) <= 2e-5
+        r.destroy()
