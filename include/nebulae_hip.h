@@ -210,8 +210,8 @@ typedef struct neb_camera {
 int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_geoms, const neb_material_desc* mats,
                      uint32_t n_mats, const neb_texture_desc* texs, uint32_t n_texs);
 /* DeferredRenderer::InitRTAccelerationStructures (src/DeferredRenderer.cpp:978-1030): builds the acceleration structure --
- * on the device, as the reference's driver does (RTAccelerationStructureBuilder.cpp:73-130): Morton sort, PLOC clustering,
- * collapse to 4-wide nodes; the host reads back one counter per pass, never a node.
+ * on the device, as the reference's driver does (RTAccelerationStructureBuilder.cpp:73-130): Morton sort, binned-SAH splits
+ * level by level, collapse to 4-wide nodes; the host reads back one counter per pass, never a node.
  * One-time setup: enqueues on `stream` and SYNCHRONISES it before returning.  On failure the scene keeps its previous
  * state (unbuilt, or the previous valid tree); calling it again rebuilds. */
 int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream);
@@ -221,7 +221,7 @@ int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3]);
 /* Inner-node levels of the BVH4 of the last successful build.  neb_gi_build_bvh returns NEB_ERR_OUT_OF_RANGE (and keeps the
  * previous tree, if any) when the depth exceeds what the traversal stack covers: 21, or "gi_max_bvh_depth". */
 int neb_gi_bvh_depth(const neb_ctx* ctx, uint32_t* depth);
-/* Clustering passes (PLOC iterations) the last successful build took: diagnostics. */
+/* Passes (levels of the binary SAH tree) the last successful build took: diagnostics. */
 int neb_gi_build_passes(const neb_ctx* ctx, uint32_t* passes);
 /* DeferredRenderer::SubmitCommandsGIPathtrace: radiance[cur].rgb += mean over spp of the path radiance
  * (stands in for NRC Resolve, DeferredRenderer.cpp:586).  Reads the ALBEDO / ROUGH_METAL / WORLDPOS planes and

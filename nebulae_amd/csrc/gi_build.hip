@@ -1,11 +1,12 @@
 // gi_build.hip -- scene upload and acceleration structure of the GI path (one-time setup).
 //
 // Reference: src/nri/GIProcessedScene.cpp:16-137 (scene tables); RTAccelerationStructureBuilder.cpp:14-130 (driver
-// BVH, built on the GPU once -> replaced by an own device build: Morton sort, PLOC clustering, collapse to a 4-wide
+// BVH, built on the GPU once -> replaced by an own device build: Morton sort, binned-SAH splits, collapse to a 4-wide
 // tree, all in HIP kernels).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "gi_device.h"
 
@@ -139,26 +140,43 @@ __global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint6
 }
 
 // ------------------------------------------------------------------------------------------------
-// Topology: PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) over the Morton-sorted triangles, on
-// the device.  Clusters live in an array in Morton order; every iteration each cluster finds, within +-kPlocRadius
-// positions, the neighbour whose merged box has the smallest surface area; mutual pairs merge into a new binary node;
-// the array is compacted (prefix sum) and the loop repeats until one cluster -- the root -- is left.  Unlike the Morton
-// splits of an LBVH this is driven by box area throughout (near the root too, where every ray pays), and unlike a
-// top-down SAH sweep it is a few dozen data-parallel passes.
-// Binary nodes: [0, n) = the sorted triangles, [n, 2n - 1) = merges in creation order.
+// Topology: top-down binned-SAH build on the device, one level per pass.
+// A segment = a run of the primitive index array that still has to be split, owned by one binary node.  Per level one
+// workgroup per segment (a) reduces the centroid bounds, (b) bins the primitives' boxes into kSahBins bins per axis in
+// LDS, (c) evaluates the surface-area heuristic  A_left * N_left + A_right * N_right  at every bin boundary of the three
+// axes, (d) partitions the run in place order (stable) into the other index array.  A second kernel then creates the
+// child nodes and next level's segments at positions given by a prefix sum, so node numbering -- hence the whole tree
+// -- is deterministic (every GPU of a strip group must build the same tree: ties between coincident hits are
+// resolved by traversal order).  Splitting continues down to runs of <= 2 triangles, the leaf size of the BVH4.
+// The first levels have few, long segments and use a fraction of the chip; all levels together take a few milliseconds
+// at 262 k triangles -- against ~0.3 s for the host sweep-SAH pass this replaces.
+// (Measured first and dropped: PLOC, agglomerative clustering over the Morton order.  At search radius 8 / 16 / 64 the
+// closest-hit pass took 464 / 481 / 519 us, no better than the plain Karras LBVH (464 us) and far from the SAH
+// sweep (381 us): on the stand-in's regular tessellations every neighbouring pair ties, and a wider window only adds
+// irregular merges.)
+// Binary nodes: [0, n) = the triangles in Morton order, [n, 2n - 1) = inner nodes in creation order; node n is the root.
 // ------------------------------------------------------------------------------------------------
-#ifndef NEB_PLOC_RADIUS
-#define NEB_PLOC_RADIUS 16
+#ifndef NEB_SAH_BINS
+#define NEB_SAH_BINS 32
 #endif
-constexpr int kPlocRadius = NEB_PLOC_RADIUS;
+constexpr int kSahBins = NEB_SAH_BINS;
+constexpr int kSahThreads = 256;
 
-struct PlocNodes {
-    float4* lo;      // {min.xyz, left child as int bits}   (leaves: children = -1)
+struct PlocNodes { // (binary tree under construction; the name predates the SAH builder)
+    float4* lo;      // {min.xyz, left child as int bits}   (triangles: children = -1)
     float4* hi;      // {max.xyz, right child as int bits}
     uint32_t* size;  // triangles below the node
 };
 
-__global__ void ploc_init_kernel(const float4* __restrict__ tris, uint32_t n, PlocNodes N, uint32_t* clusters)
+struct SahSegment {
+    uint32_t begin, end, node;
+};
+struct SahSplit { // result of one segment's split
+    uint32_t mid; // left = [begin, mid), right = [mid, end)
+    float lbox[6], rbox[6];
+};
+
+__global__ void sah_init_kernel(const float4* __restrict__ tris, uint32_t n, PlocNodes N, uint32_t* idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -168,7 +186,7 @@ __global__ void ploc_init_kernel(const float4* __restrict__ tris, uint32_t n, Pl
     N.lo[i] = make_float4(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)), __int_as_float(-1));
     N.hi[i] = make_float4(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)), __int_as_float(-1));
     N.size[i] = 1u;
-    clusters[i] = i;
+    idx[i] = i;
 }
 
 __device__ __forceinline__ float box_half_area(float3 lo, float3 hi)
@@ -177,103 +195,255 @@ __device__ __forceinline__ float box_half_area(float3 lo, float3 hi)
     return dx * dy + dy * dz + dz * dx;
 }
 
-// state[0] = live clusters, state[1] = next free node id (read side of the iteration; the apply kernel writes the other half)
-__global__ __launch_bounds__(256) void ploc_nearest_kernel(PlocNodes N, const uint32_t* __restrict__ clusters, const uint32_t* __restrict__ state,
-                                                           uint32_t* nearest)
+// order-preserving float <-> uint map (atomicMin / atomicMax on LDS words)
+__device__ __forceinline__ uint32_t float_to_ordered(float f)
 {
-    __shared__ float3 s_lo[256 + 2 * kPlocRadius], s_hi[256 + 2 * kPlocRadius];
-    const uint32_t m = state[0];
-    const int base = (int)(blockIdx.x * 256u) - kPlocRadius;
-    if (blockIdx.x * 256u >= m)
-        return;
-    for (int k = threadIdx.x; k < 256 + 2 * kPlocRadius; k += 256) {
-        const int j = base + k;
-        if (j >= 0 && j < (int)m) {
-            const uint32_t c = clusters[j];
-            const float4 lo = N.lo[c], hi = N.hi[c];
-            s_lo[k] = f3(lo.x, lo.y, lo.z);
-            s_hi[k] = f3(hi.x, hi.y, hi.z);
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__device__ __forceinline__ int sah_bin(float c, float cmin, float scale) { return min(kSahBins - 1, max(0, (int)((c - cmin) * scale))); }
+
+__global__ __launch_bounds__(kSahThreads) void sah_split_kernel(PlocNodes N, const SahSegment* __restrict__ segs, const uint32_t* __restrict__ idx_in,
+                                                                uint32_t* __restrict__ idx_out, SahSplit* __restrict__ splits)
+{
+    // bins: axis 0..2 = x, y, z by centroid; axis 3 = by position (first / second half of the run): the fallback when all
+    // centroids coincide.  Per bin: box lo.xyz, hi.xyz as ordered uints, and a count.
+    __shared__ uint32_t s_lo[4][kSahBins][3], s_hi[4][kSahBins][3], s_cnt[4][kSahBins];
+    __shared__ uint32_t s_cmin[3], s_cmax[3];
+    __shared__ float s_cost[kSahThreads];
+    __shared__ int s_pick[kSahThreads];
+    __shared__ uint32_t s_scan[kSahThreads];
+    __shared__ uint32_t s_run[2];
+    const SahSegment sg = segs[blockIdx.x];
+    const uint32_t begin = sg.begin, end = sg.end, cnt = end - begin, half = begin + cnt / 2;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 4 * kSahBins; k += kSahThreads) {
+        const int ax = k / kSahBins, b = k % kSahBins;
+        for (int q = 0; q < 3; ++q) {
+            s_lo[ax][b][q] = 0xffffffffu;
+            s_hi[ax][b][q] = 0u;
+        }
+        s_cnt[ax][b] = 0u;
+    }
+    if (tid < 3) {
+        s_cmin[tid] = 0xffffffffu;
+        s_cmax[tid] = 0u;
+    }
+    __syncthreads();
+    // (a) centroid bounds
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = begin + tid; i < end; i += kSahThreads) {
+            const uint32_t p = idx_in[i];
+            const float4 lo = N.lo[p], hi = N.hi[p];
+            const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+            for (int q = 0; q < 3; ++q) {
+                mn[q] = fminf(mn[q], c[q]);
+                mx[q] = fmaxf(mx[q], c[q]);
+            }
+        }
+        for (int q = 0; q < 3; ++q) {
+            atomicMin(&s_cmin[q], float_to_ordered(mn[q]));
+            atomicMax(&s_cmax[q], float_to_ordered(mx[q]));
         }
     }
     __syncthreads();
-    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-    if (i >= (int)m)
-        return;
-    const float3 lo = s_lo[threadIdx.x + kPlocRadius], hi = s_hi[threadIdx.x + kPlocRadius];
-    // The partner minimises a key that is a SYMMETRIC function of the unordered pair -- (merged area, not an aligned pair
-    // {2k, 2k+1}, index distance, smaller index) -- so the globally smallest pair always picks each other and every
-    // iteration makes progress; the "aligned pair" term makes a field of identical boxes halve per iteration instead of
-    // losing one pair at a time.
-    float best = INFINITY;
-    uint32_t best_key = 0xffffffffu;
-    int best_j = -1, best_mn = 0x7fffffff;
-    for (int d = -kPlocRadius; d <= kPlocRadius; ++d) {
-        const int j = i + d;
-        if (d == 0 || j < 0 || j >= (int)m)
-            continue;
-        const float3 l2 = s_lo[threadIdx.x + kPlocRadius + d], h2 = s_hi[threadIdx.x + kPlocRadius + d];
-        const float area = box_half_area(f3(fminf(lo.x, l2.x), fminf(lo.y, l2.y), fminf(lo.z, l2.z)), f3(fmaxf(hi.x, h2.x), fmaxf(hi.y, h2.y), fmaxf(hi.z, h2.z)));
-        const int mn = min(i, j);
-        const uint32_t dist = (uint32_t)abs(d);
-        const uint32_t key = ((((mn & 1) == 0 && dist == 1u) ? 0u : 1u) << 8) | dist;
-        if (area < best || (area == best && (key < best_key || (key == best_key && mn < best_mn)))) {
-            best = area;
-            best_key = key;
-            best_j = j;
-            best_mn = mn;
+    float cmin[3], scale[3];
+    for (int q = 0; q < 3; ++q) {
+        cmin[q] = ordered_to_float(s_cmin[q]);
+        const float ext = ordered_to_float(s_cmax[q]) - cmin[q];
+        scale[q] = ext > 0.0f ? (float)kSahBins / ext : 0.0f; // a flat axis puts everything into bin 0: no split there
+    }
+    // (b) binning
+    for (uint32_t i = begin + tid; i < end; i += kSahThreads) {
+        const uint32_t p = idx_in[i];
+        const float4 lo = N.lo[p], hi = N.hi[p];
+        const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+        const uint32_t l[3] = {float_to_ordered(lo.x), float_to_ordered(lo.y), float_to_ordered(lo.z)};
+        const uint32_t h[3] = {float_to_ordered(hi.x), float_to_ordered(hi.y), float_to_ordered(hi.z)};
+        for (int ax = 0; ax < 4; ++ax) {
+            const int b = ax < 3 ? sah_bin(c[ax], cmin[ax], scale[ax]) : (i < half ? 0 : 1);
+            for (int q = 0; q < 3; ++q) {
+                atomicMin(&s_lo[ax][b][q], l[q]);
+                atomicMax(&s_hi[ax][b][q], h[q]);
+            }
+            atomicAdd(&s_cnt[ax][b], 1u);
         }
     }
-    nearest[i] = (uint32_t)best_j; // (m >= 2 here, so a partner exists)
-}
-
-// flags: low 32 bits = 1 if position i survives into the next cluster array, high 32 bits = 1 if it creates a node
-__global__ void ploc_flags_kernel(const uint32_t* __restrict__ nearest, const uint32_t* __restrict__ state, uint32_t n_max, unsigned long long* flags)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_max)
-        return;
-    const uint32_t m = state[0];
-    unsigned long long f = 0ull;
-    if (i < m) {
-        const uint32_t j = nearest[i];
-        const bool mutual = nearest[j] == i;
-        if (!mutual)
-            f = 1ull;
-        else if (i < j)
-            f = 1ull | (1ull << 32);
+    __syncthreads();
+    // (c) SAH at every bin boundary: candidate = (axis, first bin of the right side)
+    {
+        float cost = INFINITY;
+        int pick = -1;
+        for (int cand = tid; cand < 3 * (kSahBins - 1); cand += kSahThreads) {
+            const int ax = cand / (kSahBins - 1), s = cand % (kSahBins - 1) + 1;
+            float3 llo = f3(INFINITY, INFINITY, INFINITY), lhi = f3(-INFINITY, -INFINITY, -INFINITY), rlo = llo, rhi = lhi;
+            uint32_t nl = 0, nr = 0;
+            for (int b = 0; b < kSahBins; ++b) {
+                const uint32_t c = s_cnt[ax][b];
+                if (!c)
+                    continue;
+                const float3 blo = f3(ordered_to_float(s_lo[ax][b][0]), ordered_to_float(s_lo[ax][b][1]), ordered_to_float(s_lo[ax][b][2]));
+                const float3 bhi = f3(ordered_to_float(s_hi[ax][b][0]), ordered_to_float(s_hi[ax][b][1]), ordered_to_float(s_hi[ax][b][2]));
+                if (b < s) {
+                    llo = f3(fminf(llo.x, blo.x), fminf(llo.y, blo.y), fminf(llo.z, blo.z));
+                    lhi = f3(fmaxf(lhi.x, bhi.x), fmaxf(lhi.y, bhi.y), fmaxf(lhi.z, bhi.z));
+                    nl += c;
+                } else {
+                    rlo = f3(fminf(rlo.x, blo.x), fminf(rlo.y, blo.y), fminf(rlo.z, blo.z));
+                    rhi = f3(fmaxf(rhi.x, bhi.x), fmaxf(rhi.y, bhi.y), fmaxf(rhi.z, bhi.z));
+                    nr += c;
+                }
+            }
+            if (nl && nr) {
+                const float cst = box_half_area(llo, lhi) * (float)nl + box_half_area(rlo, rhi) * (float)nr;
+                if (cst < cost) {
+                    cost = cst;
+                    pick = cand;
+                }
+            }
+        }
+        s_cost[tid] = cost;
+        s_pick[tid] = pick;
     }
-    flags[i] = f;
+    __syncthreads();
+    for (int off = kSahThreads / 2; off > 0; off >>= 1) { // argmin; ties -> the smaller candidate index (deterministic)
+        if (tid < off) {
+            const float c2 = s_cost[tid + off];
+            const int p2 = s_pick[tid + off];
+            if (p2 >= 0 && (s_pick[tid] < 0 || c2 < s_cost[tid] || (c2 == s_cost[tid] && p2 < s_pick[tid]))) {
+                s_cost[tid] = c2;
+                s_pick[tid] = p2;
+            }
+        }
+        __syncthreads();
+    }
+    const int pick = s_pick[0];
+    const int axis = pick >= 0 ? pick / (kSahBins - 1) : 3;
+    const int split = pick >= 0 ? pick % (kSahBins - 1) + 1 : 1;
+    uint32_t n_left = 0;
+    for (int b = 0; b < split; ++b)
+        n_left += s_cnt[axis][b];
+    if (tid == 0) {
+        s_run[0] = 0u;
+        s_run[1] = 0u;
+        SahSplit sp;
+        sp.mid = begin + n_left;
+        float l[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int b = 0; b < kSahBins; ++b) {
+            if (!s_cnt[axis][b])
+                continue;
+            float* d = b < split ? l : r;
+            for (int q = 0; q < 3; ++q) {
+                d[q] = fminf(d[q], ordered_to_float(s_lo[axis][b][q]));
+                d[3 + q] = fmaxf(d[3 + q], ordered_to_float(s_hi[axis][b][q]));
+            }
+        }
+        for (int q = 0; q < 6; ++q) {
+            sp.lbox[q] = l[q];
+            sp.rbox[q] = r[q];
+        }
+        splits[blockIdx.x] = sp;
+    }
+    __syncthreads();
+    // (d) stable partition of the run into idx_out
+    for (uint32_t base = begin; base < end; base += kSahThreads) {
+        const uint32_t i = base + tid;
+        uint32_t p = 0, flag = 0;
+        const bool in = i < end;
+        if (in) {
+            p = idx_in[i];
+            int b;
+            if (axis < 3) {
+                const float4 lo = N.lo[p], hi = N.hi[p];
+                const float c = axis == 0 ? 0.5f * (lo.x + hi.x) : (axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
+                b = sah_bin(c, cmin[axis], scale[axis]);
+            } else {
+                b = i < half ? 0 : 1;
+            }
+            flag = b < split ? 1u : 0u;
+        }
+        s_scan[tid] = flag;
+        __syncthreads();
+        for (int off = 1; off < kSahThreads; off <<= 1) { // inclusive scan of the flags
+            const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t incl = s_scan[tid], lefts_before = incl - flag, chunk_lefts = s_scan[kSahThreads - 1];
+        const uint32_t run_l = s_run[0], run_r = s_run[1];
+        if (in) {
+            const uint32_t dst = flag ? begin + run_l + lefts_before : begin + n_left + run_r + ((uint32_t)tid - lefts_before);
+            idx_out[dst] = p;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t chunk = min((uint32_t)kSahThreads, end - base);
+            s_run[0] = run_l + chunk_lefts;
+            s_run[1] = run_r + (chunk - chunk_lefts);
+        }
+        __syncthreads();
+    }
 }
 
-__global__ void ploc_apply_kernel(PlocNodes N, const uint32_t* __restrict__ clusters, uint32_t* __restrict__ clusters_out, const uint32_t* __restrict__ nearest,
-                                  const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ scan, const uint32_t* __restrict__ state,
-                                  uint32_t* __restrict__ state_out)
+// per segment: how many child nodes it creates (children of >= 2 triangles) and how many of them go on (>= 3 triangles),
+// packed (nodes << 32 | segments) for one prefix sum
+__global__ void sah_count_kernel(const SahSegment* __restrict__ segs, const SahSplit* __restrict__ splits, uint32_t n_segs, unsigned long long* counts)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t m = state[0];
-    if (i >= m)
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_segs)
         return;
-    const unsigned long long f = flags[i], sc = scan[i];
-    if (i == m - 1) {
-        const unsigned long long tot = sc + f;
+    const uint32_t cl = splits[k].mid - segs[k].begin, cr = segs[k].end - splits[k].mid;
+    const unsigned long long nodes = (cl >= 2 ? 1u : 0u) + (cr >= 2 ? 1u : 0u), more = (cl >= 3 ? 1u : 0u) + (cr >= 3 ? 1u : 0u);
+    counts[k] = (nodes << 32) | more;
+}
+
+// state[0] = segments of the next level, state[1] = next free node id
+__global__ void sah_emit_kernel(PlocNodes N, const SahSegment* __restrict__ segs, const SahSplit* __restrict__ splits, uint32_t n_segs,
+                                const unsigned long long* __restrict__ counts, const unsigned long long* __restrict__ scan, const uint32_t* __restrict__ idx,
+                                const uint32_t* __restrict__ state, uint32_t* __restrict__ state_out, SahSegment* __restrict__ next_segs)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_segs)
+        return;
+    const SahSegment sg = segs[k];
+    const SahSplit sp = splits[k];
+    uint32_t node = state[1] + (uint32_t)(scan[k] >> 32), slot = (uint32_t)scan[k];
+    if (k == n_segs - 1) {
+        const unsigned long long tot = scan[k] + counts[k];
         state_out[0] = (uint32_t)tot;
         state_out[1] = state[1] + (uint32_t)(tot >> 32);
     }
-    if (!(f & 1ull))
-        return;
-    const uint32_t pos = (uint32_t)sc;
-    const uint32_t ci = clusters[i];
-    if (f >> 32) {
-        const uint32_t cj = clusters[nearest[i]];
-        const uint32_t node = state[1] + (uint32_t)(sc >> 32);
-        const float4 l1 = N.lo[ci], h1 = N.hi[ci], l2 = N.lo[cj], h2 = N.hi[cj];
-        N.lo[node] = make_float4(fminf(l1.x, l2.x), fminf(l1.y, l2.y), fminf(l1.z, l2.z), __int_as_float((int)ci));
-        N.hi[node] = make_float4(fmaxf(h1.x, h2.x), fmaxf(h1.y, h2.y), fmaxf(h1.z, h2.z), __int_as_float((int)cj));
-        N.size[node] = N.size[ci] + N.size[cj];
-        clusters_out[pos] = node;
-    } else {
-        clusters_out[pos] = ci;
+    int ref[2];
+    const uint32_t b[2] = {sg.begin, sp.mid}, e[2] = {sp.mid, sg.end};
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t c = e[side] - b[side];
+        if (c == 1u) {
+            ref[side] = (int)idx[b[side]];
+            continue;
+        }
+        const float* bx = side == 0 ? sp.lbox : sp.rbox;
+        const uint32_t id = node++;
+        ref[side] = (int)id;
+        N.size[id] = c;
+        if (c == 2u) { // a pair: its children are the two triangles; it is not split further
+            N.lo[id] = make_float4(bx[0], bx[1], bx[2], __int_as_float((int)idx[b[side]]));
+            N.hi[id] = make_float4(bx[3], bx[4], bx[5], __int_as_float((int)idx[b[side] + 1]));
+        } else {     // children are filled in when its own segment is split, one level down
+            N.lo[id] = make_float4(bx[0], bx[1], bx[2], __int_as_float(-1));
+            N.hi[id] = make_float4(bx[3], bx[4], bx[5], __int_as_float(-1));
+            next_segs[slot++] = SahSegment{b[side], e[side], id};
+        }
     }
+    // the split node itself: keep its box, set its children
+    float4 lo = N.lo[sg.node], hi = N.hi[sg.node];
+    lo.w = __int_as_float(ref[0]);
+    hi.w = __int_as_float(ref[1]);
+    N.lo[sg.node] = lo;
+    N.hi[sg.node] = hi;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -658,8 +828,9 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     }
     // Everything is built into locals and committed to g->view only at the very end, on success: a failed (re)build
     // leaves the scene exactly as it was -- still unbuilt, or still holding the previous, valid tree.
-    // The whole build runs on the device: Morton keys -> radix sort -> PLOC merges -> BVH4 collapse + leaf-order triangle
-    // permutation -> shading records.  The host only reads back one counter per pass (live clusters / level size).
+    // The whole build runs on the device: Morton keys -> radix sort -> binned-SAH splits level by level -> BVH4 collapse +
+    // leaf-order triangle permutation -> shading records.  The host only reads back one counter per pass (segments / nodes of
+    // the next level).
     std::vector<void*> temps, fresh; // freed at the end / device arrays that outlive the build (freed again on failure)
     bool oom = false;
     auto dalloc = [&](size_t bytes, bool keep) -> void* {
@@ -686,11 +857,12 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     N.lo = (float4*)dalloc(n2 * 16, false);
     N.hi = (float4*)dalloc(n2 * 16, false);
     N.size = (uint32_t*)dalloc(n2 * 4, false);
-    uint32_t* d_clusters[2] = {(uint32_t*)dalloc((size_t)n * 4, false), (uint32_t*)dalloc((size_t)n * 4, false)};
-    uint32_t* d_nearest = (uint32_t*)dalloc((size_t)n * 4, false);
+    uint32_t* d_idx[2] = {(uint32_t*)dalloc((size_t)n * 4, false), (uint32_t*)dalloc((size_t)n * 4, false)};
+    SahSegment* d_segs[2] = {(SahSegment*)dalloc((size_t)n * sizeof(SahSegment), false), (SahSegment*)dalloc((size_t)n * sizeof(SahSegment), false)};
+    SahSplit* d_splits = (SahSplit*)dalloc((size_t)n * sizeof(SahSplit), false);
     unsigned long long* d_flags = (unsigned long long*)dalloc((size_t)n * 8, false);
     unsigned long long* d_scan = (unsigned long long*)dalloc((size_t)n * 8, false);
-    uint32_t* d_state = (uint32_t*)dalloc(8 * 4, false); // two {live clusters, next node id} pairs + the collapse's level counter
+    uint32_t* d_state = (uint32_t*)dalloc(8 * 4, false); // two {segments of the next level, next node id} pairs + the collapse's level counter
     Bvh4Node* d_wide_tmp = (Bvh4Node*)dalloc((size_t)n * sizeof(Bvh4Node), false); // (at most n - 1 wide nodes)
     uint32_t* d_qnode = (uint32_t*)dalloc((size_t)n * 4, false);
     uint32_t* d_qoff = (uint32_t*)dalloc((size_t)n * 4, false);
@@ -741,34 +913,52 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     BUILD_HIP(hipcub::DeviceRadixSort::SortKeys(d_cub, cub_bytes, d_keys, d_keys2, (int)n, 0, 64, stream));
     hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, d_keys2, n, (1ull << index_bits) - 1ull, d_sorted);
     BUILD_HIP(hipGetLastError());
-    // ---- PLOC ----
-    hipLaunchKernelGGL(ploc_init_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)d_sorted, n, N, d_clusters[0]);
+    // ---- binary topology: binned SAH, one level per pass ----
+    hipLaunchKernelGGL(sah_init_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)d_sorted, n, N, d_idx[0]);
     BUILD_HIP(hipGetLastError());
-    uint32_t h_state[2] = {n, n};
-    BUILD_HIP(hipMemcpyAsync(d_state, h_state, sizeof(h_state), hipMemcpyHostToDevice, stream));
-    uint32_t m = n, iter = 0;
-    while (m > 1) {
-        const uint32_t* rs = d_state + 2 * (iter & 1u);
-        uint32_t* ws = d_state + 2 * ((iter + 1u) & 1u);
-        const uint32_t* cin = d_clusters[iter & 1u];
-        uint32_t* cout = d_clusters[(iter + 1u) & 1u];
-        const dim3 grid((m + 255) / 256);
-        hipLaunchKernelGGL(ploc_nearest_kernel, grid, dim3(256), 0, stream, N, cin, rs, d_nearest);
-        hipLaunchKernelGGL(ploc_flags_kernel, grid, dim3(256), 0, stream, (const uint32_t*)d_nearest, rs, m, d_flags);
-        BUILD_HIP(hipGetLastError());
-        BUILD_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_flags, d_scan, (int)m, stream));
-        hipLaunchKernelGGL(ploc_apply_kernel, grid, dim3(256), 0, stream, N, cin, cout, (const uint32_t*)d_nearest, (const unsigned long long*)d_flags,
-                           (const unsigned long long*)d_scan, rs, ws);
-        BUILD_HIP(hipGetLastError());
-        uint32_t m_new = 0;
-        BUILD_HIP(hipMemcpyAsync(&m_new, ws, 4, hipMemcpyDeviceToHost, stream));
-        BUILD_HIP(hipStreamSynchronize(stream));
-        if (m_new == 0 || m_new >= m)
-            return bail(NEB_ERR_HIP, "neb_gi_build_bvh: PLOC made no progress (internal error)");
-        m = m_new;
-        ++iter;
+    uint32_t passes = 0;
+    const uint32_t root_node = n; // (only meaningful when n > kMaxLeafTris)
+    if (n > (uint32_t)kMaxLeafTris) {
+        const SahSegment root_seg{0u, n, root_node};
+        float minus_one;
+        const int m1 = -1;
+        memcpy(&minus_one, &m1, 4);
+        const float4 root_lo = make_float4(g->scene_min[0], g->scene_min[1], g->scene_min[2], minus_one);
+        const float4 root_hi = make_float4(g->scene_max[0], g->scene_max[1], g->scene_max[2], minus_one);
+        const uint32_t h_state[2] = {1u, n + 1u};
+        BUILD_HIP(hipMemcpyAsync(d_segs[0], &root_seg, sizeof(root_seg), hipMemcpyHostToDevice, stream));
+        BUILD_HIP(hipMemcpyAsync(N.lo + root_node, &root_lo, 16, hipMemcpyHostToDevice, stream));
+        BUILD_HIP(hipMemcpyAsync(N.hi + root_node, &root_hi, 16, hipMemcpyHostToDevice, stream));
+        BUILD_HIP(hipMemcpyAsync(N.size + root_node, &n, 4, hipMemcpyHostToDevice, stream));
+        BUILD_HIP(hipMemcpyAsync(d_state, h_state, sizeof(h_state), hipMemcpyHostToDevice, stream));
+        BUILD_HIP(hipStreamSynchronize(stream)); // (the small host buffers above live on this stack frame)
+        uint32_t n_segs = 1;
+        while (n_segs > 0) {
+            if (passes > 4096u)
+                return bail(NEB_ERR_HIP, "neb_gi_build_bvh: the SAH build does not terminate (internal error)");
+            const uint32_t* rs = d_state + 2 * (passes & 1u);
+            uint32_t* ws = d_state + 2 * ((passes + 1u) & 1u);
+            const SahSegment* segs = d_segs[passes & 1u];
+            const uint32_t* idx_in = d_idx[passes & 1u];
+            uint32_t* idx_out = d_idx[(passes + 1u) & 1u];
+            hipLaunchKernelGGL(sah_split_kernel, dim3(n_segs), dim3(kSahThreads), 0, stream, N, segs, idx_in, idx_out, d_splits);
+            const dim3 grid((n_segs + 255) / 256);
+            hipLaunchKernelGGL(sah_count_kernel, grid, dim3(256), 0, stream, segs, (const SahSplit*)d_splits, n_segs, d_flags);
+            BUILD_HIP(hipGetLastError());
+            BUILD_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_flags, d_scan, (int)n_segs, stream));
+            hipLaunchKernelGGL(sah_emit_kernel, grid, dim3(256), 0, stream, N, segs, (const SahSplit*)d_splits, n_segs, (const unsigned long long*)d_flags,
+                               (const unsigned long long*)d_scan, (const uint32_t*)idx_out, rs, ws, d_segs[(passes + 1u) & 1u]);
+            BUILD_HIP(hipGetLastError());
+            uint32_t next = 0;
+            BUILD_HIP(hipMemcpyAsync(&next, ws, 4, hipMemcpyDeviceToHost, stream));
+            BUILD_HIP(hipStreamSynchronize(stream));
+            if (next > n)
+                return bail(NEB_ERR_HIP, "neb_gi_build_bvh: segment bound exceeded (internal error)");
+            n_segs = next;
+            ++passes;
+        }
     }
-    g->build_passes = iter;
+    g->build_passes = passes;
     // ---- collapse to BVH4, triangles into leaf order ----
     int root_code = 0, max_depth = 0;
     uint32_t n_wide = 0;
@@ -788,8 +978,9 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
         a.inner_count = d_icount;
         a.inner_scan = d_iscan;
         a.level_state = d_state + 4;
-        BUILD_HIP(hipMemcpyAsync(d_qnode, d_clusters[iter & 1u], 4, hipMemcpyDeviceToDevice, stream)); // the root = the last cluster
+        BUILD_HIP(hipMemcpyAsync(d_qnode, &root_node, 4, hipMemcpyHostToDevice, stream));
         BUILD_HIP(hipMemsetAsync(d_qoff, 0, 4, stream));
+        BUILD_HIP(hipStreamSynchronize(stream));
         uint32_t level_start = 0, level_count = 1;
         while (level_count > 0) {
             ++max_depth;

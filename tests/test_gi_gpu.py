@@ -405,8 +405,8 @@ def test_hip_matches_the_numpy_restatement_golden(name):
 
 
 def test_device_build_handles_degenerate_inputs():
-    """The PLOC build on scenes where every merge cost ties: thousands of IDENTICAL triangles (the symmetric tie-break
-    pairs neighbours, so the cluster count still halves per pass) and a long row of equal quads.  Which of the coincident
+    """The device SAH build on scenes that defeat spatial splitting: thousands of IDENTICAL triangles (all centroids
+    coincide: the builder falls back to halving the run) and a long row of equal quads.  Which of the coincident
     triangles a ray reports is arbitrary, so distances and radiance are compared, not primitive ids."""
     W, H = 96, 64
     cam = S.orbit_camera()
@@ -429,7 +429,7 @@ def test_device_build_handles_degenerate_inputs():
         r.init(W, H)
         r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=2))
         assert r.scene_info()[0] == len(I) // 3
-        assert 3 * r.bvh_depth() <= 64 and r.build_passes() <= 40, (r.bvh_depth(), r.build_passes())
+        assert 3 * r.bvh_depth() <= 64 and r.build_passes() <= 64, (r.bvh_depth(), r.build_passes())
         upload_gbuffer(r, gb)
         r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
         r.set_debug_hits(True)

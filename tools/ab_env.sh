@@ -1,0 +1,22 @@
+#!/bin/bash
+# tuning only: per-kernel mean durations (rocprofv3 --kernel-trace --stats) of `python bench.py` under different environment
+# settings.  usage (GPU box):  bash tools/ab_env.sh "NEB_PLOC_BUDGET=0" "NEB_PLOC_BUDGET=8388608 NEB_PLOC_RADIUS=32" ...
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+k=0
+for setting in "$@"; do
+  k=$((k + 1))
+  d=gpurun_out/abenv_$k
+  rm -rf "$d"
+  ( for kv in $setting; do export "$kv"; done
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python bench.py --steps 24 --warmup 8 --cpu-frames 0 $AB_BENCH_FLAGS > "$d.log" 2>&1 ) || { tail -5 "$d.log"; exit 1; }
+  python - "$setting" "$d" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[2] + "/*/*kernel_stats.csv")[0]
+rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(f))}
+tot = {r["Name"]: float(r["TotalDurationNs"]) / 1e3 for r in csv.DictReader(open(f))}
+pick = lambda s: sum(v for k, v in rows.items() if s in k)
+build = sum(v for k, v in tot.items() if "ploc_" in k or "collapse_" in k)
+print("%-48s raygen_trace %.1f shade %.1f shadow %.1f  | build kernels %.0f us" % (sys.argv[1], pick("gi_raygen_trace"), pick("gi_shade"), pick("gi_shadow_trace"), build))
+PY
+done
