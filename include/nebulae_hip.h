@@ -51,7 +51,10 @@ typedef enum neb_plane {
     NEB_PLANE_ROUGH_METAL = 7, /* R16G16_FLOAT        4 B/px, 1 slot                              */
     NEB_PLANE_WORLDPOS = 8,    /* R16G16B16A16_FLOAT  8 B/px, 1 slot                              */
     NEB_PLANE_LDR = 9,         /* R8G8B8A8_UNORM      4 B/px, 1 slot (tonemapped back buffer, row f3) */
-    NEB_PLANE_COUNT = 10
+    NEB_PLANE_GEOMETRY = 10,   /* R32G32B32A32_FLOAT 16 B/px, 1 slot: {decoded shading normal.xyz, depth in [0,1]} of the current frame.
+                                  No reference counterpart: the temporal pass decodes normal[cur] / depth[cur] once per frame and the
+                                  a-trous levels read this instead of decoding them five times (read-only for callers). */
+    NEB_PLANE_COUNT = 11
 } neb_plane;
 
 /* Slot selectors for the 2-slot (ping-pong) planes. */
@@ -129,7 +132,9 @@ int neb_stream_synchronize(neb_ctx* ctx, neb_stream stream);
 /* ---- SVGF entry points (enqueue only) ---- */
 /* SVGFDenoiser::ResetHistory (SVGFDenoiser.cpp:49-64): radiance[hist] <- radiance[cur]. */
 int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream);
-/* SVGFDenoiser::SubmitTemporalAccumulation (SVGFDenoiser.cpp:66-131) over all resident rows. */
+/* SVGFDenoiser::SubmitTemporalAccumulation (SVGFDenoiser.cpp:66-131) over all resident rows.
+ * The G-buffer of the frame (normal[cur], depth[cur]) must be complete before this call, as the G-buffer pass precedes SVGF in the
+ * reference: the a-trous levels of the frame read the decoded copy this pass (or, for rows it did not cover, a lazy decode) made. */
 int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream);
 /* SVGFDenoiser::SubmitATrousComputeWavelet (SVGFDenoiser.cpp:133-203): all levels, all rows.
  * Only valid when the context holds the full image (row_begin == 0, row_end == height). */

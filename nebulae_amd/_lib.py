@@ -10,7 +10,7 @@ from . import build as _build
 
 NEB_OK = 0
 PLANE_RADIANCE, PLANE_NORMAL, PLANE_DEPTH, PLANE_MOMENTS, PLANE_VARIANCE, PLANE_SCRATCH = 0, 1, 2, 3, 4, 5
-PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS, PLANE_LDR = 6, 7, 8, 9
+PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS, PLANE_LDR, PLANE_GEOMETRY = 6, 7, 8, 9, 10
 SLOT_CURRENT, SLOT_HISTORY = -1, -2
 
 

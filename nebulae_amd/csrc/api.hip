@@ -20,6 +20,7 @@ const PlaneInfo kPlaneInfo[NEB_PLANE_COUNT] = {
     {4, 1},  // ROUGH_METAL  R16G16_FLOAT
     {8, 1},  // WORLDPOS     R16G16B16A16_FLOAT
     {4, 1},  // LDR          R8G8B8A8_UNORM
+    {16, 1}, // GEOMETRY     R32G32B32A32_FLOAT (decoded shading normal + depth of the current frame)
 };
 } // namespace neb
 
@@ -61,6 +62,7 @@ void marker_pop()
 using namespace neb;
 
 static thread_local std::string g_create_error;
+static void geometry_invalidate(neb_ctx* ctx);
 
 static int fail(neb_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -216,6 +218,7 @@ int neb_begin_frame(neb_ctx* ctx, uint32_t frame_index)
         return NEB_ERR_INVALID_ARG;
     ctx->cur = (int)(frame_index & 1u); // SVGFDenoiser.cpp:41-42
     ctx->hist = ctx->cur ^ 1;
+    geometry_invalidate(ctx); // a new frame has a new G-buffer
     return NEB_OK;
 }
 
@@ -313,6 +316,8 @@ int neb_get_plane(neb_ctx* ctx, int plane, int slot, void** dptr, size_t* pitch_
     const int s = resolve_slot(ctx, plane, slot);
     if (s < 0)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_get_plane: bad plane/slot");
+    if (plane == NEB_PLANE_NORMAL || plane == NEB_PLANE_DEPTH)
+        geometry_invalidate(ctx); // the caller may write through the pointer: decode again before the next a-trous level
     *dptr = ctx->planes[plane][s];
     if (pitch_bytes)
         *pitch_bytes = (size_t)ctx->W * kPlaneInfo[plane].bytes_per_px;
@@ -334,6 +339,8 @@ static int copy_rows(neb_ctx* ctx, int plane, int slot, uint32_t row0, uint32_t 
     const size_t pitch = (size_t)ctx->W * kPlaneInfo[plane].bytes_per_px;
     char* d = (char*)ctx->planes[plane][s] + (size_t)(row0 - ctx->row_begin) * pitch;
     NEB_GUARD(ctx);
+    if (upload && (plane == NEB_PLANE_NORMAL || plane == NEB_PLANE_DEPTH))
+        geometry_invalidate(ctx);
     if (upload)
         NEB_HIP(ctx, hipMemcpyAsync(d, host, pitch * nrows, hipMemcpyHostToDevice, (hipStream_t)stream));
     else
@@ -374,6 +381,47 @@ int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream)
     return NEB_OK;
 }
 
+// ---- decoded geometry plane: which image rows of it match normal[cur] / depth[cur] of this frame ----
+static void geometry_invalidate(neb_ctx* ctx) { ctx->geom_lo = ctx->geom_hi = 0; }
+
+static void geometry_mark(neb_ctx* ctx, uint32_t row0, uint32_t row1)
+{
+    if (row0 >= row1)
+        return;
+    if (ctx->geom_lo < ctx->geom_hi && row0 <= ctx->geom_hi && row1 >= ctx->geom_lo) { // touches the valid run: extend it
+        ctx->geom_lo = row0 < ctx->geom_lo ? row0 : ctx->geom_lo;
+        ctx->geom_hi = row1 > ctx->geom_hi ? row1 : ctx->geom_hi;
+    } else {
+        ctx->geom_lo = row0;
+        ctx->geom_hi = row1;
+    }
+}
+
+static hipError_t geometry_ensure(neb_ctx* ctx, uint32_t row0, uint32_t row1, hipStream_t stream)
+{
+    auto decode = [&](uint32_t a, uint32_t b) {
+        return a < b ? launch_decode_geometry(ctx->W, ctx->row_begin, a, b, (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][ctx->cur],
+                                              (const uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur], (float4*)ctx->planes[NEB_PLANE_GEOMETRY][0], stream)
+                     : hipSuccess;
+    };
+    hipError_t e = hipSuccess;
+    if (ctx->geom_lo >= ctx->geom_hi || row1 < ctx->geom_lo || row0 > ctx->geom_hi) { // nothing valid nearby: decode the request
+        e = decode(row0, row1);
+        ctx->geom_lo = row0;
+        ctx->geom_hi = row1;
+        return e;
+    }
+    if (row0 < ctx->geom_lo) {
+        e = decode(row0, ctx->geom_lo);
+        ctx->geom_lo = row0;
+    }
+    if (e == hipSuccess && row1 > ctx->geom_hi) {
+        e = decode(ctx->geom_hi, row1);
+        ctx->geom_hi = row1;
+    }
+    return e;
+}
+
 static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
 {
     SvgfLaunch L;
@@ -398,6 +446,9 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
     const int c = ctx->cur, h = ctx->hist;
     NEB_GUARD(ctx);
     ScopedRange range("SVGF: Temporal Accumulation"); // SVGFDenoiser.cpp:69
+    // the pass also leaves normal[cur] / depth[cur] decoded in the geometry plane for the a-trous levels -- for the pixels it
+    // covers: with a ragged right / bottom remainder (Dispatch(W/8, H/8) floors) the levels' taps clamp into pixels it skips
+    const bool fused_geometry = (ctx->W % 8u) == 0 && (ctx->H % 8u) == 0;
     hipError_t e = launch_temporal(make_launch(ctx, row0, row1), (float4*)ctx->planes[NEB_PLANE_RADIANCE][c],
                                    (const float4*)ctx->planes[NEB_PLANE_RADIANCE][h],
                                    (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][c],
@@ -406,9 +457,12 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
                                    (const uint2*)ctx->planes[NEB_PLANE_NORMAL][h],
                                    (const uint32_t*)ctx->planes[NEB_PLANE_MOMENTS][h],
                                    (uint32_t*)ctx->planes[NEB_PLANE_MOMENTS][c],
-                                   (uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0], (hipStream_t)stream);
+                                   (uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0],
+                                   fused_geometry ? (float4*)ctx->planes[NEB_PLANE_GEOMETRY][0] : nullptr, (hipStream_t)stream);
     if (e != hipSuccess)
         return fail(ctx, NEB_ERR_HIP, "svgf_temporal launch", e);
+    if (fused_geometry)
+        geometry_mark(ctx, row0, row1);
     return NEB_OK;
 }
 
@@ -469,6 +523,7 @@ int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint
     // every (globally clamped) tap row must be resident: rows [row0 - 2*step, row1 - 1 + 2*step] clamped to the image
     const uint32_t Hd = (ctx->H / 8u) * 8u;
     const uint32_t r1 = row1 < Hd ? row1 : Hd;
+    NEB_GUARD(ctx);
     if (row0 < r1) {
         const uint32_t lo = row0 >= 2 * step ? row0 - 2 * step : 0;
         uint32_t hi = r1 - 1 + 2 * step;
@@ -476,18 +531,20 @@ int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint
             hi = ctx->H - 1;
         if (lo < ctx->row_begin || hi >= ctx->row_end)
             return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_atrous_level_rows: tap rows (halo) not resident");
+        // the tap rows the temporal pass did not decode (halo rows of a strip, or a level run on its own) are decoded now
+        hipError_t ge = geometry_ensure(ctx, lo, hi + 1, (hipStream_t)stream);
+        if (ge != hipSuccess)
+            return fail(ctx, NEB_ERR_HIP, "svgf geometry decode launch", ge);
     }
     int sp, ss, dp, ds;
     chain_link(ctx, level, &sp, &ss, &dp, &ds);
-    NEB_GUARD(ctx);
     char range_name[64];
     snprintf(range_name, sizeof(range_name), "SVGF: A-Trous compute %u (step %u)", level, step); // SVGFDenoiser.cpp:155
     ScopedRange range(range_name);
     hipError_t e = launch_atrous(make_launch(ctx, row0, row1), ctx->atrous_variant, step,
                                  (const float4*)ctx->planes[sp][ss], (float4*)ctx->planes[dp][ds],
                                  (const uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0],
-                                 (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][ctx->cur],
-                                 (const uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur], (hipStream_t)stream);
+                                 (const float4*)ctx->planes[NEB_PLANE_GEOMETRY][0], (hipStream_t)stream);
     if (e != hipSuccess)
         return fail(ctx, NEB_ERR_HIP, "svgf_atrous launch", e);
     return NEB_OK;

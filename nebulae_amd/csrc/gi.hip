@@ -889,6 +889,7 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
     a.row1 = ctx->row_end;
     a.tiles_x = (ctx->W + 7) / 8;
     const uint32_t tiles_y = (a.row1 - a.row0 + 7) / 8;
+    ctx->geom_lo = ctx->geom_hi = 0; // normal[cur] / depth[cur] change: the decoded geometry plane is stale
     hipLaunchKernelGGL(gbuffer_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;

@@ -90,6 +90,27 @@ __global__ void texture_footprints_kernel(const uint32_t* __restrict__ px, uint3
     out[i * stride] = make_uint4(px[(size_t)y * w + x], px[(size_t)y * w + x1], px[(size_t)y1 * w + x], px[(size_t)y1 * w + x1]);
 }
 
+// One 32-byte entry per texel position of a material whose three maps share a size: the bilinear footprint
+// {(x,y), (x+1,y), (x,y+1), (x+1,y+1)} (wrap applied) x the eight channels the shaders read, 8 bytes per texel:
+// lo = albedo.r | albedo.g << 8 | albedo.b << 16 | normal.r << 24,  hi = normal.g | normal.b << 8 | rm.g << 16 | rm.b << 24.
+__global__ void material_bundle_kernel(const uint32_t* __restrict__ pa, const uint32_t* __restrict__ pn, const uint32_t* __restrict__ pr, uint32_t w,
+                                       uint32_t h, uint4* out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)w * h)
+        return;
+    const uint32_t y = (uint32_t)(i / w), x = (uint32_t)(i - (size_t)y * w);
+    const uint32_t x1 = (x + 1) % w, y1 = (y + 1) % h;
+    auto pack = [&](uint32_t xx, uint32_t yy) {
+        const size_t k = (size_t)yy * w + xx;
+        const uint32_t a = pa[k], n = pn[k], r = pr[k];
+        return make_uint2((a & 0x00ffffffu) | (n << 24), ((n >> 8) & 0xffffu) | (((r >> 8) & 0xffffu) << 16));
+    };
+    const uint2 t00 = pack(x, y), t10 = pack(x1, y), t01 = pack(x, y1), t11 = pack(x1, y1);
+    out[2 * i] = make_uint4(t00.x, t00.y, t10.x, t10.y);
+    out[2 * i + 1] = make_uint4(t01.x, t01.y, t11.x, t11.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Spatial order: 64-bit Morton keys of the triangle centroids -> radix sort -> gather
 // ------------------------------------------------------------------------------------------------
@@ -688,8 +709,9 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         d.metal = mats[i].roughnessMetalness[1];
     }
     // ---- textures: the raw RGBA8 images go up once; the bilinear-footprint tables are built from them on the device ----
-    // (a footprint entry holds the 4 texels of a bilinear fetch, wrap applied: 16 B per texel position and map.  Sponza's
-    // 69 maps of 1024^2 make 1.2 GB of per-map tables / 1.6 GB of material bundles -- nothing to assemble on the host.)
+    // (a footprint entry holds the 4 texels of a bilinear fetch, wrap applied: 16 B per texel position and map, or 32 B per
+    // texel position for a material's three maps together.  Sponza's 69 maps of 1024^2 make 0.8 GB of material bundles --
+    // nothing to assemble on the host.)
     std::vector<size_t> raw_off(n_texs);
     size_t raw_total = 0;
     for (uint32_t i = 0; i < n_texs; ++i) {
@@ -704,10 +726,10 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         raw_off[i] = raw_total;
         raw_total += (size_t)texs[i].width * texs[i].height;
     }
-    // materials whose three maps share one size keep their footprints interleaved (DevMat::bundle, 64 B per texel position);
+    // materials whose three maps share one size keep their footprints interleaved (DevMat::bundle, 32 B per texel position);
     // every other map a material uses gets a standalone table
     constexpr size_t kBundleBudget = (size_t)4 << 30; // bytes; beyond it the remaining materials sample their maps separately
-    size_t bundle_entries = 0, table_entries = 0;     // in 64-byte / 16-byte units
+    size_t bundle_entries = 0, table_entries = 0;     // in 32-byte / 16-byte units
     std::vector<char> standalone(n_texs, 0);
     for (uint32_t i = 0; i < n_mats; ++i) {
         DevMat& d = dmats[i];
@@ -716,7 +738,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         if (d.tex[0] >= 0 && d.tex[1] >= 0 && d.tex[2] >= 0) {
             const DevTex &ta = dtexs[d.tex[0]], &tn = dtexs[d.tex[1]], &tr = dtexs[d.tex[2]];
             const size_t n_pos = (size_t)ta.w * ta.h;
-            if (ta.w == tn.w && ta.w == tr.w && ta.h == tn.h && ta.h == tr.h && (bundle_entries + n_pos) * 64 <= kBundleBudget &&
+            if (ta.w == tn.w && ta.w == tr.w && ta.h == tn.h && ta.h == tr.h && (bundle_entries + n_pos) * 32 <= kBundleBudget &&
                 bundle_entries + n_pos <= 0xffffffffull) {
                 d.bundle = (uint32_t)bundle_entries;
                 d.bundle_w = ta.w;
@@ -739,7 +761,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
             dtexs[i].offset = (uint32_t)table_entries;
             table_entries += (size_t)dtexs[i].w * dtexs[i].h;
         }
-    g->texture_table_bytes = table_entries * 16 + bundle_entries * 64;
+    g->texture_table_bytes = table_entries * 16 + bundle_entries * 32;
     {
         uint32_t* d_raw = nullptr;
         uint4* d_tables = nullptr;
@@ -754,7 +776,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         };
         talloc((void**)&d_raw, raw_total * 4, false);
         talloc((void**)&d_tables, table_entries * 16, true);
-        talloc((void**)&d_bundles, bundle_entries * 64, true);
+        talloc((void**)&d_bundles, bundle_entries * 32, true);
         for (uint32_t i = 0; i < n_texs && te == hipSuccess; ++i)
             te = hipMemcpy(d_raw + raw_off[i], texs[i].rgba8, (size_t)texs[i].width * texs[i].height * 4, hipMemcpyHostToDevice);
         for (uint32_t i = 0; i < n_texs && te == hipSuccess; ++i)
@@ -769,11 +791,9 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
             if (!d.bundle_w)
                 continue;
             const size_t n_pos = (size_t)d.bundle_w * d.bundle_h;
-            for (int k = 0; k < 3 && te == hipSuccess; ++k) { // slot k of every 64-byte entry
-                hipLaunchKernelGGL(texture_footprints_kernel, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, nullptr, d_raw + raw_off[d.tex[k]],
-                                   d.bundle_w, d.bundle_h, d_bundles + 4 * (size_t)d.bundle + k, 4u);
-                te = hipGetLastError();
-            }
+            hipLaunchKernelGGL(material_bundle_kernel, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0, nullptr, d_raw + raw_off[d.tex[0]],
+                               d_raw + raw_off[d.tex[1]], d_raw + raw_off[d.tex[2]], d.bundle_w, d.bundle_h, d_bundles + 2 * (size_t)d.bundle);
+            te = hipGetLastError();
         }
         if (te == hipSuccess)
             te = hipDeviceSynchronize();

@@ -487,8 +487,8 @@ template <bool FAST = false> __device__ float4 sample_texture(const SceneView& S
 }
 
 // The (up to) three filtered map fetches of a material at one uv.  A material whose three maps share one size keeps
-// their bilinear footprints interleaved, one 64-byte entry per texel position (DevMat::bundle): one line per hit
-// instead of three.  Maps a material does not have are left untouched (the caller uses the factors).
+// their bilinear footprints interleaved and trimmed to the channels the shaders read, one 32-byte entry per texel
+// position (DevMat::bundle): one 32-byte fetch per hit instead of three 16-byte ones in three places.  Maps a material does not have are left untouched (the caller uses the factors).
 struct MapSamples {
     float4 albedo = {0.f, 0.f, 0.f, 0.f}, normal = {0.f, 0.f, 0.f, 0.f}, rm = {0.f, 0.f, 0.f, 0.f};
 };
@@ -498,11 +498,24 @@ template <bool FAST = false> __device__ __forceinline__ void sample_material_map
         int x0, y0;
         float fx, fy;
         texel_position(m.bundle_w, m.bundle_h, u, v, x0, y0, fx, fy);
-        const uint4* e = S.bundles + 4 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
-        const uint4 fa = e[0], fn = e[1], fr = e[2]; // one 64-byte line
-        out.albedo = filter_footprint<FAST>(fa, fx, fy);
-        out.normal = filter_footprint<FAST>(fn, fx, fy);
-        out.rm = filter_footprint<FAST>(fr, fx, fy);
+        // one 32-byte entry: the four texels of the footprint, 8 bytes each {albedo.rgb, normal.rgb, roughness (rm.g), metalness (rm.b)}
+        // -- the eight channels the shaders read (alpha and rm.r are never sampled); same UNORM8 values, same filter arithmetic
+        const uint4* e = S.bundles + 2 * ((size_t)m.bundle + (size_t)y0 * m.bundle_w + x0);
+        const uint4 top = e[0], bot = e[1]; // {t00.lo, t00.hi, t10.lo, t10.hi}, {t01.lo, t01.hi, t11.lo, t11.hi}
+        float ch[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            auto un = [&](uint32_t lo, uint32_t hi) {
+                const float q = (float)(((c < 4 ? lo : hi) >> (8 * (c & 3))) & 0xffu);
+                return FAST ? q * (1.0f / 255.0f) : q / 255.0f;
+            };
+            const float a = un(top.x, top.y), b = un(top.z, top.w), cc = un(bot.x, bot.y), dd = un(bot.z, bot.w);
+            const float tp = a + fx * (b - a), bt = cc + fx * (dd - cc);
+            ch[c] = tp + fy * (bt - tp);
+        }
+        out.albedo = make_float4(ch[0], ch[1], ch[2], 0.0f);
+        out.normal = make_float4(ch[3], ch[4], ch[5], 0.0f);
+        out.rm = make_float4(0.0f, ch[6], ch[7], 0.0f);
         return;
     }
     if (m.tex[0] >= 0)

@@ -27,10 +27,10 @@ struct DevMat {
     int32_t tex[3];
     float albedo[3];
     float rough, metal;
-    // When the material has all three maps and they share one size, their bilinear footprints are also stored
-    // interleaved, one 64-byte entry per texel position {albedo 4 texels, normal 4, roughness/metalness 4, pad}: the
-    // three filtered fetches of a hit (same uv) then touch one line instead of three.  bundle_w == 0: not bundled.
-    uint32_t bundle;   // first entry, in 64-byte units, into SceneView::bundles
+    // When the material has all three maps and they share one size, their bilinear footprints are stored interleaved, one
+    // 32-byte entry per texel position: the 4 texels of the footprint x {albedo.rgb, normal.rgb, roughness, metalness}
+    // -- the three filtered fetches of a hit (same uv) are then ONE 32-byte access.  bundle_w == 0: not bundled.
+    uint32_t bundle;   // first entry, in 32-byte units, into SceneView::bundles
     uint32_t bundle_w, bundle_h;
     uint32_t pad;
 };
@@ -95,7 +95,7 @@ struct SceneView {
     const float* uvs;        // 2 per vertex
     const float* tangents;   // 4 per vertex
     const uint32_t* texels;  // RGBA8 bilinear footprint table: 4 texels (16 B) per texel position, see sample_texture
-    const uint4* bundles;    // per-material interleaved footprints (4 x uint4 per texel position), see DevMat::bundle
+    const uint4* bundles;    // per-material interleaved footprints (2 x uint4 per texel position), see DevMat::bundle
     const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
     uint32_t n_tris;
     int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene

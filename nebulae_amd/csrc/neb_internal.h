@@ -62,10 +62,14 @@ struct SvgfLaunch {
 // Kernel launchers (enqueue only).  All pointers are device pointers to resident row `row_begin`.
 hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* rad_hist, const uint32_t* depth_cur,
                            const uint32_t* depth_hist, const uint2* normal_cur, const uint2* normal_hist,
-                           const uint32_t* mom_hist, uint32_t* mom_cur, uint16_t* variance, hipStream_t s);
+                           const uint32_t* mom_hist, uint32_t* mom_cur, uint16_t* variance, float4* geometry, hipStream_t s);
 
+// `geometry`: {decoded shading normal.xyz, depth} per pixel (NEB_PLANE_GEOMETRY), valid for every tap row
 hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
-                         const uint16_t* variance, const uint32_t* depth, const uint2* normal, hipStream_t s);
+                         const uint16_t* variance, const float4* geometry, hipStream_t s);
+// decodes depth / normal rows [row0, row1) (all W columns) into the geometry plane
+hipError_t launch_decode_geometry(uint32_t W, uint32_t row_begin, uint32_t row0, uint32_t row1, const uint32_t* depth, const uint2* normal,
+                                  float4* geometry, hipStream_t s);
 
 // raysort.hip: stable LSD radix sort of (key, value) pairs on key bits [0, bits), bits <= 16 (enqueue only)
 size_t ray_sort_scratch_bytes(size_t n);
@@ -89,6 +93,7 @@ struct neb_ctx {
     uint32_t W = 0, H = 0, row_begin = 0, row_end = 0, levels = 4;
     void* planes[NEB_PLANE_COUNT][2] = {};
     int cur = 0, hist = 1;
+    uint32_t geom_lo = 0, geom_hi = 0; // image rows [geom_lo, geom_hi) of the geometry plane hold this frame's decoded normal / depth
     neb_svgf_params params{};
     int atrous_variant = 1; // 0 = direct-load kernel, 1 = LDS row-lattice kernel
     neb::GiState* gi = nullptr;

@@ -32,6 +32,7 @@ struct TemporalArgs {
     const uint32_t* mom_hist;
     uint32_t* mom_cur;
     uint16_t* variance;
+    float4* geometry;               // {decoded shading normal, depth} of the current frame for the a-trous levels, or null
     uint32_t W, Wd, row_off, nrows; // row_off = row0 - row_begin
     float neg_inv_two_sigma2_log2e, alpha, varianceEps;
 };
@@ -53,7 +54,10 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
 
     const float3 Nc = oct16_unpack_zw(nc);
     const float3 Nh = oct16_unpack_zw(nh);
-    const float dz = fabsf(depth_unorm24(dc) - depth_unorm24(dh));
+    const float zc = depth_unorm24(dc);
+    if (a.geometry) // decoded once here instead of once per a-trous level and staged texel
+        a.geometry[i] = make_float4(Nc.x, Nc.y, Nc.z, zc);
+    const float dz = fabsf(zc - depth_unorm24(dh));
     // SVGF_DWeight: exp(-dz^2 / (2 sigma^2))   (svgf_common.hlsli:11-15)
     const float wDepth = fast_exp2(dz * dz * a.neg_inv_two_sigma2_log2e);
     // SVGF_NWeight: saturate(dot)               (svgf_common.hlsli:4-7)
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
 
 hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* rad_hist, const uint32_t* depth_cur,
                            const uint32_t* depth_hist, const uint2* normal_cur, const uint2* normal_hist,
-                           const uint32_t* mom_hist, uint32_t* mom_cur, uint16_t* variance, hipStream_t s)
+                           const uint32_t* mom_hist, uint32_t* mom_cur, uint16_t* variance, float4* geometry, hipStream_t s)
 {
     const uint32_t Wd = (L.W / 8u) * 8u, Hd = (L.H / 8u) * 8u; // Dispatch(W/8,H/8): SVGFDenoiser.cpp:116
     const uint32_t row1 = L.row1 < Hd ? L.row1 : Hd;
@@ -96,6 +100,7 @@ hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* r
     a.mom_hist = mom_hist;
     a.mom_cur = mom_cur;
     a.variance = variance;
+    a.geometry = geometry;
     a.W = L.W;
     a.Wd = Wd;
     a.row_off = L.row0 - L.row_begin;
@@ -109,6 +114,29 @@ hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* r
     return hipGetLastError();
 }
 
+// The same decode for rows the temporal pass did not cover (halo rows of a strip; ragged images; a level run on its own).
+__global__ __launch_bounds__(256) void svgf_decode_geometry_kernel(const uint32_t* __restrict__ depth, const uint32_t* __restrict__ normal32,
+                                                                   float4* __restrict__ geometry, size_t first, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (k >= n)
+        return;
+    const size_t i = first + k;
+    const float3 N = oct16_unpack_zw(normal32[2 * i + 1]); // .zw = shading normal
+    geometry[i] = make_float4(N.x, N.y, N.z, depth_unorm24(depth[i]));
+}
+
+hipError_t launch_decode_geometry(uint32_t W, uint32_t row_begin, uint32_t row0, uint32_t row1, const uint32_t* depth, const uint2* normal,
+                                  float4* geometry, hipStream_t s)
+{
+    if (row0 >= row1)
+        return hipSuccess;
+    const size_t first = (size_t)(row0 - row_begin) * W, n = (size_t)(row1 - row0) * W;
+    hipLaunchKernelGGL(svgf_decode_geometry_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, depth, reinterpret_cast<const uint32_t*>(normal),
+                       geometry, first, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // A-trous: 5x5 taps at spacing `step`, edge-stopped by depth, normal and luminance.
 // ------------------------------------------------------------------------------------------
@@ -116,8 +144,7 @@ struct AtrousArgs {
     const float4* src;
     float4* dst;
     const uint16_t* variance;
-    const uint32_t* depth;
-    const uint2* normal;
+    const float4* geometry;     // {decoded shading normal.xyz, depth}: NEB_PLANE_GEOMETRY
     int W, H, Wd;               // image size and floor-dispatched width
     int row_begin, row_end;     // resident image rows [row_begin, row_end)
     int row0, row1;             // image rows to write (row1 already clipped to (H/8)*8)
@@ -144,17 +171,6 @@ __host__ __device__ constexpr float atrous_log2k(int dx, int dy)
     return lx + ly;
 }
 
-// exact c / (2^24 - 1): q = c*r, then one Newton step on the remainder (differs from the correctly rounded
-// quotient on 24 of the 2^24 codes, by one ulp)
-__device__ __forceinline__ float depth_unorm24_fast(uint32_t d)
-{
-    const float c = (float)(d & 0xffffffu);
-    const float r = 1.0f / 16777215.0f;
-    const float q = c * r;
-    const float rem = fmaf(-q, 16777215.0f, c);
-    return fmaf(rem, r, q);
-}
-
 // max(0, dot(n0, n)) of svgf_atrous.hlsl:74, saturated: the [0, 1] clamp is the free output modifier of the dot
 // product's last fma (a bare max(x, 0) is a separate v_max per tap).  Two unit normals can give 1 + 2 ulp, where the
 // reference's pow(d, 128) would be 1 + 3e-5 and this is 1 -- a deliberate divergence, the same in both
@@ -179,8 +195,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
     const float4 c0 = a.src[i];
     const float lum0 = luminance(c0.x, c0.y, c0.z);
     const float cl = lum_scale(half_bits_to_float(a.variance[i]), a.phiColor);
-    const float z0 = depth_unorm24_fast(a.depth[i]);
-    const float3 n0 = oct16_unpack_zw(a.normal[i].y);
+    const float4 g0 = a.geometry[i];
+    const float z0 = g0.w;
+    const float3 n0 = make_float3(g0.x, g0.y, g0.z);
     float sr = 0.f, sg = 0.f, sb = 0.f, sw = 0.f;
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
@@ -190,8 +207,9 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
         for (int dx = -2; dx <= 2; ++dx) {
             const int qx = min(max(x + dx * a.step, 0), a.W - 1);
             const float4 c = a.src[rowoff + qx];
-            const float z = depth_unorm24_fast(a.depth[rowoff + qx]);
-            const float3 n = oct16_unpack_zw(a.normal[rowoff + qx].y);
+            const float4 g = a.geometry[rowoff + qx];
+            const float z = g.w;
+            const float3 n = make_float3(g.x, g.y, g.z);
             const float lum = luminance(c.x, c.y, c.z);
             const float d = normal_dot_sat(fmaf(n0.z, n.z, fmaf(n0.y, n.y, n0.x * n.x)));
             float e = fmaf(a.phiNormal, fast_log2(d), atrous_log2k(dx, dy));
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
 //   rows of the lattice {r + S*j}.  Taps of a lattice row are lattice rows j-2..j+2, so the
 //   tile needs only BH+4 image rows (each a contiguous, coalesced segment of BW+4S texels)
 //   for any step S: read amplification (1 + 4/BH)(1 + 4S/BW) instead of (1 + 4S/T)^2.
-//   Staging decodes depth (D24 -> float) and the oct shading normal ONCE per texel and
+//   Staging reads the radiance and the frame's decoded geometry plane {n.xyz, z} (written once by the temporal pass) and
 //   keeps {r,g,b,z} and {nx,ny,nz,lum} as two float4 LDS planes (ds_read_b128, lane-contiguous,
 //   conflict-free).  Wave w filters lattice rows [w*R, w*R+R): a lane walks its column's R+4
 //   staged rows once and feeds each staged texel to every output row it is a tap of.
@@ -233,16 +251,18 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
     using T = AtrousTile<S, R>;
     constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD;
     extern __shared__ float4 lds[];
-    float4* __restrict__ A = lds;               // {r, g, b, z}
-    float4* __restrict__ B = lds + ROWS * COLS; // {nx, ny, nz, lum}
+    float4* __restrict__ A = lds;               // {r, g, b, lum}
+    float4* __restrict__ B = lds + ROWS * COLS; // {nx, ny, nz, z}: the geometry plane's texels, copied by LDS-DMA
 
     const float4* __restrict__ src = a.src;
-    const uint32_t* __restrict__ depth = a.depth;
-    const uint32_t* __restrict__ normal32 = reinterpret_cast<const uint32_t*>(a.normal);
+    const float4* __restrict__ geometry = a.geometry;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     // Tile walk, XCD-aware: workgroups b, b+8, ... share an XCD (and its L2); each XCD takes a contiguous
     // run of tiles, and the workgroups of an XCD interleave inside that run.  Speed only.
+    // (Handing the tiles out dynamically instead -- one ticket counter per XCD, tickets requested a tile ahead -- was
+    // measured at 46 us per level against 35: a device-scope atomic is a round trip to the memory side of the fabric, and
+    // the static split is already balanced where it matters, per CU: 8 tiles on all but 8 CUs against 7.97 on average.)
     const uint32_t per_xcd = (a.nblocks + 7u) >> 3;
     const uint32_t xcd = blockIdx.x & 7u, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const uint32_t t_end = min((xcd + 1u) * per_xcd, a.nblocks);
@@ -256,7 +276,6 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
         lcol[k] = i - lrow[k] * COLS;
     }
     float4 pc[NLOAD];
-    uint32_t pd[NLOAD], pn[NLOAD];
 
     auto tile_origin = [&](uint32_t t, int& r, int& jbase, int& x0) -> bool {
         const int tx_tile = (int)(t % (uint32_t)a.tiles_x);
@@ -278,8 +297,22 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
             const int x = min(max(x0 - 2 * S + lcol[k], 0), a.W - 1);
             const size_t q = (size_t)(y - a.row_begin) * a.W + x;
             pc[k] = src[q];
-            pd[k] = depth[q];
-            pn[k] = normal32[2 * q + 1];
+        }
+    };
+    // The geometry texels go global -> LDS directly (global_load_lds_dwordx4: per-lane source address, destination =
+    // wave-uniform base + lane * 16 B, which is exactly this staging order), no registers and no VALU.  Issued once the
+    // whole workgroup has finished reading the previous tile, and complete before the barrier that precedes the filter.
+    auto issue_geometry_dma = [&](int r, int jbase, int x0) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+            if (threadIdx.x + 256 * k < TOTAL) {
+                int y = min(max(r + S * (jbase + lrow[k] - 2), 0), a.H - 1);
+                y = min(max(y, a.row_begin), a.row_end - 1);
+                const int x = min(max(x0 - 2 * S + lcol[k], 0), a.W - 1);
+                const size_t q = (size_t)(y - a.row_begin) * a.W + x;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(geometry + q),
+                                                 (__attribute__((address_space(3))) void*)(B + 256 * k + 64 * wv), 16, 0, 0);
+            }
         }
     };
     auto issue_loads = [&](int r, int jbase, int x0) {
@@ -297,17 +330,20 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
         issue_loads(r, jbase, x0);
 
     while (have) {
-        // ---- decode the prefetched texels into LDS ----
+        // ---- stage the tile: radiance (prefetched into registers during the previous tile) + its luminance -> plane A;
+        // geometry -> plane B by DMA (normal and depth arrive decoded: the temporal pass did that once per frame) ----
+        float lum[NLOAD];
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k)
+            lum[k] = luminance(pc[k].x, pc[k].y, pc[k].z);
+        issue_geometry_dma(r, jbase, x0);
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             const int i = threadIdx.x + 256 * k;
-            if (i < TOTAL) {
-                const float3 n = oct16_unpack_zw(pn[k]);
-                A[i] = make_float4(pc[k].x, pc[k].y, pc[k].z, depth_unorm24_fast(pd[k]));
-                B[i] = make_float4(n.x, n.y, n.z, luminance(pc[k].x, pc[k].y, pc[k].z));
-            }
+            if (i < TOTAL)
+                A[i] = make_float4(pc[k].x, pc[k].y, pc[k].z, lum[k]);
         }
-        __syncthreads();
+        __syncthreads(); // (also waits for this wave's DMA: an LDS-DMA is a pending LDS write on the VM counter)
 
         // ---- next tile: issue its loads now, consume them after this tile is filtered ----
         const int cr = r, cjbase = jbase, cx0 = x0;
@@ -334,11 +370,11 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
             const int lr = wv * R + k + 2;
             const float4 cA = A[lr * COLS + lane + 2 * S];
             const float4 cB = B[lr * COLS + lane + 2 * S];
-            z0[k] = cA.w;
+            z0[k] = cB.w;
             n0x[k] = cB.x;
             n0y[k] = cB.y;
             n0z[k] = cB.z;
-            lum0[k] = cB.w;
+            lum0[k] = cA.w;
             const int yo = cr + S * (cjbase + wv * R + k);
             valid[k] = (xo < a.Wd) && (yo < a.row1);
             float var_f = 0.f;
@@ -371,8 +407,8 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
                     const float lk = atrous_log2k(dx, dy);
                     const float d = normal_dot_sat(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)));
                     float e = fmaf(phiN, fast_log2(d), lk);
-                    e = fmaf(-fabsf(z0[k] - tA.w), cz, e);
-                    e = fmaf(-fabsf(lum0[k] - tB.w), cl[k], e);
+                    e = fmaf(-fabsf(z0[k] - tB.w), cz, e);
+                    e = fmaf(-fabsf(lum0[k] - tA.w), cl[k], e);
                     const float w = fast_exp2(e);
                     sr[k] = fmaf(w, tA.x, sr[k]);
                     sg[k] = fmaf(w, tA.y, sg[k]);
@@ -436,7 +472,7 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
 }
 
 hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
-                         const uint16_t* variance, const uint32_t* depth, const uint2* normal, hipStream_t s)
+                         const uint16_t* variance, const float4* geometry, hipStream_t s)
 {
     const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
     const uint32_t Wd = (L.W / 8u) * 8u, Hd = (L.H / 8u) * 8u; // SVGFDenoiser.cpp:185
@@ -447,8 +483,7 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
     a.src = src;
     a.dst = dst;
     a.variance = variance;
-    a.depth = depth;
-    a.normal = normal;
+    a.geometry = geometry;
     a.W = (int)L.W;
     a.H = (int)L.H;
     a.Wd = (int)Wd;

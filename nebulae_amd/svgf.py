@@ -14,14 +14,14 @@ import numpy as np
 
 from . import _lib
 from ._lib import (PLANE_DEPTH, PLANE_MOMENTS, PLANE_NORMAL, PLANE_RADIANCE, PLANE_SCRATCH, PLANE_VARIANCE,  # noqa: F401
-                   PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS, PLANE_LDR, SLOT_CURRENT, SLOT_HISTORY, NebError)
+                   PLANE_ALBEDO, PLANE_ROUGH_METAL, PLANE_WORLDPOS, PLANE_LDR, PLANE_GEOMETRY, SLOT_CURRENT, SLOT_HISTORY, NebError)
 
 # plane -> (numpy dtype, channels)
 PLANE_LAYOUT = {
     PLANE_RADIANCE: (np.float32, 4), PLANE_NORMAL: (np.float16, 4), PLANE_DEPTH: (np.uint32, 1),
     PLANE_MOMENTS: (np.float16, 2), PLANE_VARIANCE: (np.float16, 1), PLANE_SCRATCH: (np.float32, 4),
     PLANE_ALBEDO: (np.uint32, 1), PLANE_ROUGH_METAL: (np.float16, 2), PLANE_WORLDPOS: (np.float16, 4),
-    PLANE_LDR: (np.uint32, 1),
+    PLANE_LDR: (np.uint32, 1), PLANE_GEOMETRY: (np.float32, 4),
 }
 
 
