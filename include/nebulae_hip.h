@@ -148,6 +148,33 @@ int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint
 /* Which plane/slot level `level` reads and writes (for halo exchange between levels). */
 int neb_svgf_atrous_level_planes(const neb_ctx* ctx, uint32_t level, int* src_plane, int* src_slot, int* dst_plane, int* dst_slot);
 
+/* ======================= Multi-GPU row strips: halo exchange over RCCL (no reference counterpart) ================
+ * One context per GPU holds image rows [row_begin, row_end) = the strip it owns plus halo rows (neb_create_info).  Every stage is
+ * per-pixel except the a-trous wavelet, so the only data that crosses GPUs are halo rows of radiance (and variance), swapped with
+ * the up / down neighbour by grouped ncclSend / ncclRecv straight out of / into the planes (rows are contiguous: no packing), on the
+ * caller's stream.  RCCL is resolved at run time (dlopen of librccl): hosts link nothing extra, and without RCCL these calls return
+ * NEB_ERR_STATE while everything single-GPU keeps working.  nebulae_amd/strips.py holds the partition arithmetic (which rows, when). */
+typedef struct neb_halo_plane {
+    int32_t plane; /* neb_plane */
+    int32_t slot;  /* 0, 1, NEB_SLOT_CURRENT or NEB_SLOT_HISTORY */
+} neb_halo_plane;
+typedef struct neb_halo_swap {
+    int32_t peer;                  /* rank in the communicator */
+    uint32_t send_row0, send_row1; /* image rows sent to the peer (owned by this strip) */
+    uint32_t recv_row0, recv_row1; /* image rows received from it (halo rows of this strip) */
+} neb_halo_swap;
+/* ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy through the library: one rank makes the 128-byte id, the host carries it to
+ * the others however it likes (MPI, a socket, torch.distributed), every rank creates its communicator with it. */
+int neb_strips_unique_id(void* id128);
+int neb_strips_comm_create(int device, int n_ranks, int rank, const void* id128, void** out_comm);
+int neb_strips_comm_destroy(void* comm);
+/* For every listed plane and every swap: send rows [send_row0, send_row1), receive rows [recv_row0, recv_row1), all in ONE RCCL group,
+ * enqueued on `stream` (ordered after the kernels that produced the rows, before the ones that read the halo).  Every rank of the
+ * communicator must make the matching call.  comm = the ncclComm_t from neb_strips_comm_create (or the host's own). */
+int neb_strips_exchange(neb_ctx* ctx, void* comm, const neb_halo_plane* planes, uint32_t n_planes, const neb_halo_swap* swaps, uint32_t n_swaps,
+                        neb_stream stream);
+const char* neb_strips_last_error(void); /* message of the last failed neb_strips_* call that had no context */
+
 /* ======================= GI: one-bounce indirect diffuse =========================================
  * Replaces DeferredRenderer::SubmitCommandsGIPathtrace (src/DeferredRenderer.cpp:396-591) driving
  * assets/shaders/pathtracer.hlsl with the NRC calls stubbed (rtxgi/Nrc.hlsli:579-621), and the DXR

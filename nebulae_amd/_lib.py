@@ -23,6 +23,14 @@ class CreateInfo(C.Structure):
                 ("row_end", C.c_uint32), ("atrous_levels", C.c_uint32)]
 
 
+class HaloPlane(C.Structure):
+    _fields_ = [("plane", C.c_int32), ("slot", C.c_int32)]
+
+
+class HaloSwap(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("send_row0", C.c_uint32), ("send_row1", C.c_uint32), ("recv_row0", C.c_uint32), ("recv_row1", C.c_uint32)]
+
+
 class SvgfParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("depthSigma", "alpha", "varianceEps", "phiColor", "phiNormal", "phiDepth")]
 
@@ -55,6 +63,11 @@ _SIGS = {
     "neb_svgf_temporal_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "neb_svgf_atrous_level_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "neb_svgf_atrous_level_planes": (C.c_int, [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_int)] * 4),
+    "neb_strips_unique_id": (C.c_int, [C.c_void_p]),
+    "neb_strips_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "neb_strips_comm_destroy": (C.c_int, [C.c_void_p]),
+    "neb_strips_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(HaloPlane), C.c_uint32, C.POINTER(HaloSwap), C.c_uint32, C.c_void_p]),
+    "neb_strips_last_error": (C.c_char_p, []),
 }
 
 

@@ -31,7 +31,7 @@ the world_size-2 gloo tests inject an oracle-backed stand-in to exercise exactly
 import math
 
 from .renderer import DeferredRenderer
-from .svgf import PLANE_RADIANCE, PLANE_SCRATCH, PLANE_VARIANCE, SVGFDenoiser
+from .svgf import PLANE_RADIANCE, PLANE_SCRATCH, PLANE_VARIANCE, NebError, SVGFDenoiser
 
 
 def frame_factors(n):
@@ -110,7 +110,10 @@ class StripPartition:
 class StripRenderer(DeferredRenderer):
     """DeferredRenderer over one row strip.  With world == 1 it is exactly the single-GPU renderer."""
 
-    def __init__(self, part, rank, device=0, group=None, denoiser_factory=SVGFDenoiser):
+    def __init__(self, part, rank, device=0, group=None, denoiser_factory=SVGFDenoiser, exchange=None):
+        """exchange: "torch" (default) = torch.distributed P2P on the planes; "rccl" (or NEB_STRIPS_EXCHANGE=rccl) = the
+        library's own C entry point neb_strips_exchange (grouped ncclSend / ncclRecv on its own communicator and a side
+        stream): what a C++ host without PyTorch would call.  `group` is then only used once, to carry the RCCL unique id."""
         super().__init__()
         self.svgf = denoiser_factory()
         self.part, self.rank, self.group = part, rank, group
@@ -120,6 +123,59 @@ class StripRenderer(DeferredRenderer):
         import os
         self._staging = os.environ.get("NEB_STRIPS_STAGING") or None  # None | "host" | "device"
         self._staging_decided = False
+        self.exchange = exchange or os.environ.get("NEB_STRIPS_EXCHANGE") or "torch"
+        if self.exchange not in ("torch", "rccl"):
+            raise ValueError(f"unknown halo exchange backend {self.exchange!r}")
+        self._comm = None
+        self._xstream = None
+        self._device = device
+        if self.exchange == "rccl" and part.N > 1:
+            self._comm = self._create_comm()
+
+    def _create_comm(self):
+        """ncclCommInitRank through the library: rank 0 draws the unique id, the torch group (any backend) carries it."""
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+        lib = self._lib
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            self._check(lib.neb_strips_unique_id(buf), "neb_strips_unique_id")
+        on_cuda = dist.get_backend(self.group) != "gloo"
+        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        t = t.cuda() if on_cuda else t
+        dist.broadcast(t, src=0, group=self.group)
+        ident = bytes(t.cpu().numpy().tobytes())
+        comm = C.c_void_p()
+        rc = lib.neb_strips_comm_create(self._device, self.part.N, self.rank, ident, C.byref(comm))
+        if rc != 0:
+            raise NebError(f"neb_strips_comm_create failed ({rc}): {lib.neb_strips_last_error().decode()}")
+        return comm
+
+    def _swap_rows_rccl_begin(self, planes, plan):
+        """The same exchange through neb_strips_exchange, on a side stream so that work enqueued on the launch stream between
+        begin and finish runs beside it."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+        if not plan:
+            return lambda: None
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream()
+        P = (_lib.HaloPlane * len(planes))(*[_lib.HaloPlane(p, sl) for p, sl in planes])
+        S_ = (_lib.HaloSwap * len(plan))(*[_lib.HaloSwap(peer, s0, s1, r0, r1) for peer, (s0, s1), (r0, r1) in plan])
+        launch = torch.cuda.ExternalStream(self.info.stream) if self.info.stream else torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(launch)
+        self._xstream.wait_event(ready)
+        self._check(self._lib.neb_strips_exchange(self._ctx, self._comm, P, len(planes), S_, len(plan), C.c_void_p(self._xstream.cuda_stream)),
+                    "neb_strips_exchange")
+        done = torch.cuda.Event()
+        done.record(self._xstream)
+        return lambda: launch.wait_event(done)
 
     def _plane_rows(self, plane, slot, row0, row1):
         key = (plane, slot)
@@ -174,6 +230,8 @@ class StripRenderer(DeferredRenderer):
         import torch.distributed as dist
         if not plan:
             return lambda: None
+        if self._comm is not None:
+            return self._swap_rows_rccl_begin(planes, plan)
         send = [self._plane_rows(p, sl, s0, s1) for p, sl in planes for _, (s0, s1), _ in plan]
         recv = [self._plane_rows(p, sl, r0, r1) for p, sl in planes for _, _, (r0, r1) in plan]
         peers = [peer for _ in planes for peer, _, _ in plan]
@@ -233,6 +291,12 @@ class StripRenderer(DeferredRenderer):
         out = [torch.empty_like(src) for _ in range(self.part.N)] if self.rank == dst else None
         dist.gather(src, out, dst=dst, group=self.group)
         return torch.cat(out, dim=0) if self.rank == dst else None
+
+    def destroy(self):
+        if self._comm is not None:
+            self._lib.neb_strips_comm_destroy(self._comm)
+            self._comm = None
+        super().destroy()
 
     def submit_commands_svgf_denoising(self, events=None):
         if self.dynamic_scene_this_frame and not self.denoise_while_moving:  # src/DeferredRenderer.cpp:595

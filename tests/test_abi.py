@@ -51,6 +51,15 @@ def test_create_rejects_bad_arguments_without_touching_a_gpu():
     assert b"row range" in lib.neb_last_error(None)
 
 
+def test_strip_exchange_entry_points_validate_arguments_without_a_gpu():
+    lib = _lib.load()
+    comm = C.c_void_p()
+    assert lib.neb_strips_comm_create(0, 0, 0, None, C.byref(comm)) == -1 and b"bad argument" in lib.neb_strips_last_error()
+    assert lib.neb_strips_unique_id(None) == -1
+    assert lib.neb_strips_comm_destroy(None) == 0
+    assert lib.neb_strips_exchange(None, None, None, 0, None, 0, None) == -1
+
+
 def test_no_cpu_fallback_when_no_device():
     import torch
     if torch.cuda.is_available():

@@ -39,3 +39,43 @@ def test_two_strips_equal_full_image_gi_plus_svgf(scheme):
     assert np.array_equal(got, want)
     full.destroy()
     ls.destroy()
+
+
+def test_c_entry_point_exchanges_rows_over_rccl():
+    """neb_strips_exchange: grouped ncclSend / ncclRecv straight out of / into the planes, on the caller's stream, through an
+    RCCL communicator the library creates itself (librccl resolved at run time).  One GPU: a communicator of one rank that
+    sends its rows to itself -- the same call a strip makes towards its neighbours (the multi-rank rendezvous runs on the
+    driver's multi-GPU node; the partition arithmetic is covered by the gloo tests)."""
+    import ctypes as C
+
+    from nebulae_amd import _lib
+    from nebulae_amd.svgf import PLANE_VARIANCE, SLOT_CURRENT, NebError, SVGFDenoiser
+    W, H = 64, 48
+    d = SVGFDenoiser()
+    d.init(W, H, atrous_levels=2, row_begin=8, row_end=40)
+    lib = d._lib
+    ident = (C.c_char * 128)()
+    assert lib.neb_strips_unique_id(ident) == 0, lib.neb_strips_last_error()
+    comm = C.c_void_p()
+    assert lib.neb_strips_comm_create(0, 1, 0, ident, C.byref(comm)) == 0, lib.neb_strips_last_error()
+    d.begin_frame(3)
+    rng = np.random.default_rng(5)
+    rad = rng.normal(size=(32, W, 4)).astype(np.float32)
+    var = rng.uniform(size=(32, W)).astype(np.float16)
+    d.upload(PLANE_RADIANCE, SLOT_CURRENT, rad)
+    d.upload(PLANE_VARIANCE, 0, var)
+    planes = (_lib.HaloPlane * 2)(_lib.HaloPlane(PLANE_RADIANCE, SLOT_CURRENT), _lib.HaloPlane(PLANE_VARIANCE, 0))
+    swaps = (_lib.HaloSwap * 2)(_lib.HaloSwap(0, 12, 16, 8, 12), _lib.HaloSwap(0, 30, 36, 34, 40))  # (peer, send rows, recv rows)
+    stream = torch.cuda.current_stream().cuda_stream
+    d._check(lib.neb_strips_exchange(d._ctx, comm, planes, 2, swaps, 2, C.c_void_p(stream)), "neb_strips_exchange")
+    torch.cuda.synchronize()
+    got_r, got_v = d.download(PLANE_RADIANCE), d.download(PLANE_VARIANCE)
+    want_r, want_v = rad.copy(), var.copy()
+    want_r[0:4], want_v[0:4] = rad[4:8], var[4:8]          # image rows 8..12 <- 12..16
+    want_r[26:32], want_v[26:32] = rad[22:28], var[22:28]  # image rows 34..40 <- 30..36
+    assert np.array_equal(got_r, want_r) and np.array_equal(got_v, want_v)
+    # rows outside the resident range are refused before any RCCL call is made
+    bad = (_lib.HaloSwap * 1)(_lib.HaloSwap(0, 0, 4, 8, 12))
+    assert lib.neb_strips_exchange(d._ctx, comm, planes, 2, bad, 1, C.c_void_p(stream)) == -5
+    assert lib.neb_strips_comm_destroy(comm) == 0
+    d.destroy()
