@@ -178,7 +178,7 @@ const char* neb_strips_last_error(void); /* message of the last failed neb_strip
 /* ======================= GI: one-bounce indirect diffuse =========================================
  * Replaces DeferredRenderer::SubmitCommandsGIPathtrace (src/DeferredRenderer.cpp:396-591) driving
  * assets/shaders/pathtracer.hlsl with the NRC calls stubbed (rtxgi/Nrc.hlsli:579-621), and the DXR
- * driver BVH (src/nri/raytracing/RTAccelerationStructureBuilder.cpp:14-130) with an on-device LBVH. */
+ * driver BVH (src/nri/raytracing/RTAccelerationStructureBuilder.cpp:14-130) with a BVH built on the device (binned SAH, 4-wide). */
 
 /* One submesh: StaticMeshGeometryData (src/nri/GIProcessedScene.h:17-31; shader mirror
  * pathtracer.hlsl:73-87).  The bindless (bufferIndex, offset) pairs become host pointers to the

@@ -6,8 +6,7 @@
 //   rtxgi/Nrc.hlsli:579-621, nrcMaxPathVertices = 2), :299-395 ReconstructSurfaceData, :209-228
 //   EvaluateDirectBRDF; brdf.hlsli; rand.hlsli; sun_disk_sampling.hlsli:45-52;
 //   src/nri/GIProcessedScene.cpp:16-137 (scene tables); RTAccelerationStructureBuilder.cpp:14-130
-//   (driver BVH -> replaced by a Karras LBVH built here, its upper levels re-linked by SAH and collapsed to a
-//   4-wide tree); deferred_gbuffers.hlsl:36-104 (G-buffer encodings).
+//   (driver BVH -> replaced by a binned-SAH tree built on the device and collapsed to 4-wide nodes, gi_build.hip); deferred_gbuffers.hlsl:36-104 (G-buffer encodings).
 // Not a DXR transliteration: there is no ray-gen/miss/closest-hit pipeline and no driver BVH.  The path runs as
 // wavefront stages over per-pixel records: a wave owns an 8x8 pixel tile, each lane generates its ray from the
 // G-buffer and walks the BVH4 with a per-lane stack kept in LDS (lane-contiguous, conflict-free); a second kernel
@@ -378,7 +377,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
 }
 
 // ------------------------------------------------------------------------------------------------
-// G-buffer producer ("next" row f2): primary visibility through the same LBVH
+// G-buffer producer ("next" row f2): primary visibility through the same BVH
 // ------------------------------------------------------------------------------------------------
 struct GbufArgs {
     SceneView S;

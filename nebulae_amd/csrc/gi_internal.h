@@ -50,7 +50,7 @@ struct BvhNode {
     uint32_t pad1;
 };
 
-// 128-byte BVH4 node produced by collapsing the LBVH (SoA per axis: one float4 per bound and axis).
+// 128-byte BVH4 node produced by collapsing the binary SAH tree (SoA per axis: one float4 per bound and axis).
 // child >= 0: inner node index; child < 0: leaf, code = ~child = (first_triangle << 2) | (count - 1), count <= 4;
 // unused slots carry an inverted (never-hit) box.  The lower and the upper plane of an axis sit 64 bytes apart, so
 // a ray picks its near plane with a per-ray byte offset (0 or 64 by the sign of its direction) and the far plane
@@ -72,9 +72,6 @@ static_assert(sizeof(Bvh4Node) == 128 && offsetof(Bvh4Node, hix) == offsetof(Bvh
 #define NEB_LEAF_BATCH 12
 #endif
 constexpr int kLeafBatch = NEB_LEAF_BATCH;
-#ifndef NEB_TOP_SAH
-#define NEB_TOP_SAH 2 // > 0: LBVH subtrees of up to this many triangles are re-linked by a sweep-SAH top level (host pass); 0 / 512 / 64 / 16 / 8 / 4 / 2 / 1 measured 464 / 454 / 437 / 427 / 419 / 403 / 400 / 474 us for the closest-hit pass
-#endif
 #ifndef NEB_FAST_SHADE
 #define NEB_FAST_SHADE 1 // gi_shade_kernel uses the 1-ulp hardware rcp / rsq / sqrt (see fdiv)
 #endif

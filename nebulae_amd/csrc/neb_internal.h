@@ -76,7 +76,7 @@ size_t ray_sort_scratch_bytes(size_t n);
 hipError_t ray_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t* vals_out, size_t n, int bits,
                           void* scratch, hipStream_t stream);
 
-struct GiState;               // gi.hip: scene tables, LBVH, counters
+struct GiState;               // gi.hip / gi_build.hip: scene tables, BVH, counters
 void gi_destroy(GiState* g);
 void gi_on_resize(GiState* g);
 int gi_set_debug_hits(neb_ctx* ctx, int on);

@@ -427,7 +427,18 @@ inline bool slab(const Node& n, V3 o, V3 inv, float tmin, float tmax, float& tne
 
 } // namespace
 
-static unsigned long long g_node_visits = 0, g_tri_tests = 0; // diagnostics (not thread-exact; fine for averages)
+// diagnostics: per-thread tallies, folded into the totals when a parallel region ends (a shared counter bumped from the
+// traversal loop made 16 threads barely faster than one)
+static unsigned long long g_node_visits = 0, g_tri_tests = 0;
+static thread_local unsigned long long t_node_visits = 0, t_tri_tests = 0;
+static void fold_traversal_stats()
+{
+#pragma omp atomic
+    g_node_visits += t_node_visits;
+#pragma omp atomic
+    g_tri_tests += t_tri_tests;
+    t_node_visits = t_tri_tests = 0;
+}
 extern "C" void trace_ref_stats(unsigned long long* nodes, unsigned long long* tris, int reset)
 {
     *nodes = g_node_visits;
@@ -454,11 +465,9 @@ static bool trace(const trace_ref_scene* s, const std::vector<uint32_t>& right, 
         float tn;
         if (!slab(n, o, inv, tmin, hit.t, tn))
             continue;
-#pragma omp atomic
-        g_node_visits++;
+        t_node_visits++;
         if (n.count) {
-#pragma omp atomic
-            g_tri_tests += n.count;
+            t_tri_tests += n.count;
             for (uint32_t i = 0; i < n.count; ++i) {
                 float t, u, v;
                 if (intersect_tri(s->tris[n.left + i], o, d, tmin, hit.t, t, u, v)) {
@@ -684,7 +693,9 @@ extern "C" uint64_t trace_ref_gi(const trace_ref_scene* s, uint32_t W, uint32_t 
     const V3 sun_rad = v3(c->sunLightRadiance[0], c->sunLightRadiance[1], c->sunLightRadiance[2]);
     if (row1 > H)
         row1 = H;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : rays)
+#pragma omp parallel num_threads(threads) reduction(+ : rays)
+    {
+#pragma omp for schedule(dynamic, 4) nowait
     for (int yy = (int)row0; yy < (int)row1; ++yy) {
         for (uint32_t x = 0; x < W; ++x) {
             const uint32_t y = (uint32_t)yy;
@@ -773,6 +784,8 @@ extern "C" uint64_t trace_ref_gi(const trace_ref_scene* s, uint32_t W, uint32_t 
                 hits[i] = dbg;
         }
     }
+        fold_traversal_stats();
+    }
     return rays;
 }
 
@@ -789,7 +802,9 @@ extern "C" void trace_ref_gbuffer(const trace_ref_scene* s, uint32_t W, uint32_t
     const float aspect = (float)W / (float)H;
     const float zn = cam->znear, zf = cam->zfar;
     const float m22 = zf / (zn - zf), m32 = zn * zf / (zn - zf); // XMMatrixPerspectiveFovRH
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+#pragma omp parallel num_threads(threads)
+    {
+#pragma omp for schedule(dynamic, 4) nowait
     for (int yy = 0; yy < (int)H; ++yy) {
         for (uint32_t x = 0; x < W; ++x) {
             const size_t i = (size_t)yy * W + x;
@@ -879,6 +894,8 @@ extern "C" void trace_ref_gbuffer(const trace_ref_scene* s, uint32_t W, uint32_t
             depth_stencil[i] = ds;
         }
     }
+        fold_traversal_stats();
+    }
 }
 
 // ---- deferred_pbr.hlsl:39-115 ----
@@ -892,7 +909,9 @@ extern "C" uint64_t trace_ref_pbr_direct(const trace_ref_scene* s, uint32_t W, u
     const V3 sun_rad = v3(c->sunLightRadiance[0], c->sunLightRadiance[1], c->sunLightRadiance[2]);
     uint64_t rays = 0;
     auto clampf = [](float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); };
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : rays)
+#pragma omp parallel num_threads(threads) reduction(+ : rays)
+    {
+#pragma omp for schedule(dynamic, 4) nowait
     for (int yy = 0; yy < (int)H; ++yy) {
         for (uint32_t x = 0; x < W; ++x) {
             const uint32_t y = (uint32_t)yy;
@@ -938,6 +957,8 @@ extern "C" uint64_t trace_ref_pbr_direct(const trace_ref_scene* s, uint32_t W, u
             radiance[4 * i + 2] = O.z * LdotN * sun_rad.z * vis;
             radiance[4 * i + 3] = 1.0f;
         }
+    }
+        fold_traversal_stats();
     }
     return rays;
 }
