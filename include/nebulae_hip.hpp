@@ -107,8 +107,44 @@ namespace Neb
             ThrowIfFailed(m_svgf.Context(), neb_gi_trace(m_svgf.Context(), &globalConstants, commandList), "neb_gi_trace");
         }
 
+        // the acceleration structure is built on the device; these report what came out of it
+        uint32_t BvhDepth() const
+        {
+            uint32_t d = 0;
+            ThrowIfFailed(m_svgf.Context(), neb_gi_bvh_depth(m_svgf.Context(), &d), "neb_gi_bvh_depth");
+            return d;
+        }
+
     private:
         SVGFDenoiser& m_svgf;
+    };
+
+    // Halo exchange between the row strips of a multi-GPU frame (no reference counterpart: Nebulae is single-GPU).
+    // One communicator per strip group; Exchange() enqueues one RCCL group of sends / receives on the caller's stream.
+    class StripExchange
+    {
+    public:
+        StripExchange() = default;
+        StripExchange(const StripExchange&) = delete;
+        StripExchange& operator=(const StripExchange&) = delete;
+        ~StripExchange() { neb_strips_comm_destroy(m_comm); }
+        static void MakeUniqueId(void* id128) { Check(neb_strips_unique_id(id128), "neb_strips_unique_id"); }
+        void Init(int device, int numRanks, int rank, const void* id128)
+        {
+            Check(neb_strips_comm_create(device, numRanks, rank, id128, &m_comm), "neb_strips_comm_create");
+        }
+        void Exchange(SVGFDenoiser& strip, const neb_halo_plane* planes, uint32_t nPlanes, const neb_halo_swap* swaps, uint32_t nSwaps, neb_stream commandList)
+        {
+            ThrowIfFailed(strip.Context(), neb_strips_exchange(strip.Context(), m_comm, planes, nPlanes, swaps, nSwaps, commandList), "neb_strips_exchange");
+        }
+
+    private:
+        static void Check(int status, const char* what)
+        {
+            if (status != NEB_OK)
+                throw NebException(status, std::string(what) + ": " + neb_strips_last_error());
+        }
+        void* m_comm = nullptr;
     };
 
 } // namespace Neb

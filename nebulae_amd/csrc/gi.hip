@@ -105,6 +105,12 @@ __device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine
         block_counts[blockIdx.x] += total; // slot owned by this workgroup; launches on one stream are ordered
 }
 
+#ifndef NEB_FAST_RAYGEN
+#define NEB_FAST_RAYGEN 0 // A/B arm: 1 = 1-ulp hardware rcp / rsq / sqrt / x^5 in ray generation, 2 = also v_sin / v_cos.  Measured: the
+                          // kernel takes 380 us either way (377 us exact) although ray generation is ~15 % of its instructions, and
+                          // six parity tests leave their 2e-5 band (a direction that moves by an ulp lands on another texel footprint)
+#endif
+template <bool FAST, bool FAST_TRIG>
 __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         const uint2 wp = a.world_pos[i];
         const float3 worldPos = f3(half_bits_to_float(wp.x & 0xffffu), half_bits_to_float(wp.x >> 16), half_bits_to_float(wp.y & 0xffffu));
         const uint32_t nzw = a.normal[i].y;
-        const float3 SN = oct_unpack(half_bits_to_float(nzw & 0xffffu), half_bits_to_float(nzw >> 16));
+        const float3 SN = oct_unpack<FAST>(half_bits_to_float(nzw & 0xffffu), half_bits_to_float(nzw >> 16));
         const float metalness = half_bits_to_float(a.rough_metal[i] >> 16);
         uint32_t rng;
         float3 V;
@@ -132,11 +138,11 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         (void)rand01(rng); // consumed by NrcCreatePathState (:438)
         const float3 F0 = specular_f0(albedo, metalness);
         float3 throughput = f3(1, 1, 1) * (albedo * (1.0f - metalness)); // :474
-        const float pd = 1.0f - specular_probability(saturate1(dot3(normalize3(V), SN)), F0, albedo);
+        const float pd = 1.0f - specular_probability<FAST>(saturate1(dot3(normalize3<FAST>(V), SN)), F0, albedo);
         if (rand01(rng) < pd)
-            throughput = f3(throughput.x / pd, throughput.y / pd, throughput.z / pd); // :476-479
+            throughput = f3(fdiv<FAST>(throughput.x, pd), fdiv<FAST>(throughput.y, pd), fdiv<FAST>(throughput.z, pd)); // :476-479
         const float u0 = rand01(rng), u1 = rand01(rng);
-        const float3 dir = cosine_hemisphere_aligned(u0, u1, SN);
+        const float3 dir = cosine_hemisphere_aligned<FAST, FAST_TRIG>(u0, u1, SN);
         const float3 org = worldPos + SN * 1e-2f; // :138
         const bool bounce = a.c.maxPathVertices > 1; // for (bounce = 1; bounce < nrcMaxPathVertices; ...)
         a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
@@ -684,7 +690,7 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
             a.bounce = b;
             if (b == 1)
-                hipLaunchKernelGGL(gi_raygen_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
             if (g->sort_bounce) {
                 uint32_t* bs = g->d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
                 GI_HIP(ctx, ray_sort_pairs(bs + a.first_px, bs + npx + a.first_px, bs + 2 * npx + a.first_px, bs + 3 * npx + a.first_px,

@@ -76,7 +76,7 @@ __device__ __forceinline__ float rand01(uint32_t& s)
 }
 
 // octahedron_encoding.hlsli:16-34
-__device__ __forceinline__ float3 oct_unpack(float ex, float ey)
+template <bool FAST = false> __device__ __forceinline__ float3 oct_unpack(float ex, float ey)
 {
     float3 v = f3(ex, ey, 1.0f - fabsf(ex) - fabsf(ey));
     if (v.z < 0.0f) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ float3 oct_unpack(float ex, float ey)
         v.x = nx;
         v.y = ny;
     }
-    return normalize3(v);
+    return normalize3<FAST>(v);
 }
 __device__ __forceinline__ float2 oct_pack(float3 v)
 {
@@ -151,10 +151,10 @@ template <bool FAST = false> __device__ __forceinline__ float specular_probabili
     const float p = fdiv<FAST>(diff, fmaxf(0.0001f, fres + diff));
     return fminf(fmaxf(p, 0.1f), 0.9f);
 }
-template <bool FAST = false> __device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
+template <bool FAST = false, bool FAST_TRIG = false> __device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
 {
     const float a = fsqrt<FAST>(u0), b = kPiTwo * u1;
-    const float3 z = f3(a * cosf(b), a * sinf(b), fsqrt<FAST>(1.0f - u0));
+    const float3 z = f3(a * (FAST_TRIG ? __cosf(b) : cosf(b)), a * (FAST_TRIG ? __sinf(b) : sinf(b)), fsqrt<FAST>(1.0f - u0));
     const float3 up = fabsf(sn.z) < 0.999f ? f3(0, 0, 1) : f3(1, 0, 0);
     const float3 tx = normalize3<FAST>(cross3(up, sn));
     const float3 ty = cross3(sn, tx);

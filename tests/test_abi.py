@@ -75,7 +75,8 @@ def test_cpp_mirror_header_compiles_against_the_abi(tmp_path):
     import subprocess
     src = tmp_path / "use.cpp"
     src.write_text('#include "nebulae_hip.hpp"\n'
-                   'int main() { Neb::SVGFDenoiser d; Neb::GIPathtracer g(d);\n'
+                   'int main() { Neb::SVGFDenoiser d; Neb::GIPathtracer g(d); Neb::StripExchange x;\n'
+                   '  try { x.Init(0, 0, 0, nullptr); return 3; } catch (const Neb::NebException& e) { if (e.Status != NEB_ERR_INVALID_ARG) return 4; }\n'
                    '  try { d.Init(0, 0); } catch (const Neb::NebException& e) { return e.Status == NEB_ERR_INVALID_ARG ? 0 : 2; }\n'
                    '  return 1; }\n')
     exe = tmp_path / "use"
