@@ -68,6 +68,7 @@ struct GiArgs {
     unsigned long long* ray_counter; // diagnostics: [1..4] traversal steps (only touched when stats != 0)
     uint32_t* bounce_counts;     // per-workgroup bounce-ray counts
     uint32_t* shadow_counts;     // per-workgroup shadow-ray counts
+    uint32_t* resume_counts;     // the same for gi_resume_shade_kernel (it runs beside gi_shade_kernel: its own slots)
     uint32_t W, row_begin, row0, row1, tiles_x;
     uint32_t sample;             // index of the sample this launch handles
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
@@ -81,7 +82,40 @@ struct GiArgs {
     uint32_t raygen_only;        // 1: gi_raygen_trace_kernel only writes the ray record and its key (a sorted trace follows)
     float smin[3], sinv[3];      // scene box for the Morton keys
     uint32_t first_px, n_px;     // dispatched pixel range [first_px, first_px + n_px) of the resident planes
+    // tail suspension of the closest-hit pass (gi_device.h: traverse_core): a wave whose live lanes drop to suspend_lanes
+    // parks them -- 32-dword records, kSuspendSlots per wave -- and gi_resume_trace_kernel finishes them in dense waves
+    uint32_t suspend_lanes;      // 0 = off
+    uint32_t* suspend_records;   // [waves][kSuspendSlots][32]: {pixel, node, sp, node visits, triangle tests, hit t u v tri, stack[23]}
+    uint32_t* suspend_counts;    // [waves]: records parked by each wave of the launch
+    uint32_t n_waves;            // waves of the closest-hit launch
 };
+constexpr uint32_t kSuspendSlots = 8; // upper bound of "gi_suspend_lanes"
+constexpr uint32_t kSuspendRecordDwords = 32;
+static_assert(9 + kSuspendMaxStack == kSuspendRecordDwords, "suspend record layout");
+
+// Parks the suspended lanes of this wave (every lane of the wave calls it; `suspended` is false for the others).
+__device__ __forceinline__ void park_suspended(const GiArgs& a, bool suspended, uint32_t pixel, int node, const TravStack& st, const Hit& hit)
+{
+    const unsigned long long mask = __ballot(suspended);
+    if (threadIdx.x == 0)
+        a.suspend_counts[blockIdx.x] = (uint32_t)__popcll(mask);
+    if (!suspended)
+        return;
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << threadIdx.x) - 1ull));
+    uint32_t* rec = a.suspend_records + ((size_t)blockIdx.x * kSuspendSlots + rank) * kSuspendRecordDwords;
+    rec[0] = pixel;
+    rec[1] = (uint32_t)node;
+    rec[2] = (uint32_t)st.sp;
+    rec[3] = hit.node_visits;
+    rec[4] = hit.tri_tests;
+    rec[5] = __float_as_uint(hit.t); // the best hit so far (t = tmax, triangle = ~0: none yet)
+    rec[6] = __float_as_uint(hit.u);
+    rec[7] = __float_as_uint(hit.v);
+    rec[8] = hit.tri;
+    for (int k = 0; k < st.sp; ++k)
+        rec[9 + k] = (uint32_t)(k < kLdsStack ? st.lds[64 * k] : st.spill[k - kLdsStack]);
+}
+
 
 __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
 {
@@ -118,6 +152,16 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
     size_t i;
     const bool active = gi_pixel(a, x, y, i);
     uint32_t rays = 0;
+    // traversal state, kept outside the branch: the lanes a suspended wave parks are written out at wave level below
+    Hit hit;
+    hit.t = kTraceMax;
+    hit.u = hit.v = 0.0f;
+    hit.tri = ~0u;
+    hit.node_visits = hit.tri_tests = 0;
+    int spill_mem[kSpillStack];
+    TravStack st{stack_mem + threadIdx.x, spill_mem, 0};
+    int node = kTravDone;
+    bool suspended = false;
     if (active) {
         const float3 albedo = unpack_r11g11b10(a.albedo[i]);
         const uint2 wp = a.world_pos[i];
@@ -156,11 +200,16 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
             a.bsort_keys[i] = bounce ? bounce_sort_key(org, dir, a.smin, a.sinv) : (1u << kSortBits) - 1u;
             a.bsort_vals[i] = (uint32_t)i;
         }
-        if (bounce && !a.raygen_only) {
-            Hit hit;
-            if (traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit, a.stats != 0))
+        if (bounce && !a.raygen_only && a.S.n_tris) {
+            bool found = false;
+            node = a.S.root;
+            suspended = a.stats ? traverse_core<false, true, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes)
+                                : traverse_core<false, false, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes);
+            if (suspended) // parked: gi_resume_shade_kernel owns this pixel from here (its state goes into a record below)
+                h = make_float4(-3.0f, 0.f, 0.f, 0.f);
+            else if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
-            if (a.stats) { // diagnostics only
+            if (a.stats && !suspended) { // diagnostics only
                 atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
                 atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
                 a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2)); // loop iterations of this ray
@@ -168,6 +217,8 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         }
         a.R.hit[i] = h;
     }
+    if (a.suspend_lanes)
+        park_suspended(a, suspended, (uint32_t)i, node, st, hit);
     count_rays(a.bounce_counts, rays);
 }
 
@@ -203,130 +254,198 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_bounce_trace_kernel(Gi
         count_rays(a.bounce_counts, rays);
 }
 
+// What gi_shade_kernel leaves for a pixel's shadow pass (GiRecords::srec) and how many shadow rays it made.
+struct ShadeOut {
+    float4 rec_o = {0.f, 0.f, 0.f, 0.f}, shadow_d = {0.f, 0.f, 0.f, 0.f} /* valid = 0: no shadow ray */, rec_c = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f};
+    uint32_t rays = 0;
+};
+
+// Shading of path vertex a.bounce of pixel i, whose bounce ray ended in `h` {t (< 0 miss), u, v, triangle}: miss -> sky; hit ->
+// ReconstructSurfaceData, sun-disk shadow ray + BRDF contribution, and for maxPathVertices > 2 the next bounce ray.
 // FAST: the arithmetic policy of gi_device.h (1-ulp hardware rcp / rsq / sqrt / sin / cos, the forms an HLSL compiler emits);
 // FAST = false is the C arithmetic of the oracle (option "gi_exact_shade", see neb_set_option).
+template <bool FAST>
+__device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const float4 h, ShadeOut& o)
+{
+    const float4 pth = a.R.path[i];
+    const float4 rd = a.R.ray_d[i];
+    const uint32_t trav_iters = a.stats ? __float_as_uint(a.R.srec[4 * i + kSrContrib].w) : 0u; // diagnostics (written by the tracer)
+    float3 throughput = f3(pth.x, pth.y, pth.z);
+    if (!(a.sample == 0 && a.bounce == 1))
+        o.sum = a.R.srec[4 * i + kSrSum];
+    float4 next_d = make_float4(0.f, 0.f, 0.f, 0.f);   // alive = 0: the path ends here
+    neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
+    const bool alive = rd.w != 0.0f; // (vertex 1 with maxPathVertices <= 1: hit.x == -2, nothing is added)
+    if (alive && h.x == -1.0f) { // miss: radiance += skyColor * throughput (:508)
+        o.sum.x += a.c.skyColor[0] * throughput.x;
+        o.sum.y += a.c.skyColor[1] * throughput.y;
+        o.sum.z += a.c.skyColor[2] * throughput.z;
+    } else if (alive && h.x >= 0.0f) {
+        const uint32_t tri = __float_as_uint(h.w);
+        Surface surf;
+        uint32_t geom;
+        const bool shaded = reconstruct_surface<FAST>(a.S, tri, h.y, h.z, surf, geom);
+        dbg.t = h.x;
+        dbg.geometry = geom;
+        if (a.hits)
+            dbg.primitive = __float_as_uint(a.S.shade[8 * (size_t)tri + 7].x);
+        if (shaded) {
+            const float4 ro = a.R.ray_o[i];
+            const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
+            const float3 hitP = org + dir * h.x;
+            const float3 V = normalize3<FAST>(-dir); // :522
+            uint32_t rng = __float_as_uint(pth.w);
+            const float a0 = rand01(rng), a1 = rand01(rng);
+            const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<FAST>(a1);
+            const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
+            const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
+            const float3 L = normalize3<FAST>(-sun_dir);
+            const float3 Bv = normalize3<FAST>(perpendicular(L));
+            const float3 T = cross3(Bv, L);
+            // (the disk offset is scaled by tan(0.29 deg) = 0.005: the ~1e-6 error of v_sin / v_cos moves the direction by
+            // less than an ulp, so the hardware forms are safe here; the hemisphere sampler keeps sinf / cosf)
+            const float sn_a = FAST ? __sinf(angle) : sinf(angle), cs_a = FAST ? __cosf(angle) : cosf(angle);
+            const float3 inc = normalize3<FAST>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
+            const bool transition = dot3(surf.GN, inc) <= 0.0f;
+            const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
+            const float3 O = evaluate_direct_brdf<FAST>(surf, V, L) * sun_rad * throughput; // :573-574
+            o.rec_o = make_float4(so.x, so.y, so.z, 0.001f);
+            o.shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
+            o.rec_c = make_float4(O.x, O.y, O.z, 0.f);
+            o.rays = 1;
+            if (a.bounce + 1 < a.c.maxPathVertices) { // not the last vertex (:579-583): sample the next bounce
+                // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
+                // so the Rand(rng) of :614 returns the same number as the first of them.
+                uint32_t rng_copy = rng;
+                const float3 SNn = normalize3<FAST>(surf.SN);
+                const float e0 = rand01(rng_copy), e1 = rand01(rng_copy);
+                const float3 Ld = cosine_hemisphere_aligned<FAST>(e0, e1, SNn);
+                const float pdiff = 1.0f - specular_probability<FAST>(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
+                const float3 no = hitP + surf.GN * 1e-2f; // :607
+                throughput = throughput * (surf.albedo * (1.0f - surf.metalness)); // :613
+                if (rand01(rng) < pdiff)
+                    throughput = f3(fdiv<FAST>(throughput.x, pdiff), fdiv<FAST>(throughput.y, pdiff), fdiv<FAST>(throughput.z, pdiff)); // :614-618
+                a.R.ray_o[i] = make_float4(no.x, no.y, no.z, 0.001f);
+                next_d = make_float4(Ld.x, Ld.y, Ld.z, 1.0f);
+                a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
+            } // (the last vertex leaves R.path alone: the next sample's ray generation rewrites it)
+            if (a.sample + 1 < a.c.samplesPerPixel) // V and the RNG stream carry over to the next sample only
+                a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
+        }
+    }
+    if (a.bounce + 1 < a.c.maxPathVertices) // nobody traces or shades a ray after the last vertex
+        a.R.ray_d[i] = next_d;
+    if (a.sort_keys) { // shadow rays are all (nearly) parallel: grouping them by origin makes a wave's rays walk the same nodes
+        uint32_t key = (1u << kSortBits) - 1u; // pixels without a shadow ray sort last
+        if (o.shadow_d.w != 0.0f) {
+            key = min(morton30(f3(o.rec_o.x, o.rec_o.y, o.rec_o.z), a.smin, a.sinv) >> (30 - kSortBits), (1u << kSortBits) - 2u);
+        }
+        a.sort_keys[i] = key;
+        a.sort_vals[i] = (uint32_t)i;
+    }
+    if (a.bsort_keys) { // next bounce ray: direction octant, then origin
+        uint32_t key = (1u << kSortBits) - 1u;
+        if (next_d.w != 0.0f) {
+            const float4 no4 = a.R.ray_o[i];
+            key = bounce_sort_key(f3(no4.x, no4.y, no4.z), f3(next_d.x, next_d.y, next_d.z), a.smin, a.sinv);
+        }
+        a.bsort_keys[i] = key;
+        a.bsort_vals[i] = (uint32_t)i;
+    }
+    if (a.hits && a.bounce == 1) {
+        if (a.stats)
+            dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py)
+        a.hits[i] = dbg;
+    }
+}
+
+// One wave per 8x8 pixel tile.  Pixels whose bounce ray was parked by a thinned-out closest-hit wave (hit.x == -3) are not
+// this kernel's: gi_resume_shade_kernel finishes their traversal and shades them, concurrently, on another stream.
 template <bool FAST>
 __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
 {
     uint32_t x, y;
     size_t i;
     const bool active = gi_pixel(a, x, y, i);
-    uint32_t rays = 0;
-    // the pixel's shadow record (GiRecords::srec), built in registers and stored through an LDS transpose below
-    float4 rec_o = make_float4(0.f, 0.f, 0.f, 0.f), rec_c = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 shadow_d = make_float4(0.f, 0.f, 0.f, 0.f); // valid = 0: no shadow ray
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    ShadeOut o;
+    bool parked = false;
     if (active) {
         const float4 h = a.R.hit[i];
-        const float4 pth = a.R.path[i];
-        const float4 rd = a.R.ray_d[i];
-        const uint32_t trav_iters = a.stats ? __float_as_uint(a.R.srec[4 * i + kSrContrib].w) : 0u; // diagnostics (written by the tracer)
-        float3 throughput = f3(pth.x, pth.y, pth.z);
-        if (!(a.sample == 0 && a.bounce == 1))
-            sum = a.R.srec[4 * i + kSrSum];
-        float4 next_d = make_float4(0.f, 0.f, 0.f, 0.f);   // alive = 0: the path ends here
-        neb_gi_hit dbg = {-1.0f, ~0u, ~0u, 0u};
-        const bool alive = rd.w != 0.0f; // (vertex 1 with maxPathVertices <= 1: hit.x == -2, nothing is added)
-        if (alive && h.x == -1.0f) { // miss: radiance += skyColor * throughput (:508)
-            sum.x += a.c.skyColor[0] * throughput.x;
-            sum.y += a.c.skyColor[1] * throughput.y;
-            sum.z += a.c.skyColor[2] * throughput.z;
-        } else if (alive && h.x >= 0.0f) {
-            const uint32_t tri = __float_as_uint(h.w);
-            Surface surf;
-            uint32_t geom;
-            const bool shaded = reconstruct_surface<FAST>(a.S, tri, h.y, h.z, surf, geom);
-            dbg.t = h.x;
-            dbg.geometry = geom;
-            if (a.hits)
-                dbg.primitive = __float_as_uint(a.S.shade[8 * (size_t)tri + 7].x);
-            if (shaded) {
-                const float4 ro = a.R.ray_o[i];
-                const float3 org = f3(ro.x, ro.y, ro.z), dir = f3(rd.x, rd.y, rd.z);
-                const float3 hitP = org + dir * h.x;
-                const float3 V = normalize3<FAST>(-dir); // :522
-                uint32_t rng = __float_as_uint(pth.w);
-                const float a0 = rand01(rng), a1 = rand01(rng);
-                const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<FAST>(a1);
-                const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
-                const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
-                const float3 L = normalize3<FAST>(-sun_dir);
-                const float3 Bv = normalize3<FAST>(perpendicular(L));
-                const float3 T = cross3(Bv, L);
-                // (the disk offset is scaled by tan(0.29 deg) = 0.005: the ~1e-6 error of v_sin / v_cos moves the direction by
-                // less than an ulp, so the hardware forms are safe here; the hemisphere sampler keeps sinf / cosf)
-                const float sn_a = FAST ? __sinf(angle) : sinf(angle), cs_a = FAST ? __cosf(angle) : cosf(angle);
-                const float3 inc = normalize3<FAST>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
-                const bool transition = dot3(surf.GN, inc) <= 0.0f;
-                const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
-                const float3 O = evaluate_direct_brdf<FAST>(surf, V, L) * sun_rad * throughput; // :573-574
-                rec_o = make_float4(so.x, so.y, so.z, 0.001f);
-                shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
-                rec_c = make_float4(O.x, O.y, O.z, 0.f);
-                rays = 1;
-                if (a.bounce + 1 < a.c.maxPathVertices) { // not the last vertex (:579-583): sample the next bounce
-                    // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
-                    // so the Rand(rng) of :614 returns the same number as the first of them.
-                    uint32_t rng_copy = rng;
-                    const float3 SNn = normalize3<FAST>(surf.SN);
-                    const float e0 = rand01(rng_copy), e1 = rand01(rng_copy);
-                    const float3 Ld = cosine_hemisphere_aligned<FAST>(e0, e1, SNn);
-                    const float pdiff = 1.0f - specular_probability<FAST>(saturate1(dot3(V, SNn)), specular_f0(surf.albedo, surf.metalness), surf.albedo);
-                    const float3 no = hitP + surf.GN * 1e-2f; // :607
-                    throughput = throughput * (surf.albedo * (1.0f - surf.metalness)); // :613
-                    if (rand01(rng) < pdiff)
-                        throughput = f3(fdiv<FAST>(throughput.x, pdiff), fdiv<FAST>(throughput.y, pdiff), fdiv<FAST>(throughput.z, pdiff)); // :614-618
-                    a.R.ray_o[i] = make_float4(no.x, no.y, no.z, 0.001f);
-                    next_d = make_float4(Ld.x, Ld.y, Ld.z, 1.0f);
-                    a.R.path[i] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(rng));
-                } // (the last vertex leaves R.path alone: the next sample's ray generation rewrites it)
-                if (a.sample + 1 < a.c.samplesPerPixel) // V and the RNG stream carry over to the next sample only
-                    a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
-            }
-        }
-        if (a.bounce + 1 < a.c.maxPathVertices) // nobody traces or shades a ray after the last vertex
-            a.R.ray_d[i] = next_d;
-        if (a.sort_keys) { // shadow rays are all (nearly) parallel: grouping them by origin makes a wave's rays walk the same nodes
-            uint32_t key = (1u << kSortBits) - 1u; // pixels without a shadow ray sort last
-            if (shadow_d.w != 0.0f) {
-                key = min(morton30(f3(rec_o.x, rec_o.y, rec_o.z), a.smin, a.sinv) >> (30 - kSortBits), (1u << kSortBits) - 2u);
-            }
-            a.sort_keys[i] = key;
-            a.sort_vals[i] = (uint32_t)i;
-        }
-        if (a.bsort_keys) { // next bounce ray: direction octant, then origin
-            uint32_t key = (1u << kSortBits) - 1u;
-            if (next_d.w != 0.0f) {
-                const float4 no4 = a.R.ray_o[i];
-                key = bounce_sort_key(f3(no4.x, no4.y, no4.z), f3(next_d.x, next_d.y, next_d.z), a.smin, a.sinv);
-            }
-            a.bsort_keys[i] = key;
-            a.bsort_vals[i] = (uint32_t)i;
-        }
-        if (a.hits && a.bounce == 1) {
-            if (a.stats)
-                dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py)
-            a.hits[i] = dbg;
-        }
+        parked = a.suspend_lanes != 0u && a.bounce == 1u && h.x == -3.0f;
+        if (!parked)
+            shade_pixel<FAST>(a, i, h, o);
     }
+    const unsigned long long parked_mask = __ballot(parked); // lane l <-> pixel (l & 7, l >> 3) of the tile
     // Store the 64-byte records of the wave's 8x8 tile.  Lane-per-pixel stores would write 16 bytes at a 64-byte stride
     // four times over; transposed through LDS, every store instruction writes two 512-byte runs (one tile row each).
     __shared__ float4 xpose[64 * 4];
     const uint32_t lane = threadIdx.x;
-    xpose[lane * 4 + kSrO] = rec_o;
-    xpose[lane * 4 + kSrD] = shadow_d;
-    xpose[lane * 4 + kSrContrib] = rec_c;
-    xpose[lane * 4 + kSrSum] = sum;
+    xpose[lane * 4 + kSrO] = o.rec_o;
+    xpose[lane * 4 + kSrD] = o.shadow_d;
+    xpose[lane * 4 + kSrContrib] = o.rec_c;
+    xpose[lane * 4 + kSrSum] = o.sum;
     __syncthreads(); // the workgroup is this one wave
     const uint32_t tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t row = 2 * k + (lane >> 5), col = (lane & 31u) >> 2, comp = lane & 3u;
         const uint32_t px = tile_x * 8 + col, py = a.row0 + tile_y * 8 + row;
-        if (px < a.W && py < a.row1)
+        if (px < a.W && py < a.row1 && !((parked_mask >> (row * 8 + col)) & 1ull))
             a.R.srec[4 * ((size_t)(py - a.row_begin) * a.W + px) + comp] = xpose[(row * 8 + col) * 4 + comp];
     }
-    count_rays(a.shadow_counts, rays);
+    count_rays(a.shadow_counts, o.rays);
+}
+
+// Finishes the parked rays -- one per lane, dense waves -- and shades them: the second half of tail suspension
+// (traverse_core, gi_device.h: an A/B arm, off by default).  Runs on a side stream beside gi_shade_kernel, which skips
+// exactly these pixels.
+template <bool FAST>
+__global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_resume_shade_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    // lane j <-> slot (j % suspend_lanes) of wave (j / suspend_lanes): a thinned-out wave parks on average 3.3 of 4 lanes, so
+    // the slots are dense enough as they are (a prefix-sum compaction in one workgroup cost 72 us, more than it could save)
+    const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t w = j / a.suspend_lanes, k = j - w * a.suspend_lanes;
+    ShadeOut o;
+    if (w < a.n_waves && k < a.suspend_counts[w]) {
+        const uint32_t* rec = a.suspend_records + ((size_t)w * kSuspendSlots + k) * kSuspendRecordDwords;
+        const size_t i = rec[0];
+        int node = (int)rec[1];
+        int spill_mem[kSpillStack];
+        TravStack st{stack_mem + threadIdx.x, spill_mem, 0};
+        const int sp = (int)rec[2];
+        for (int q = 0; q < sp; ++q)
+            st.push((int)rec[9 + q]);
+        const float4 ro = a.R.ray_o[i], rd = a.R.ray_d[i];
+        Hit hit;
+        hit.node_visits = rec[3];
+        hit.tri_tests = rec[4];
+        hit.t = __uint_as_float(rec[5]);
+        hit.u = __uint_as_float(rec[6]);
+        hit.v = __uint_as_float(rec[7]);
+        hit.tri = rec[8];
+        bool found = hit.tri != ~0u;
+        if (a.stats)
+            (void)traverse_core<false, true, false>(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, st, node, hit, found, 0);
+        else
+            (void)traverse_core<false, false, false>(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, st, node, hit, found, 0);
+        // (R.hit[i] keeps its "parked" mark: gi_shade_kernel runs concurrently and must not find a finished hit there and shade
+        // the pixel a second time; nothing else reads the vertex-1 hit record)
+        const float4 h = found ? make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri)) : make_float4(-1.0f, 0.f, 0.f, 0.f);
+        if (a.stats) { // diagnostics only
+            atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
+            atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
+            a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2));
+        }
+        shade_pixel<FAST>(a, i, h, o);
+        float4* rec_out = a.R.srec + 4 * i;
+        rec_out[kSrO] = o.rec_o;
+        rec_out[kSrD] = o.shadow_d;
+        rec_out[kSrContrib] = o.rec_c;
+        rec_out[kSrSum] = o.sum;
+    }
+    count_rays(a.resume_counts, o.rays);
 }
 
 // (A persistent-wave variant with per-lane ray refill was measured and dropped: lanes of a wave finish after
@@ -668,6 +787,9 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         }
     }
     a.defer_resolve = g->defer_resolve ? 1u : 0u;
+    a.suspend_lanes = g->sort_bounce ? 0u : g->suspend_lanes; // (a sorted bounce trace runs through gi_bounce_trace_kernel)
+    a.suspend_records = a.suspend_counts = nullptr;
+    a.n_waves = 0;
     g->pending_spp = c->samplesPerPixel;
     g->pending_row0 = row0;
     g->pending_row1 = row1;
@@ -676,21 +798,52 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
     if (!g->d_block_counts) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t)));
-        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow rays made by the resume pass}
+        GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
         g->d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    a.resume_counts = g->d_block_counts + 2 * g->n_block_counts;
+    if (a.suspend_lanes) {
+        if (!g->d_suspend) { // records for every wave a launch over the resident rows can have, + counts, list, total
+            const size_t words = n_blocks * kSuspendSlots * kSuspendRecordDwords + n_blocks;
+            void* p = nullptr;
+            GI_HIP(ctx, hipMalloc(&p, words * sizeof(uint32_t)));
+            g->allocs.push_back(p);
+            g->d_suspend = (uint32_t*)p;
+        }
+        a.suspend_records = g->d_suspend;
+        a.suspend_counts = g->d_suspend + n_blocks * kSuspendSlots * kSuspendRecordDwords;
+        a.n_waves = grid.x;
+        if (!g->side_stream) { // the resume pass runs beside the shade pass: a stream and two events of the library's own
+            GI_HIP(ctx, hipStreamCreateWithFlags(&g->side_stream, hipStreamNonBlocking));
+            GI_HIP(ctx, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+            GI_HIP(ctx, hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+        }
+    }
+    bool forked = false;
     const uint32_t n_vertices = c->maxPathVertices > 1 ? c->maxPathVertices - 1 : 1; // path vertices traced per sample
     for (uint32_t s = 0; s < c->samplesPerPixel; ++s) {
         a.sample = s;
         for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
             a.bounce = b;
-            if (b == 1)
+            if (b == 1) {
                 hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
+                if (a.suspend_lanes && !a.raygen_only) { // fork: the parked rays are finished and shaded on the side stream
+                    GI_HIP(ctx, hipEventRecord(g->ev_fork, (hipStream_t)stream));
+                    GI_HIP(ctx, hipStreamWaitEvent(g->side_stream, g->ev_fork, 0));
+                    const dim3 rgrid((grid.x * a.suspend_lanes + 63u) / 64u);
+                    if (kFastShade && !g->exact_shade)
+                        hipLaunchKernelGGL(gi_resume_shade_kernel<true>, rgrid, block, 0, g->side_stream, a);
+                    else
+                        hipLaunchKernelGGL(gi_resume_shade_kernel<false>, rgrid, block, 0, g->side_stream, a);
+                    GI_HIP(ctx, hipEventRecord(g->ev_join, g->side_stream));
+                    forked = true;
+                }
+            }
             if (g->sort_bounce) {
                 uint32_t* bs = g->d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
                 GI_HIP(ctx, ray_sort_pairs(bs + a.first_px, bs + npx + a.first_px, bs + 2 * npx + a.first_px, bs + 3 * npx + a.first_px,
@@ -705,6 +858,10 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
                 hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
             else
                 hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+            if (forked) { // join: the sort and the shadow pass read the records of both
+                GI_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, g->ev_join, 0));
+                forked = false;
+            }
             if (g->sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the
                 // sorted pixel indices land back in vals
@@ -768,14 +925,15 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
     if (!g->d_block_counts) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t)));
-        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow rays made by the resume pass}
+        GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
         g->d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    a.resume_counts = g->d_block_counts + 2 * g->n_block_counts;
     hipLaunchKernelGGL(pbr_direct_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
@@ -809,7 +967,7 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
     GiState* g = ctx->gi;
     GI_GUARD(ctx);
     unsigned long long v[8] = {};
-    std::vector<uint32_t> counts(2 * g->n_block_counts);
+    std::vector<uint32_t> counts(3 * g->n_block_counts);
     GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (g->d_block_counts)
         GI_HIP(ctx, hipMemcpyAsync(counts.data(), g->d_block_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -916,6 +1074,13 @@ int gi_set_max_bvh_depth(neb_ctx* ctx, int depth)
     if (!ctx->gi || depth < 1 || depth > (kLdsStack + kSpillStack) / 3)
         return NEB_ERR_STATE;
     ctx->gi->max_bvh_depth = (uint32_t)depth;
+    return NEB_OK;
+}
+int gi_set_suspend_lanes(neb_ctx* ctx, int lanes)
+{
+    if (!ctx->gi || lanes < 0 || lanes > (int)kSuspendSlots)
+        return NEB_ERR_STATE;
+    ctx->gi->suspend_lanes = (uint32_t)lanes;
     return NEB_OK;
 }
 int gi_set_exact_shade(neb_ctx* ctx, int on)

@@ -313,22 +313,29 @@ struct TravStack {
 // round trips per iteration.  Shadow rays skip the front-to-back ordering of the children.
 constexpr int kTravDone = (int)0x80000000;
 
-template <bool ANY_HIT, bool STATS>
-__device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit)
+// Tail suspension (closest-hit rays; option "gi_suspend_lanes", OFF by default).  The lanes of a wave need very different
+// numbers of iterations (p50 16, p99 29, the slowest of 64 lanes ~33), so the last third of a wave's life runs a handful
+// of lanes at full instruction cost.  With SUSPEND, a wave stops as soon as at most `suspend_lanes` of its lanes are still
+// traversing: they leave with their state {node, stack, best hit so far} and gi_resume_shade_kernel finishes all such
+// stragglers in dense waves.  A resumed ray continues exactly where it stopped: same visits, same hits (the parity tests
+// run with it on as well).  Replayed on the host from measured per-ray iteration counts (tools/gi_divergence.py) it
+// promised x0.81 of the wave-iterations at 4 lanes (5 % of the rays parked), x0.78 at 8 -- and the closest-hit launch does
+// drop from 383 to 338 / 322 us.  But the parked rays are the LONGEST ones: their follow-up pass is a chain of ~60
+// dependent node fetches whatever its width -- 56-73 us run alone, 157-189 us run beside the bandwidth-bound shade pass
+// (which it slows from 140 to 155-188 us) -- so the GI dispatch as a whole gets no faster (752 us off, 760-772 us on).
+// Kept as an A/B arm.
+constexpr int kSuspendMaxStack = 23; // stack entries a suspended ray can carry (record = 32 dwords = 128 B: 9 of state + these)
+
+// The traversal loop proper, resumable: starts from (node, st, hit, found) and runs until the ray is done or -- with
+// SUSPEND -- the wave is down to `suspend_lanes` live lanes; returns true when it stopped early (node != kTravDone then).
+template <bool ANY_HIT, bool STATS, bool SUSPEND>
+__device__ __forceinline__ bool traverse_core(const SceneView& S, float3 o, float3 d, float tmin, TravStack& st, int& node, Hit& hit, bool& found,
+                                              int suspend_lanes)
 {
-    hit.t = tmax;
-    hit.tri = ~0u;
-    hit.node_visits = hit.tri_tests = 0;
-    if (S.n_tris == 0)
-        return false;
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     // byte offset of the plane the ray enters through, per axis, inside a Bvh4Node (the exit plane is offset ^ 64)
     const uint32_t onx = d.x < 0.0f ? 64u : 0u, ony = d.y < 0.0f ? 80u : 16u, onz = d.z < 0.0f ? 96u : 32u;
-    bool found = false;
-    int spill_mem[kSpillStack];
-    TravStack st{lds_stack, spill_mem, 0};
-    int node = S.root;
     constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
         if (node >= 0) {
@@ -426,11 +433,34 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
                     }
                 }
             }
-            if (ANY_HIT && found)
-                return true;
+            if (ANY_HIT && found) {
+                node = kTravDone;
+                return false;
+            }
             node = st.sp ? st.pop() : kTravDone;
         }
+        if (SUSPEND) { // (all lanes still in the loop see the same ballot: the branch is uniform among them)
+            const unsigned long long live = __ballot(node != kTravDone);
+            if (__popcll(live) <= suspend_lanes && __ballot(node != kTravDone && st.sp > kSuspendMaxStack) == 0ull)
+                return node != kTravDone;
+        }
     }
+    return false;
+}
+
+template <bool ANY_HIT, bool STATS>
+__device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit)
+{
+    hit.t = tmax;
+    hit.tri = ~0u;
+    hit.node_visits = hit.tri_tests = 0;
+    if (S.n_tris == 0)
+        return false;
+    bool found = false;
+    int spill_mem[kSpillStack];
+    TravStack st{lds_stack, spill_mem, 0};
+    int node = S.root;
+    (void)traverse_core<ANY_HIT, STATS, false>(S, o, d, tmin, st, node, hit, found, 0);
     return found;
 }
 

@@ -47,8 +47,10 @@ def scenes():
 
 @pytest.mark.parametrize("name,spp,sort_rays",
                          [(n, s, m) for n in ("cornell", "cornell_factors", "atrium_small") for s, m in ((1, 0), (3, 1), (1, 3), (2, 2))]
-                         + [("atrium_mixed_tex", 1, 1)])
+                         + [("atrium_mixed_tex", 1, 1), ("atrium_small", 2, 1 | 16), ("cornell", 1, 0 | 32)])
 def test_gi_matches_oracle(name, spp, sort_rays):
+    """sort_rays: "gi_sort_rays" mask in the low bits; bits 4+ = "gi_suspend_lanes" (tail suspension of the closest-hit pass
+    on, 4 or 8 lanes: parked rays are finished and shaded by gi_resume_shade_kernel -- same hits, same radiance)."""
     make, cam, W, H = scenes()[name]
     sc = make()
     o = OracleTracer(sc)
@@ -63,7 +65,8 @@ def test_gi_matches_oracle(name, spp, sort_rays):
     base[..., 3] = 1.0
     r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, base)
     r.set_debug_hits(True)
-    r.svgf.set_option("gi_sort_rays", sort_rays)
+    r.svgf.set_option("gi_sort_rays", sort_rays & 3)
+    r.svgf.set_option("gi_suspend_lanes", (sort_rays >> 4) * 4)
     r.ray_count(reset=True)
     r.submit_commands_gi_pathtrace()
     got = r.svgf.download(PLANE_RADIANCE)

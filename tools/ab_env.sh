@@ -17,6 +17,9 @@ rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(f))}
 tot = {r["Name"]: float(r["TotalDurationNs"]) / 1e3 for r in csv.DictReader(open(f))}
 pick = lambda s: sum(v for k, v in rows.items() if s in k)
 build = sum(v for k, v in tot.items() if "ploc_" in k or "collapse_" in k)
-print("%-48s raygen_trace %.1f shade %.1f shadow %.1f  | build kernels %.0f us" % (sys.argv[1], pick("gi_raygen_trace"), pick("gi_shade"), pick("gi_shadow_trace"), build))
+import json
+line = [l for l in open(sys.argv[2] + ".log") if l.startswith("{")]
+j = json.loads(line[-1]) if line else {"value": 0, "kernel_us": {"gi_trace": 0}}
+print("%-44s raygen_trace %.1f resume %.1f shade %.1f shadow %.1f | GI (events) %.1f us, %.1f fps" % (sys.argv[1], pick("gi_raygen_trace"), pick("gi_resume"), pick("gi_shade"), pick("gi_shadow_trace"), j["kernel_us"]["gi_trace"], j["value"]))
 PY
 done

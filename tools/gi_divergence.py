@@ -60,3 +60,20 @@ for G in (256, 512, 1024):
     for N in (8, 16, 24, 32):
         c = compaction_cost(G, N, 2.0)
         print("workgroup %4d rays, rounds of %2d iterations (+2 per live wave and round): cost x%.2f of baseline" % (G, N, c / base))
+
+# (e) tail suspension: a wave stops as soon as at most T of its lanes are still traversing (and it has run at least M
+# iterations); the stragglers' state goes to a queue and a follow-up launch finishes them in dense waves (in queue order).
+tiles = it[: (H // 8) * 8, : (W // 8) * 8].reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64).astype(np.int64)
+srt = np.sort(tiles, axis=1)[:, ::-1]  # descending per wave
+for T in (2, 4, 8, 12, 16):
+    for M in (0, 16):
+        stop = np.maximum(srt[:, T], M)                      # iteration at which only T lanes remain
+        stop = np.minimum(stop, srt[:, 0])
+        first = stop.sum()
+        rem = np.maximum(tiles - stop[:, None], 0)
+        q = rem[rem > 0]                                      # queue order = wave order
+        pad = (-q.size) % 64
+        q = np.concatenate([q, np.zeros(pad, np.int64)]).reshape(-1, 64)
+        second = q.max(axis=1).sum()
+        print("suspend at <= %2d lanes (min %2d iterations): first pass x%.3f + follow-up x%.3f = x%.3f of baseline; %.1f %% of the rays are queued"
+              % (T, M, first / base, second / base, (first + second) / base, 100.0 * (rem > 0).mean()))
