@@ -190,7 +190,7 @@ __global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint6
 constexpr int kSahBins = NEB_SAH_BINS;
 constexpr int kSahThreads = 256;
 
-struct PlocNodes { // (binary tree under construction; the name predates the SAH builder)
+struct BinaryNodes { // the binary tree under construction
     float4* lo;      // {min.xyz, left child as int bits}   (triangles: children = -1)
     float4* hi;      // {max.xyz, right child as int bits}
     uint32_t* size;  // triangles below the node
@@ -204,7 +204,7 @@ struct SahSplit { // result of one segment's split
     float lbox[6], rbox[6];
 };
 
-__global__ void sah_init_kernel(const float4* __restrict__ tris, uint32_t n, PlocNodes N, uint32_t* idx)
+__global__ void sah_init_kernel(const float4* __restrict__ tris, uint32_t n, BinaryNodes N, uint32_t* idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -233,7 +233,7 @@ __device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as
 
 __device__ __forceinline__ int sah_bin(float c, float cmin, float scale) { return min(kSahBins - 1, max(0, (int)((c - cmin) * scale))); }
 
-__global__ __launch_bounds__(kSahThreads) void sah_split_kernel(PlocNodes N, const SahSegment* __restrict__ segs, const uint32_t* __restrict__ idx_in,
+__global__ __launch_bounds__(kSahThreads) void sah_split_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, const uint32_t* __restrict__ idx_in,
                                                                 uint32_t* __restrict__ idx_out, SahSplit* __restrict__ splits)
 {
     // bins: axis 0..2 = x, y, z by centroid; axis 3 = by position (first / second half of the run): the fallback when all
@@ -430,7 +430,7 @@ __global__ void sah_count_kernel(const SahSegment* __restrict__ segs, const SahS
 }
 
 // state[0] = segments of the next level, state[1] = next free node id
-__global__ void sah_emit_kernel(PlocNodes N, const SahSegment* __restrict__ segs, const SahSplit* __restrict__ splits, uint32_t n_segs,
+__global__ void sah_emit_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, const SahSplit* __restrict__ splits, uint32_t n_segs,
                                 const unsigned long long* __restrict__ counts, const unsigned long long* __restrict__ scan, const uint32_t* __restrict__ idx,
                                 const uint32_t* __restrict__ state, uint32_t* __restrict__ state_out, SahSegment* __restrict__ next_segs)
 {
@@ -484,7 +484,7 @@ __global__ void sah_emit_kernel(PlocNodes N, const SahSegment* __restrict__ segs
 // The number of levels is the depth of the BVH4.
 // ------------------------------------------------------------------------------------------------
 struct CollapseArgs {
-    PlocNodes N;
+    BinaryNodes N;
     uint32_t n_tris;
     const float4* tris_in;  // Morton order
     float4* tris_out;       // leaf order of the final tree
@@ -498,7 +498,7 @@ struct CollapseArgs {
     uint32_t level_start, level_count;
 };
 
-__device__ __forceinline__ bool collapse_is_leaf(const PlocNodes& N, int node) { return N.size[node] <= (uint32_t)kMaxLeafTris; }
+__device__ __forceinline__ bool collapse_is_leaf(const BinaryNodes& N, int node) { return N.size[node] <= (uint32_t)kMaxLeafTris; }
 
 __global__ void collapse_open_kernel(CollapseArgs a)
 {
@@ -880,7 +880,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     float4* d_final = (float4*)dalloc((size_t)n * 48, true);   // leaf order of the final tree
     uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8, false);
     uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8, false);
-    PlocNodes N;
+    BinaryNodes N;
     N.lo = (float4*)dalloc(n2 * 16, false);
     N.hi = (float4*)dalloc(n2 * 16, false);
     N.size = (uint32_t*)dalloc(n2 * 4, false);
