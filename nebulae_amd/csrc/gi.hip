@@ -203,8 +203,13 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         if (bounce && !a.raygen_only && a.S.n_tris) {
             bool found = false;
             node = a.S.root;
-            suspended = a.stats ? traverse_core<false, true, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes)
-                                : traverse_core<false, false, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes);
+            if (a.suspend_lanes) // (A/B arm, off by default: its per-iteration ballots are kept out of the product path)
+                suspended = a.stats ? traverse_core<false, true, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes)
+                                    : traverse_core<false, false, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes);
+            else if (a.stats)
+                (void)traverse_core<false, true, false>(a.S, org, dir, 0.01f, st, node, hit, found, 0);
+            else
+                (void)traverse_core<false, false, false>(a.S, org, dir, 0.01f, st, node, hit, found, 0);
             if (suspended) // parked: gi_resume_shade_kernel owns this pixel from here (its state goes into a record below)
                 h = make_float4(-3.0f, 0.f, 0.f, 0.f);
             else if (found)
