@@ -188,7 +188,6 @@ __global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint6
 #define NEB_SAH_BINS 32
 #endif
 constexpr int kSahBins = NEB_SAH_BINS;
-constexpr int kSahThreads = 256;
 
 struct BinaryNodes { // the binary tree under construction
     float4* lo;      // {min.xyz, left child as int bits}   (triangles: children = -1)
@@ -233,6 +232,8 @@ __device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as
 
 __device__ __forceinline__ int sah_bin(float c, float cmin, float scale) { return min(kSahBins - 1, max(0, (int)((c - cmin) * scale))); }
 
+// kSahThreads: 1024 for the first levels (few, long runs: a workgroup walks its run in strides of its size), 256 below
+template <int kSahThreads>
 __global__ __launch_bounds__(kSahThreads) void sah_split_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, const uint32_t* __restrict__ idx_in,
                                                                 uint32_t* __restrict__ idx_out, SahSplit* __restrict__ splits)
 {
@@ -968,7 +969,10 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             const SahSegment* segs = d_segs[passes & 1u];
             const uint32_t* idx_in = d_idx[passes & 1u];
             uint32_t* idx_out = d_idx[(passes + 1u) & 1u];
-            hipLaunchKernelGGL(sah_split_kernel, dim3(n_segs), dim3(kSahThreads), 0, stream, N, segs, idx_in, idx_out, d_splits);
+            if ((size_t)n_segs * 2048 <= (size_t)n) // runs of 2048 primitives and more on average
+                hipLaunchKernelGGL(sah_split_kernel<1024>, dim3(n_segs), dim3(1024), 0, stream, N, segs, idx_in, idx_out, d_splits);
+            else
+                hipLaunchKernelGGL(sah_split_kernel<256>, dim3(n_segs), dim3(256), 0, stream, N, segs, idx_in, idx_out, d_splits);
             const dim3 grid((n_segs + 255) / 256);
             hipLaunchKernelGGL(sah_count_kernel, grid, dim3(256), 0, stream, segs, (const SahSplit*)d_splits, n_segs, d_flags);
             BUILD_HIP(hipGetLastError());
