@@ -19,10 +19,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d "$out/pmc_sq" -- python bench.py --steps 4 --warmup 2 --cpu-frames 0 $extra > "$out/pmc_sq.log" 2>&1 || { tail -20 "$out/pmc_sq.log"; exit 1; }
 echo "[profile_round] pmc SQ done"
+# memory-pipeline counters (own passes): texture-address unit busy cycles, L1 (TCP) accesses / misses to L2, L2 (TCC) hits / misses
+k=0
+for c in "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  k=$((k + 1))
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$out/pmc_mem$k" -- python bench.py --steps 4 --warmup 2 --cpu-frames 0 $extra > "$out/pmc_mem$k.log" 2>&1 || { tail -20 "$out/pmc_mem$k.log"; exit 1; }
+done
+echo "[profile_round] pmc memory pipeline done"
 cp "$out/bench.json" "profiles/${tag}_bench.json"
 cp $(ls "$out"/stats/*/*kernel_stats.csv | head -1) "profiles/${tag}_kernel_stats.csv"
 python tools/traffic_from_pmc.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "profiles/${tag}_hbm_traffic.json" 1920 1080 > /dev/null
 python tools/sq_from_pmc.py "$out/pmc_sq" "profiles/${tag}_sq_counters.json" > /dev/null
+python tools/mem_from_pmc.py "$out/pmc_mem1" "$out/pmc_mem2" "$out/pmc_mem3" "profiles/${tag}_kernel_stats.csv" "profiles/${tag}_mem_counters.json" > /dev/null
 mkdir -p "$out/profiles" && cp profiles/${tag}_* "$out/profiles/"
 python - "$tag" <<'PY'
 import csv, sys
