@@ -269,8 +269,9 @@ struct ShadeOut {
 // ReconstructSurfaceData, sun-disk shadow ray + BRDF contribution, and for maxPathVertices > 2 the next bounce ray.
 // FAST: the arithmetic policy of gi_device.h (1-ulp hardware rcp / rsq / sqrt / sin / cos, the forms an HLSL compiler emits);
 // FAST = false is the C arithmetic of the oracle (option "gi_exact_shade", see neb_set_option).
-template <bool FAST>
-__device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const float4 h, ShadeOut& o)
+// STAGED: the hit triangle's shading record is already in LDS at `staged` (gi_shade_kernel); otherwise it is fetched here.
+template <bool FAST, bool STAGED>
+__device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const float4 h, ShadeOut& o, const float4* staged, uint32_t staged_swz)
 {
     const float4 pth = a.R.path[i];
     const float4 rd = a.R.ray_d[i];
@@ -289,7 +290,12 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
         const uint32_t tri = __float_as_uint(h.w);
         Surface surf;
         uint32_t geom;
-        const bool shaded = reconstruct_surface<FAST>(a.S, tri, h.y, h.z, surf, geom);
+        TriShade ts;
+        if constexpr (STAGED)
+            ts = load_tri_shade_at(staged, staged_swz);
+        else
+            ts = load_tri_shade(a.S, tri);
+        const bool shaded = reconstruct_surface<FAST>(a.S, ts, h.y, h.z, surf, geom);
         dbg.t = h.x;
         dbg.geometry = geom;
         if (a.hits)
@@ -374,17 +380,37 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
     const bool active = gi_pixel(a, x, y, i);
     ShadeOut o;
     bool parked = false;
+    float4 h = make_float4(-2.0f, 0.f, 0.f, 0.f);
     if (active) {
-        const float4 h = a.R.hit[i];
+        h = a.R.hit[i];
         parked = a.suspend_lanes != 0u && a.bounce == 1u && h.x == -3.0f;
-        if (!parked)
-            shade_pixel<FAST>(a, i, h, o);
     }
+    // The 128-byte shading records of the wave's (up to) 64 hit triangles are gathered COOPERATIVELY: eight lanes fetch
+    // the eight 16-byte pieces of one record -- one cache line per eight lanes instead of one per lane and load -- straight
+    // into LDS (LDS-DMA), eight records per instruction.  The texture-address units, which the scattered per-lane gathers
+    // kept 80 % busy, see an eighth of the line lookups; each lane then reads its own record from LDS.  Piece j of the
+    // record of lane s lands at [s * 8 + j] and holds global piece j ^ (s & 7): an XOR swizzle that spreads the banks.
+    __shared__ float4 smem[64 * 8];
+    const uint32_t lane = threadIdx.x;
+    const bool has_hit = active && !parked && h.x >= 0.0f;
+    const uint32_t my_tri = has_hit ? __float_as_uint(h.w) : ~0u; // ~0: nothing to fetch for this lane (there may be no record array at all)
+#pragma unroll
+    for (uint32_t it = 0; it < 8; ++it) {
+        const uint32_t src = it * 8u + (lane >> 3);
+        const uint32_t t = (uint32_t)__shfl((int)my_tri, (int)src);
+        if (t != ~0u) { // (lanes masked off leave their LDS slot as it is: nobody reads it)
+            const float4* g = a.S.shade + 8 * (size_t)t + ((lane & 7u) ^ (src & 7u));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(smem + it * 64u), 16, 0, 0);
+        }
+    }
+    __syncthreads(); // (waits for the DMA: an LDS-DMA is a pending LDS write on the VM counter)
+    if (active && !parked)
+        shade_pixel<FAST, true>(a, i, h, o, smem + lane * 8u, lane & 7u);
     const unsigned long long parked_mask = __ballot(parked); // lane l <-> pixel (l & 7, l >> 3) of the tile
     // Store the 64-byte records of the wave's 8x8 tile.  Lane-per-pixel stores would write 16 bytes at a 64-byte stride
     // four times over; transposed through LDS, every store instruction writes two 512-byte runs (one tile row each).
-    __shared__ float4 xpose[64 * 4];
-    const uint32_t lane = threadIdx.x;
+    __syncthreads(); // every lane is done with its staged record: the buffer is reused
+    float4* xpose = smem;
     xpose[lane * 4 + kSrO] = o.rec_o;
     xpose[lane * 4 + kSrD] = o.shadow_d;
     xpose[lane * 4 + kSrContrib] = o.rec_c;
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_resume_shade_kernel(Gi
             atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
             a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2));
         }
-        shade_pixel<FAST>(a, i, h, o);
+        shade_pixel<FAST, false>(a, i, h, o, nullptr, 0u);
         float4* rec_out = a.R.srec + 4 * i;
         rec_out[kSrO] = o.rec_o;
         rec_out[kSrD] = o.shadow_d;

@@ -572,10 +572,11 @@ struct TriShade {
     float4 t0, t1, t2;
     uint32_t geom; // GeometryIndex() of the triangle (r6.w); PrimitiveIndex() is r7.x (debug records only)
 };
-__device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t tri)
+// `r` = the triangle's 8 x float4 record; piece k sits at r[k ^ swz] (swz = 0 in global memory; the copy the shade pass
+// stages in LDS is XOR-swizzled per lane to spread the banks)
+template <typename Ptr> __device__ __forceinline__ TriShade load_tri_shade_at(Ptr r, uint32_t swz)
 {
-    const float4* r = S.shade + 8 * (size_t)tri;
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r6 = r[6];
+    const float4 r0 = r[0 ^ swz], r1 = r[1 ^ swz], r2 = r[2 ^ swz], r6 = r[6 ^ swz];
     TriShade t;
     t.n0 = f3(r0.x, r0.y, r0.z);
     t.n1 = f3(r1.x, r1.y, r1.z);
@@ -584,18 +585,18 @@ __device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t 
     t.uv1 = make_float2(r2.w, r6.x);
     t.uv2 = make_float2(r6.y, r6.z);
     t.geom = __float_as_uint(r6.w);
-    t.t0 = r[3];
-    t.t1 = r[4];
-    t.t2 = r[5];
+    t.t0 = r[3 ^ swz];
+    t.t1 = r[4 ^ swz];
+    t.t2 = r[5 ^ swz];
     return t;
 }
+__device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t tri) { return load_tri_shade_at(S.shade + 8 * (size_t)tri, 0u); }
 
 // ReconstructSurfaceData (pathtracer.hlsl:299-395); `tri` is the sorted triangle index of the hit.
-template <bool FAST = false> __device__ bool reconstruct_surface(const SceneView& S, uint32_t tri, float bu, float bv, Surface& out, uint32_t& geom)
+template <bool FAST = false> __device__ __forceinline__ bool reconstruct_surface(const SceneView& S, const TriShade& ts, float bu, float bv, Surface& out, uint32_t& geom)
 {
-    // the record is fetched first and names its geometry itself: one gathered line per hit, and the geometry / material
-    // table reads hang off it instead of off a second gather into the triangle array
-    const TriShade ts = load_tri_shade(S, tri);
+    // the record names its geometry itself: one gathered line per hit, and the geometry / material table reads hang off it
+    // instead of off a second gather into the triangle array
     geom = ts.geom;
     const DevGeom g = S.geoms[geom];
     const float b0 = 1.0f - (bu + bv), b1 = bu, b2 = bv;
