@@ -485,21 +485,42 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_resume_shade_kernel(Gi
 __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
+    static_assert(kLdsStack * 64 * sizeof(int) >= 64 * 4 * sizeof(float4), "the shadow records are staged in the stack's LDS");
     uint32_t x, y;
-    size_t i;
+    size_t i = 0;
+    bool valid;
     if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
         const uint32_t j = blockIdx.x * 64u + threadIdx.x;
-        if (j >= a.n_px)
-            return;
-        i = a.sort_order[j];
-    } else if (!gi_pixel(a, x, y, i)) {
-        return;
+        valid = j < a.n_px;
+        if (valid)
+            i = a.sort_order[j];
+    } else {
+        valid = gi_pixel(a, x, y, i);
     }
-    const float4* rec = a.R.srec + 4 * i;
-    const float4 rd = rec[kSrD];
-    float4 sum = rec[kSrSum];
+    // The wave's 64 shadow records (64 bytes each, scattered: the pixels come in sorted order) are gathered cooperatively --
+    // four lanes fetch the four 16-byte pieces of one record, sixteen records per instruction, by LDS-DMA into the memory
+    // that serves as the traversal stack afterwards -- so the texture-address units see a quarter of the line lookups
+    // (see gi_shade_kernel).  Piece j of the record of lane s lands at [s * 4 + j] and holds piece j ^ (s & 3).
+    float4* stage = reinterpret_cast<float4*>(stack_mem);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t my_px = valid ? (uint32_t)i : ~0u;
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+        const uint32_t src = it * 16u + (lane >> 2);
+        const uint32_t p = (uint32_t)__shfl((int)my_px, (int)src);
+        if (p != ~0u) {
+            const float4* g = a.R.srec + 4 * (size_t)p + ((lane & 3u) ^ (src & 3u));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(stage + it * 64u), 16, 0, 0);
+        }
+    }
+    __syncthreads(); // (waits for the DMA)
+    const uint32_t swz = lane & 3u;
+    const float4 rd = stage[lane * 4u + (kSrD ^ swz)], ro = stage[lane * 4u + (kSrO ^ swz)], contrib = stage[lane * 4u + (kSrContrib ^ swz)];
+    float4 sum = stage[lane * 4u + (kSrSum ^ swz)];
+    __syncthreads(); // every lane holds its record: the memory becomes the stack
+    if (!valid)
+        return;
     if (rd.w != 0.0f) {
-        const float4 ro = rec[kSrO];
         Hit sh;
         const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh, a.stats != 0);
         if (a.stats) { // diagnostics only
@@ -507,10 +528,9 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
             atomicAdd(a.ray_counter + 4, (unsigned long long)sh.tri_tests);
         }
         if (!occluded) { // radiance += BRDF * sunRadiance * throughput (:571-575)
-            const float4 c = rec[kSrContrib];
-            sum.x += c.x;
-            sum.y += c.y;
-            sum.z += c.z;
+            sum.x += contrib.x;
+            sum.y += contrib.y;
+            sum.z += contrib.z;
             if (a.hits && a.bounce == 1)
                 a.hits[i].flags |= 1u;
         }
