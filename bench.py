@@ -381,21 +381,29 @@ def main():
         dtg, _ = w.timed(args.steps, 0, lambda k: (w.step(), r.gather_frame(dst=0)))
         fps_with_gather = args.steps / dtg * world
 
-    # ---- per-kernel durations: HIP events on the launch stream, 8 extra frames ----
-    ev = []
+    # ---- per-kernel durations: HIP events on the launch stream, 8 extra frames with an event pair per pass, and 8 more in
+    # which the L a-trous launches are bracketed by ONE pair (every event is a packet of its own between two launches: the
+    # roofline's mean level duration is taken where there are fewest of them) ----
+    ev, ev2 = [], []
     for _ in range(8):
         e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1")}
         e["levels"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
         w.step(e)
         ev.append(e)
+    for _ in range(8):
+        e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1", "a1")}
+        w.step(e)
+        ev2.append(e)
     torch.cuda.synchronize()
-    rays_ev = r.ray_count(reset=True) if do_gi else 0
+    rays_ev = (r.ray_count(reset=True) if do_gi else 0) // 2  # (two batches of 8 frames)
     t_gi = float(np.mean([e["gi0"].elapsed_time(e["gi1"]) for e in ev])) * 1e-3
     t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev])) * 1e-3
     per_level = [float(np.mean([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev])) * 1e-3 for i in range(L)]
     # (with N > 1 the first level's interval also holds the halo exchange it overlaps with, and every level but the last
     # filters a few extra rows: the roofline line is then taken over the levels after the first)
     t_atrous = float(np.mean(per_level if (world == 1 or L == 1) else per_level[1:]))
+    if world == 1 and L > 0:
+        t_atrous = float(np.mean([e["t1"].elapsed_time(e["a1"]) for e in ev2])) * 1e-3 / L
     own_px = (w.own[1] - w.own[0]) * GW                      # pixels a rank owns (= one 1080p frame)
     gb = noisy = consts = None
     if rank == 0 and args.cpu_frames > 0 and world == 1:
@@ -452,7 +460,7 @@ def main():
             "strong_1080p": strong,
             "config5": config5,
             "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": t_temporal * 1e6, "atrous_levels": [t * 1e6 for t in per_level]},
-            "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame)",
+            "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame: HIP events around the L launches / L)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,

@@ -311,14 +311,15 @@ class StripRenderer(DeferredRenderer):
         self.svgf.submit_temporal_accumulation(st, rows=own)
         if events is not None:
             events["t1"].record()
+        per_level = events.get("levels") if events is not None else None
         L = self.part.L
         once = self.part.N > 1 and self.part.scheme == "once"
         for level in range(L):
             rows = self.part.atrous_rows(self.rank, level)
             if self.part.N > 1 and self.part.scheme == "per_level":
                 self.exchange_halo(level)
-            if events is not None:
-                events["levels"][level][0].record()
+            if per_level is not None:
+                per_level[level][0].record()
             if once and level == 0:
                 # the exchange runs beside level 0 on the rows that need none of the incoming halo (taps reach 2 rows)
                 finish = self.exchange_frame_halo_begin()
@@ -333,8 +334,10 @@ class StripRenderer(DeferredRenderer):
                     self.svgf.submit_atrous_level(0, (bot, rows[1]), st)
             else:
                 self.svgf.submit_atrous_level(level, rows, st)
-            if events is not None:
-                events["levels"][level][1].record()
+            if per_level is not None:
+                per_level[level][1].record()
+        if events is not None and "a1" in events:
+            events["a1"].record()  # (with "t1": brackets all levels with two events only)
         if L == 1:  # single level filters into the scratch plane: copy the owned rows back (api.hip: neb_svgf_atrous)
             cur = self.svgf.get_current_resource_index()
             with self._exchange_stream():
