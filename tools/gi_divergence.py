@@ -77,3 +77,41 @@ for T in (2, 4, 8, 12, 16):
         second = q.max(axis=1).sum()
         print("suspend at <= %2d lanes (min %2d iterations): first pass x%.3f + follow-up x%.3f = x%.3f of baseline; %.1f %% of the rays are queued"
               % (T, M, first / base, second / base, (first + second) / base, 100.0 * (rem > 0).mean()))
+
+# (f) dynamic refill: a wave owns K consecutive tiles; whenever at least T of its lanes are idle (and rays are left in its
+# pool) the idle lanes start the next rays of the pool in place (no state moves).  Cost = loop iterations with a live
+# lane + `setup` iterations per refill event (ray generation / result write-out run by the refilling lanes only).
+def refill_cost(K, T, setup):
+    nw = tiles.shape[0] // K
+    pool = tiles[: nw * K].reshape(nw, K * 64)
+    rem = pool[:, :64].copy()
+    pos = np.full(nw, 64, np.int64)
+    end = K * 64
+    total = 0.0
+    while True:
+        live = rem > 0
+        any_live = live.any(axis=1)
+        idle = ~live
+        n_idle = idle.sum(axis=1)
+        want = (n_idle >= T) & (pos < end) | (~any_live & (pos < end))
+        if want.any():
+            w = np.nonzero(want)[0]
+            rank = np.cumsum(idle[w], axis=1) - 1
+            src = pos[w, None] + rank
+            ok = idle[w] & (src < end)
+            vals = np.take_along_axis(pool[w], np.minimum(src, end - 1), axis=1)
+            r = rem[w]
+            r[ok] = vals[ok]
+            rem[w] = r
+            pos[w] = np.minimum(pos[w] + n_idle[w], end)
+            total += setup * w.size
+            live = rem > 0
+            any_live = live.any(axis=1)
+        if not any_live.any():
+            break
+        total += any_live.sum()
+        rem = np.maximum(rem - 1, 0)
+    return total * (tiles.shape[0] / (nw * K))
+for K in (2, 4, 8, 16):
+    for T in (8, 16, 32, 48):
+        print("refill: %2d tiles per wave, refill at >= %2d idle lanes (+3 per refill): cost x%.3f of baseline" % (K, T, refill_cost(K, T, 3.0) / base))
