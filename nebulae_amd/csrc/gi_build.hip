@@ -606,6 +606,58 @@ __global__ void collapse_emit_kernel(CollapseArgs a)
         a.level_state[0] = a.inner_scan[k] + a.inner_count[k];
 }
 
+// The 64-byte copy of the wide nodes that any-hit rays walk (Bvh4NodeQ, gi_internal.h): per node and axis, origin =
+// the lower corner of the used children, scale = extent / 255 nudged up until 255 steps reach the upper corner; every
+// child plane is rounded away from the child (floor for lower planes, ceil for upper ones) and then checked in the
+// decoder's own arithmetic, fmaf(q, scale, origin), so the decoded box is never inside the exact one.
+__global__ void quantise_nodes_kernel(const Bvh4Node* __restrict__ nodes, uint32_t n, Bvh4NodeQ* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const Bvh4Node nd = nodes[i];
+    const float lo[3][4] = {{nd.lox.x, nd.lox.y, nd.lox.z, nd.lox.w}, {nd.loy.x, nd.loy.y, nd.loy.z, nd.loy.w}, {nd.loz.x, nd.loz.y, nd.loz.z, nd.loz.w}};
+    const float hi[3][4] = {{nd.hix.x, nd.hix.y, nd.hix.z, nd.hix.w}, {nd.hiy.x, nd.hiy.y, nd.hiy.z, nd.hiy.w}, {nd.hiz.x, nd.hiz.y, nd.hiz.z, nd.hiz.w}};
+    float org[3], scl[3];
+    uint32_t qlo[3], qhi[3];
+    for (int ax = 0; ax < 3; ++ax) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int q = 0; q < 4; ++q)
+            if (lo[ax][q] <= hi[ax][q]) { // (unused slots are inverted boxes)
+                mn = fminf(mn, lo[ax][q]);
+                mx = fmaxf(mx, hi[ax][q]);
+            }
+        if (!(mn <= mx))
+            mn = mx = 0.0f; // (a node without children does not occur; keep the record finite)
+        float sc = fmaxf((mx - mn) * (1.0f / 255.0f), 1e-30f);
+        while (fmaf(255.0f, sc, mn) < mx)
+            sc = nextafterf(sc, INFINITY);
+        org[ax] = mn;
+        scl[ax] = sc;
+        qlo[ax] = qhi[ax] = 0u;
+        for (int q = 0; q < 4; ++q) {
+            uint32_t l = 255u, h = 0u; // unused: inverted
+            if (lo[ax][q] <= hi[ax][q]) {
+                l = (uint32_t)fminf(floorf((lo[ax][q] - mn) / sc), 255.0f);
+                while (l > 0u && fmaf((float)l, sc, mn) > lo[ax][q])
+                    --l;
+                h = (uint32_t)fminf(ceilf((hi[ax][q] - mn) / sc), 255.0f);
+                while (h < 255u && fmaf((float)h, sc, mn) < hi[ax][q])
+                    ++h;
+            }
+            qlo[ax] |= l << (8 * q);
+            qhi[ax] |= h << (8 * q);
+        }
+    }
+    Bvh4NodeQ o;
+    o.ox = org[0], o.oy = org[1], o.oz = org[2];
+    o.sx = scl[0], o.sy = scl[1], o.sz = scl[2];
+    o.qlox = qlo[0], o.qloy = qlo[1], o.qloz = qlo[2];
+    o.qhix = qhi[0], o.qhiy = qhi[1], o.qhiz = qhi[2];
+    o.child = nd.child;
+    out[i] = o;
+}
+
 } // namespace neb
 
 using namespace neb;
@@ -1034,11 +1086,17 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
         n_wide = level_start;
     }
     Bvh4Node* d_wide = nullptr;
+    Bvh4NodeQ* d_wide_q = nullptr;
     if (n_wide) {
         d_wide = (Bvh4Node*)dalloc((size_t)n_wide * sizeof(Bvh4Node), true);
         if (!d_wide)
             return bail(NEB_ERR_HIP, "neb_gi_build_bvh: out of device memory");
         BUILD_HIP(hipMemcpyAsync(d_wide, d_wide_tmp, (size_t)n_wide * sizeof(Bvh4Node), hipMemcpyDeviceToDevice, stream));
+        d_wide_q = (Bvh4NodeQ*)dalloc((size_t)n_wide * sizeof(Bvh4NodeQ), true);
+        if (!d_wide_q)
+            return bail(NEB_ERR_HIP, "neb_gi_build_bvh: out of device memory");
+        hipLaunchKernelGGL(quantise_nodes_kernel, dim3((n_wide + 127) / 128), dim3(128), 0, stream, d_wide, n_wide, d_wide_q);
+        BUILD_HIP(hipGetLastError());
     }
     {
         SceneView sv = g->view;
@@ -1059,7 +1117,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
         return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, msg);
     }
     // ---- commit: release the previous build's arrays (a rebuild), adopt the new ones ----
-    const void* old[] = {g->view.tris, g->view.shade, g->view.nodes};
+    const void* old[] = {g->view.tris, g->view.shade, g->view.nodes, g->view.qnodes};
     if (g->built)
         (void)hipDeviceSynchronize(); // no launch may still be walking the tree that is about to be freed
     for (const void* o : old) {
@@ -1076,6 +1134,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     g->view.tris = d_final;
     g->view.shade = d_shade;
     g->view.nodes = d_wide;
+    g->view.qnodes = d_wide_q;
     g->view.root = root_code;
     g->n_nodes = n_wide;
     g->bvh_depth = (uint32_t)max_depth;
@@ -1090,7 +1149,7 @@ int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3])
     const neb::GiState* g = ctx->gi;
     out[0] = g->texture_table_bytes;
     out[1] = g->built ? (uint64_t)g->n_tris * (48 + 128) : 0;
-    out[2] = (uint64_t)g->n_nodes * sizeof(neb::Bvh4Node);
+    out[2] = (uint64_t)g->n_nodes * (sizeof(neb::Bvh4Node) + sizeof(neb::Bvh4NodeQ));
     return NEB_OK;
 }
 

@@ -276,6 +276,14 @@ __device__ __forceinline__ uint32_t slab_key(float nx, float ny, float nz, float
     return (t0 <= t1) ? ((__float_as_uint(t0) & ~3u) | slot) : 0xffffffffu;
 }
 
+// the same from entry / exit distances already computed (quantised nodes)
+__device__ __forceinline__ uint32_t slab_key_t(float ax, float ay, float az, float bx, float by, float bz, float tmin, float tmax, uint32_t slot)
+{
+    const float t0 = fmaxf(fmaxf(ax, ay), fmaxf(az, tmin));
+    const float t1 = fminf(fminf(bx, by), fminf(bz, tmax));
+    return (t0 <= t1) ? ((__float_as_uint(t0) & ~3u) | slot) : 0xffffffffu;
+}
+
 __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b)
 {
     const uint32_t lo = min(a, b), hi = max(a, b);
@@ -336,21 +344,47 @@ __device__ __forceinline__ bool traverse_core(const SceneView& S, float3 o, floa
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     // byte offset of the plane the ray enters through, per axis, inside a Bvh4Node (the exit plane is offset ^ 64)
     const uint32_t onx = d.x < 0.0f ? 64u : 0u, ony = d.y < 0.0f ? 80u : 16u, onz = d.z < 0.0f ? 96u : 32u;
+    constexpr bool QUANT = ANY_HIT ? (NEB_QUANT_ANYHIT != 0) : (NEB_QUANT_CLOSEST != 0);
+    const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
     constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
         if (node >= 0) {
             if (STATS)
                 hit.node_visits++;
-            const char* nodes = reinterpret_cast<const char*>(S.nodes);
-            const uint32_t nb = (uint32_t)node << 7; // 32-bit byte offset (scalar base + vector offset addressing)
-            const float4 nx = *reinterpret_cast<const float4*>(nodes + (nb + onx)), fx = *reinterpret_cast<const float4*>(nodes + (nb + (onx ^ 64u)));
-            const float4 ny = *reinterpret_cast<const float4*>(nodes + (nb + ony)), fy = *reinterpret_cast<const float4*>(nodes + (nb + (ony ^ 64u)));
-            const float4 nz = *reinterpret_cast<const float4*>(nodes + (nb + onz)), fz = *reinterpret_cast<const float4*>(nodes + (nb + (onz ^ 64u)));
-            const int4 ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
-            uint32_t k0 = slab_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, inv, oinv, tmin, hit.t, 0u);
-            uint32_t k1 = slab_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, inv, oinv, tmin, hit.t, 1u);
-            uint32_t k2 = slab_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, inv, oinv, tmin, hit.t, 2u);
-            uint32_t k3 = slab_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, inv, oinv, tmin, hit.t, 3u);
+            uint32_t k0, k1, k2, k3;
+            int4 ch;
+            if constexpr (QUANT) {
+                const char* nodes = reinterpret_cast<const char*>(S.qnodes);
+                const uint32_t nb = (uint32_t)node << 6;
+                const float4 p0 = *reinterpret_cast<const float4*>(nodes + nb);            // {origin.xyz, scale.x}
+                const float4 p1 = *reinterpret_cast<const float4*>(nodes + (nb + 16u));    // {scale.yz, qlo.x, qlo.y}
+                const uint4 p2 = *reinterpret_cast<const uint4*>(nodes + (nb + 32u));      // {qlo.z, qhi.xyz}
+                ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
+                // plane distance = (origin + q scale - o) / d = q (scale inv) + (origin inv - o inv)
+                const float sx = p0.w * inv.x, sy = p1.x * inv.y, sz = p1.y * inv.z;
+                const float bx = fmaf(p0.x, inv.x, -oinv.x), by = fmaf(p0.y, inv.y, -oinv.y), bz = fmaf(p0.z, inv.z, -oinv.z);
+                const uint32_t lox = __float_as_uint(p1.z), loy = __float_as_uint(p1.w);
+                const uint32_t qnx = negx ? p2.y : lox, qfx = negx ? lox : p2.y; // entry plane by the sign of the direction
+                const uint32_t qny = negy ? p2.z : loy, qfy = negy ? loy : p2.z;
+                const uint32_t qnz = negz ? p2.w : p2.x, qfz = negz ? p2.x : p2.w;
+                auto key = [&](uint32_t c) { // (v_cvt_f32_ubyte<c>: one instruction per plane)
+                    auto un = [&](uint32_t q) { return (float)((q >> (8u * c)) & 0xffu); };
+                    return slab_key_t(fmaf(un(qnx), sx, bx), fmaf(un(qny), sy, by), fmaf(un(qnz), sz, bz), fmaf(un(qfx), sx, bx),
+                                      fmaf(un(qfy), sy, by), fmaf(un(qfz), sz, bz), tmin, hit.t, c);
+                };
+                k0 = key(0u), k1 = key(1u), k2 = key(2u), k3 = key(3u);
+            } else {
+                const char* nodes = reinterpret_cast<const char*>(S.nodes);
+                const uint32_t nb = (uint32_t)node << 7; // 32-bit byte offset (scalar base + vector offset addressing)
+                const float4 nx = *reinterpret_cast<const float4*>(nodes + (nb + onx)), fx = *reinterpret_cast<const float4*>(nodes + (nb + (onx ^ 64u)));
+                const float4 ny = *reinterpret_cast<const float4*>(nodes + (nb + ony)), fy = *reinterpret_cast<const float4*>(nodes + (nb + (ony ^ 64u)));
+                const float4 nz = *reinterpret_cast<const float4*>(nodes + (nb + onz)), fz = *reinterpret_cast<const float4*>(nodes + (nb + (onz ^ 64u)));
+                ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
+                k0 = slab_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, inv, oinv, tmin, hit.t, 0u);
+                k1 = slab_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, inv, oinv, tmin, hit.t, 1u);
+                k2 = slab_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, inv, oinv, tmin, hit.t, 2u);
+                k3 = slab_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, inv, oinv, tmin, hit.t, 3u);
+            }
             // select by the slot bits without branches (two levels of v_cndmask)
             auto child_of = [&](uint32_t key) -> int {
                 const bool b0 = (key & 1u) != 0u, b1 = (key & 2u) != 0u;
