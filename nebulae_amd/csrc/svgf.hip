@@ -267,67 +267,93 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
     const uint32_t xcd = blockIdx.x & 7u, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const uint32_t t_end = min((xcd + 1u) * per_xcd, a.nblocks);
 
-    // staged-texel coordinates of this lane inside a tile: the same for every tile
-    int lrow[NLOAD], lcol[NLOAD];
-#pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {
-        const int i = threadIdx.x + 256 * k;
-        lrow[k] = i / COLS;
-        lcol[k] = i - lrow[k] * COLS;
-    }
+    // Byte offsets of this lane's staged texels from the element Tile::first.  A tile whose staged rectangle lies inside
+    // the image (and the resident rows) -- nine in ten -- needs no clamping: the offsets are the same for every such tile
+    // and its loads are "uniform tile base + offset" (scalar base, 32-bit vector offset: no address arithmetic on the VALU
+    // at all).  An edge tile overwrites them with its clamped positions (the reference's edge rule), counted from the
+    // plane's first element; the next interior tile puts the regular ones back.
+    uint32_t toff[NLOAD];
+    bool toff_regular = false;
     float4 pc[NLOAD];
 
-    auto tile_origin = [&](uint32_t t, int& r, int& jbase, int& x0) -> bool {
+    struct Tile {
+        int r, jbase, x0;
+        size_t first; // element index the offsets in toff[] count from
+    };
+    auto tile_origin = [&](uint32_t t, Tile& o) -> bool {
         const int tx_tile = (int)(t % (uint32_t)a.tiles_x);
         const int rest = (int)(t / (uint32_t)a.tiles_x);
-        r = rest % S;               // residue class of the lattice rows
+        o.r = rest % S;             // residue class of the lattice rows
         const int jt = rest / S;    // tile index along the lattice
-        const int jmin = (a.row0 - r + S - 1) / S > 0 ? (a.row0 - r + S - 1) / S : 0; // first lattice index inside [row0,row1)
-        jbase = jmin + jt * BH;
-        x0 = tx_tile * BW;
-        return r + S * jbase < a.row1; // false: whole tile below the row range
+        const int jmin = (a.row0 - o.r + S - 1) / S > 0 ? (a.row0 - o.r + S - 1) / S : 0; // first lattice index inside [row0,row1)
+        o.jbase = jmin + jt * BH;
+        o.x0 = tx_tile * BW;
+        return o.r + S * o.jbase < a.row1; // false: whole tile below the row range
     };
-    auto issue_load = [&](int k, int r, int jbase, int x0) {
-        if (threadIdx.x + 256 * k < TOTAL) {
-            // clamp to the image (the reference's edge rule, svgf_atrous.hlsl:65), then to the resident rows:
-            // a partial tile also stages rows that no valid output taps; on a row strip those may lie
-            // outside the allocation, so they are redirected to a resident row (their values are never used)
-            int y = min(max(r + S * (jbase + lrow[k] - 2), 0), a.H - 1);
-            y = min(max(y, a.row_begin), a.row_end - 1);
-            const int x = min(max(x0 - 2 * S + lcol[k], 0), a.W - 1);
-            const size_t q = (size_t)(y - a.row_begin) * a.W + x;
-            pc[k] = src[q];
+    // fills toff[] / o.first for a tile about to be loaded
+    auto tile_offsets = [&](Tile& o) {
+        const int y_first = o.r + S * (o.jbase - 2), y_last = o.r + S * (o.jbase + ROWS - 3), x_first = o.x0 - 2 * S;
+        const bool interior = y_first >= max(0, a.row_begin) && y_last < min(a.H, a.row_end) && x_first >= 0 && x_first + COLS <= a.W;
+        if (interior) {
+            o.first = (size_t)(y_first - a.row_begin) * a.W + x_first;
+            if (!toff_regular) {
+#pragma unroll
+                for (int k = 0; k < NLOAD; ++k) {
+                    const int i = threadIdx.x + 256 * k;
+                    const int lr = i / COLS;
+                    toff[k] = (uint32_t)(lr * S * a.W + (i - lr * COLS)) * 16u;
+                }
+                toff_regular = true;
+            }
+        } else {
+            o.first = 0;
+            toff_regular = false;
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                const int i = threadIdx.x + 256 * k;
+                const int lr = i / COLS, lc = i - lr * COLS;
+                // clamp to the image (svgf_atrous.hlsl:65), then to the resident rows: a partial tile also stages rows
+                // that no valid output taps; on a row strip those may lie outside the allocation, so they are
+                // redirected to a resident row (their values are never used)
+                int y = min(max(o.r + S * (o.jbase + lr - 2), 0), a.H - 1);
+                y = min(max(y, a.row_begin), a.row_end - 1);
+                const int x = min(max(o.x0 - 2 * S + lc, 0), a.W - 1);
+                toff[k] = (uint32_t)((y - a.row_begin) * a.W + x) * 16u; // (a plane is < 4 GB: checked at launch)
+            }
         }
+    };
+    auto issue_load = [&](int k, const Tile& o) {
+        if (threadIdx.x + 256 * k < TOTAL)
+            pc[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + o.first) + toff[k]);
     };
     // The geometry texels go global -> LDS directly (global_load_lds_dwordx4: per-lane source address, destination =
     // wave-uniform base + lane * 16 B, which is exactly this staging order), no registers and no VALU.  Issued once the
     // whole workgroup has finished reading the previous tile, and complete before the barrier that precedes the filter.
-    auto issue_geometry_dma = [&](int r, int jbase, int x0) {
+    auto issue_geometry_dma = [&](const Tile& o) {
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             if (threadIdx.x + 256 * k < TOTAL) {
-                int y = min(max(r + S * (jbase + lrow[k] - 2), 0), a.H - 1);
-                y = min(max(y, a.row_begin), a.row_end - 1);
-                const int x = min(max(x0 - 2 * S + lcol[k], 0), a.W - 1);
-                const size_t q = (size_t)(y - a.row_begin) * a.W + x;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(geometry + q),
+                const char* g = reinterpret_cast<const char*>(geometry + o.first) + toff[k];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(B + 256 * k + 64 * wv), 16, 0, 0);
             }
         }
     };
-    auto issue_loads = [&](int r, int jbase, int x0) {
+    auto issue_loads = [&](const Tile& o) {
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k)
-            issue_load(k, r, jbase, x0);
+            issue_load(k, o);
     };
 
     uint32_t t = xcd * per_xcd + wg_in_xcd;
-    int r = 0, jbase = 0, x0 = 0;
+    Tile nt{0, 0, 0, 0};
     bool have = false;
-    while (t < t_end && !(have = tile_origin(t, r, jbase, x0)))
+    while (t < t_end && !(have = tile_origin(t, nt)))
         t += wgs_per_xcd;
-    if (have)
-        issue_loads(r, jbase, x0);
+    if (have) {
+        tile_offsets(nt);
+        issue_loads(nt);
+    }
 
     while (have) {
         // ---- stage the tile: radiance (prefetched into registers during the previous tile) + its luminance -> plane A;
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k)
             lum[k] = luminance(pc[k].x, pc[k].y, pc[k].z);
-        issue_geometry_dma(r, jbase, x0);
+        issue_geometry_dma(nt);
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             const int i = threadIdx.x + 256 * k;
@@ -346,18 +372,20 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
         __syncthreads(); // (also waits for this wave's DMA: an LDS-DMA is a pending LDS write on the VM counter)
 
         // ---- next tile: issue its loads now, consume them after this tile is filtered ----
-        const int cr = r, cjbase = jbase, cx0 = x0;
+        const int cr = nt.r, cjbase = nt.jbase, cx0 = nt.x0;
         bool have_next = false;
         t += wgs_per_xcd;
-        while (t < t_end && !(have_next = tile_origin(t, r, jbase, x0)))
+        while (t < t_end && !(have_next = tile_origin(t, nt)))
             t += wgs_per_xcd;
+        if (have_next)
+            tile_offsets(nt); // (the current tile's DMA has been issued: toff[] is free)
         // The next tile's loads are spread over the row iterations of the filter below (one batch per row) so
         // that, chip-wide, memory traffic and arithmetic overlap instead of alternating in bursts; batches
         // beyond the R+4 row iterations go out first.
         if (have_next) {
 #pragma unroll
             for (int k = R + 4; k < NLOAD; ++k)
-                issue_load(k, r, jbase, x0);
+                issue_load(k, nt);
         }
 
         // ---- filter the current tile ----
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
 #pragma unroll
         for (int ir = 0; ir < R + 4; ++ir) {
             if (ir < NLOAD && have_next)
-                issue_load(ir, r, jbase, x0);
+                issue_load(ir, nt);
             const int lrow_base = (wv * R + ir) * COLS + lane + 2 * S;
 #pragma unroll
             for (int dx = -2; dx <= 2; ++dx) {
@@ -499,7 +527,8 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
     a.phiNormal = L.p.phiNormal;
     // variant 1 (default): R = 4 rows per lane for steps <= 4, R = 2 (smaller LDS tile, 5 waves/SIMD) for steps >= 8,
     // as measured; 2 / 3 force R = 2 / R = 4 everywhere (A/B arms)
-    if (variant >= 1) {
+    // (the LDS kernel addresses a plane with 32-bit byte offsets: a resident plane of 4 GB or more -- 16 k x 16 k -- takes the direct kernel)
+    if (variant >= 1 && (uint64_t)(L.row_end - L.row_begin) * L.W < (1ull << 28)) {
         switch (step) {
         case 1: return (variant == 2) ? launch_lds<1, 2>(a, L.device, num_cus, s) : launch_lds<1, 4>(a, L.device, num_cus, s);
         case 2: return (variant == 2) ? launch_lds<2, 2>(a, L.device, num_cus, s) : launch_lds<2, 4>(a, L.device, num_cus, s);
