@@ -629,9 +629,12 @@ __global__ void quantise_nodes_kernel(const Bvh4Node* __restrict__ nodes, uint32
             }
         if (!(mn <= mx))
             mn = mx = 0.0f; // (a node without children does not occur; keep the record finite)
-        float sc = fmaxf((mx - mn) * (1.0f / 255.0f), 1e-30f);
-        while (fmaf(255.0f, sc, mn) < mx)
-            sc = nextafterf(sc, INFINITY);
+        // scale: 255 steps must reach the upper corner in the decoder's arithmetic.  (mx - mn) and the division round by
+        // 2^-24 each, so a 2^-21 margin makes 255 * sc >= mx - mn exactly, and fmaf rounds monotonically: no search
+        // (the loop is a bounded safeguard -- a node at 1e4 with an extent of 1e-4 must not spin here)
+        float sc = fmaxf((mx - mn) / 255.0f * (1.0f + 0x1p-21f), 1e-30f);
+        for (int guard = 0; guard < 8 && fmaf(255.0f, sc, mn) < mx; ++guard)
+            sc *= 1.0f + 0x1p-20f;
         org[ax] = mn;
         scl[ax] = sc;
         qlo[ax] = qhi[ax] = 0u;

@@ -451,3 +451,50 @@ def test_device_build_handles_degenerate_inputs():
         assert np.abs(hits["t"][hit] - ohits["t"][hit]).max() <= 1e-4 * np.abs(ohits["t"][hit]).max()
         assert rel_l2(got[..., :3], want[..., :3]) <= 2e-5
         r.destroy()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["far", "tiny_far"])
+def test_quantised_nodes_stay_conservative_far_from_the_origin(kind):
+    """The traversal walks a 64-byte copy of the tree whose child boxes are 8-bit offsets from the node's corner
+    (Bvh4NodeQ, gi_internal.h), rounded outwards in the decoder's own arithmetic.  Where that rounding is hardest: a scene
+    away from the origin (64 units: as far as the reference's fp16 world-position plane still resolves a 2-unit box; an
+    ulp there is 8e-6) with a patch of 1e-3-sized quads, whose nodes have quantisation steps of 4e-6 -- below the ulp.
+    The build must terminate and no hit may be lost: hit ids, visibility and distances equal the oracle's, which walks
+    its own full-precision tree."""
+    W, H = 128, 96
+    off = np.array([64.0, 16.0, -32.0], np.float32)
+    sc = S.cornell_standin(textured=True)
+    for g in sc.geometries:  # (row-vector convention: world = p @ M[:3,:3] + M[3,:3])
+        g["M"] = g["M"].copy()
+        g["M"][3, :3] += off
+    if kind == "tiny_far":  # 32 x 32 quads of edge 1e-3 hovering in the box
+        n = 32
+        ij = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2).astype(np.float32)
+        q = np.array([[0, 0, 0], [1, 0, 0], [1, 0, 1], [0, 0, 1]], np.float32) * 1e-3
+        base = np.concatenate([ij[:, :1] * 1.5e-3, np.zeros((n * n, 1), np.float32), ij[:, 1:] * 1.5e-3], 1)
+        P = (q[None] + base[:, None, :]).reshape(-1, 3) + off[None, :] + np.array([[0.0, 0.4, 0.0]], np.float32)
+        I = (np.arange(n * n)[:, None] * 4 + np.array([0, 1, 2, 0, 2, 3])[None]).reshape(-1)
+        sc.add_geometry(P.astype(np.float32), np.tile(np.array([[0, 1, 0]], np.float32), (len(P), 1)), np.zeros((len(P), 2), np.float32), I,
+                        sc.add_material(albedo=(0.7, 0.7, 0.2, 1)))
+    cam = S.orbit_camera(origin=tuple(float(x) for x in off))
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=3))
+    assert r.scene_info()[0] == sc.num_triangles and 3 * r.bvh_depth() <= 64
+    upload_gbuffer(r, gb)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    r.set_debug_hits(True)
+    r.submit_commands_gi_pathtrace()
+    got, hits = r.svgf.download(PLANE_RADIANCE), r.download_hits()
+    want, ohits, _ = o.gi(gb, r.global_constants())
+    assert (ohits["t"] > 0).mean() > 0.1
+    same = (hits["geometry"] == ohits["geometry"]) & (hits["primitive"] == ohits["primitive"]) & ((hits["flags"] & 1) == (ohits["flags"] & 1))
+    assert 1.0 - same.mean() <= 1e-3, f"hit mismatch fraction {1.0 - same.mean():.2e}"
+    # no hit may be LOST (a missed box would turn a hit into a miss or a farther hit): mismatches may only be ties
+    lost = (ohits["t"] > 0) & ((hits["t"] <= 0) | (hits["t"] > ohits["t"] * (1 + 1e-3)))
+    assert not lost.any(), int(lost.sum())
+    assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 2e-4
+    r.destroy()
