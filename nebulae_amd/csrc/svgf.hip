@@ -358,11 +358,11 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
     while (have) {
         // ---- stage the tile: radiance (prefetched into registers during the previous tile) + its luminance -> plane A;
         // geometry -> plane B by DMA (normal and depth arrive decoded: the temporal pass did that once per frame) ----
+        issue_geometry_dma(nt); // first: its flight overlaps the wait for the prefetched radiance and the luminance arithmetic
         float lum[NLOAD];
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k)
             lum[k] = luminance(pc[k].x, pc[k].y, pc[k].z);
-        issue_geometry_dma(nt);
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             const int i = threadIdx.x + 256 * k;
