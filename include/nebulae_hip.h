@@ -251,7 +251,8 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
  * state (unbuilt, or the previous valid tree); calling it again rebuilds. */
 int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream);
 int neb_gi_scene_info(const neb_ctx* ctx, uint32_t* n_triangles, uint32_t* n_nodes);
-/* Device bytes of the scene: {texture footprint tables + material bundles, triangles + shading records, BVH nodes}. */
+/* Device bytes of the scene: {texture footprint tables + material bundles, triangles + shading records, BVH nodes: the
+ * builder's 128-byte nodes + the 64-byte quantised nodes the rays walk}. */
 int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3]);
 /* Inner-node levels of the BVH4 of the last successful build.  neb_gi_build_bvh returns NEB_ERR_OUT_OF_RANGE (and keeps the
  * previous tree, if any) when the depth exceeds what the traversal stack covers: 21, or "gi_max_bvh_depth". */
