@@ -243,10 +243,13 @@ template <int S, int R>
 struct AtrousTile {
     static constexpr int BW = 64, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4, TOTAL = ROWS * COLS;
     static constexpr int NLOAD = (TOTAL + 255) / 256;
+    // workgroups per CU: what the 160 KB of LDS hold, at most 5 (R <= 2) / 3 -- also the register budget the kernel is compiled for
+    static constexpr int LDS_BYTES = TOTAL * 2 * 16;
+    static constexpr int PER_CU = (R <= 2 ? 5 : 3) < (160 * 1024) / LDS_BYTES ? (R <= 2 ? 5 : 3) : (160 * 1024) / LDS_BYTES;
 };
 
 template <int S, int R>
-__global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(AtrousArgs a)
+__global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_lds_kernel(AtrousArgs a)
 {
     using T = AtrousTile<S, R>;
     constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD;
@@ -345,6 +348,26 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
             issue_load(k, o);
     };
 
+    // The centre pixel's variance and alpha (the only per-pixel inputs that are not staged) are fetched one tile ahead as
+    // well: loaded at the start of the filter phase they were a dependent global round trip in front of every tile's
+    // arithmetic (2.5 us per level).
+    uint32_t nvar[R];
+    float nalpha[R];
+    auto issue_centre_loads = [&](const Tile& o) {
+        const int xo = o.x0 + lane;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int yo = o.r + S * (o.jbase + wv * R + k);
+            nvar[k] = 0u;
+            nalpha[k] = 0.f;
+            if (xo < a.Wd && yo < a.row1) {
+                const size_t i = (size_t)(yo - a.row_begin) * a.W + xo;
+                nvar[k] = a.variance[i];
+                nalpha[k] = reinterpret_cast<const float*>(src)[4 * i + 3];
+            }
+        }
+    };
+
     uint32_t t = xcd * per_xcd + wg_in_xcd;
     Tile nt{0, 0, 0, 0};
     bool have = false;
@@ -353,6 +376,7 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
     if (have) {
         tile_offsets(nt);
         issue_loads(nt);
+        issue_centre_loads(nt);
     }
 
     while (have) {
@@ -373,12 +397,19 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
 
         // ---- next tile: issue its loads now, consume them after this tile is filtered ----
         const int cr = nt.r, cjbase = nt.jbase, cx0 = nt.x0;
+        uint32_t cvar[R];
+        float calpha[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            cvar[k] = nvar[k], calpha[k] = nalpha[k];
         bool have_next = false;
         t += wgs_per_xcd;
         while (t < t_end && !(have_next = tile_origin(t, nt)))
             t += wgs_per_xcd;
-        if (have_next)
+        if (have_next) {
             tile_offsets(nt); // (the current tile's DMA has been issued: toff[] is free)
+            issue_centre_loads(nt);
+        }
         // The next tile's loads are spread over the row iterations of the filter below (one batch per row) so
         // that, chip-wide, memory traffic and arithmetic overlap instead of alternating in bursts; batches
         // beyond the R+4 row iterations go out first.
@@ -405,14 +436,8 @@ __global__ __launch_bounds__(256, (R <= 2 ? 5 : 3)) void svgf_atrous_lds_kernel(
             lum0[k] = cA.w;
             const int yo = cr + S * (cjbase + wv * R + k);
             valid[k] = (xo < a.Wd) && (yo < a.row1);
-            float var_f = 0.f;
-            alpha0[k] = 0.f;
-            if (valid[k]) {
-                const size_t i = (size_t)(yo - a.row_begin) * a.W + xo;
-                var_f = half_bits_to_float(a.variance[i]);
-                alpha0[k] = reinterpret_cast<const float*>(src)[4 * i + 3];
-            }
-            cl[k] = lum_scale(var_f, a.phiColor);
+            alpha0[k] = calpha[k];
+            cl[k] = lum_scale(half_bits_to_float((uint16_t)cvar[k]), a.phiColor); // (an invalid pixel holds 0: never stored)
             sr[k] = sg[k] = sb[k] = sw[k] = 0.f;
         }
         const float cz = a.cz, phiN = a.phiNormal;
@@ -490,7 +515,8 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
     a.tiles_j = (max_lattice_rows + T::BH - 1) / T::BH;
     a.nblocks = (uint32_t)a.tiles_x * (uint32_t)S * (uint32_t)a.tiles_j;
     // persistent grid: as many workgroups as fit (LDS-limited, at most 3 per CU by the launch bounds)
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(R <= 2 ? 5 : 3, (160u * 1024u) / lds_bytes);
+    static_assert(T::LDS_BYTES == (int)lds_bytes && T::PER_CU >= 1, "tile too large for the LDS");
+    const uint32_t per_cu = (uint32_t)T::PER_CU;
     uint32_t grid = (uint32_t)num_cus * (per_cu ? per_cu : 1u);
     if (grid > a.nblocks)
         grid = a.nblocks;
