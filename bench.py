@@ -100,10 +100,13 @@ def measured_valu(width, height, levels):
     if len(per) != levels:
         return None
     insts = sum(v["SQ_INSTS_VALU"] for v in per) / len(per)
-    quad = sum(v["SQ_ACTIVE_INST_VALU"] for v in per) / len(per)
+    # priced at the measured issue cost of a wave64 f32 instruction with 3-4 waves per SIMD (tools/ubench_exec.hip,
+    # tools/ubench_valu.hip: 1.0-1.3 ns; v_exp / v_log 3.5 ns) -- NOT at SQ_ACTIVE_INST_VALU, which charges 4 cycles per
+    # instruction where the pipe needs about 2.5
+    transcendental = 2 * 25 * width * height / 64.0
     return {"lane_instructions_per_pixel": insts * 64.0 / (width * height),
-            "issue_us_per_launch": quad / 1024.0 * 4.0 / 2.4e3,  # quad-cycles per SIMD at the 2.4 GHz peak clock
-            "source": name}
+            "issue_us_per_launch": ((insts - transcendental) * 1.2e-3 + transcendental * 3.5e-3) / 1024.0,
+            "ns_per_wave_instruction": 1.2, "source": name}
 
 
 def host_cores():
@@ -464,8 +467,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
-                         # the contract prices this kernel against HBM; what limits it in fact is vector-instruction issue
-                         "limiter": "valu-issue" if (valu and valu["busy_frac"] > 0.6) else None, "valu": valu},
+                         # the contract prices this kernel against HBM; what a level's time is made of in fact (timing-only
+                         # builds): ~15 us tap arithmetic + ~12 us LDS reads / staging / barriers + ~7 us exposed memory
+                         "limiter": "on-chip work (VALU + LDS issue), memory time only partly hidden" if valu else None, "valu": valu},
             "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9 / HBM_PEAK_GBPS},
             # the same byte model over longer intervals: all of SVGF (temporal + L levels, kernel time), and the whole frame

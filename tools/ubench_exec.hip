@@ -5,8 +5,10 @@
 #include <cstdio>
 #pragma clang diagnostic ignored "-Wunused-result"
 
-__global__ __launch_bounds__(256) void k(float* out, int iters, float s, unsigned long long mask)
+__global__ __launch_bounds__(256) void k(float* out, int iters, float s, unsigned long long mask, unsigned long long mask_odd)
 {
+    if ((threadIdx.x >> 6) & 1u) // odd waves of the workgroup run with the second mask
+        mask = mask_odd;
     float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const unsigned lane = threadIdx.x & 63u;
     if ((mask >> lane) & 1ull) { // the loop runs with EXEC = mask
@@ -21,16 +23,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s, unsigne
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
-static void run(const char* name, unsigned long long mask, int blocks_per_cu)
+static void run(const char* name, unsigned long long mask, int blocks_per_cu, unsigned long long mask_odd = 0, bool mixed = false)
 {
+    if (!mixed)
+        mask_odd = mask;
     float* out;
     const int nb = 256 * blocks_per_cu, iters = 20000;
     hipMalloc(&out, nb * 256 * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<<<nb, 256>>>(out, 100, 0.999f, mask);
+    k<<<nb, 256>>>(out, 100, 0.999f, mask, mask_odd);
     hipEventRecord(e0);
-    k<<<nb, 256>>>(out, iters, 0.999f, mask);
+    k<<<nb, 256>>>(out, iters, 0.999f, mask, mask_odd);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -46,10 +50,18 @@ int main()
         run("all 64 lanes", ~0ull, w);
         run("lanes 0-31", 0xffffffffull, w);
         run("lanes 0-15", 0xffffull, w);
+        run("lanes 0-7", 0xffull, w);
+        run("lanes 0-3", 0xfull, w);
+        run("lanes 0-1", 0x3ull, w);
         run("lane 0 only", 1ull, w);
+        run("lane 37 only", 1ull << 37, w);
         run("one lane in each quarter", 0x0001000100010001ull, w);
-        run("one lane in quarters 0 and 2", 0x0000000100000001ull, w);
+        run("two lanes in each quarter", 0x0101010101010101ull, w);
+        run("four lanes in each quarter", 0x1111111111111111ull, w);
         run("even lanes", 0x5555555555555555ull, w);
+        run("all but lane 0", ~1ull, w);
+        run("even waves full, odd waves lane 0", ~0ull, w, 1ull, true);
+        run("even waves full, odd waves idle", ~0ull, w, 0ull, true);
     }
     return 0;
 }
