@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
 
     const float4* __restrict__ src = a.src;
     const float4* __restrict__ geometry = a.geometry;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (wave-uniform: row bases and row addresses become scalar)
 
     // Tile walk, XCD-aware: workgroups b, b+8, ... share an XCD (and its L2); each XCD takes a contiguous
     // run of tiles, and the workgroups of an XCD interleave inside that run.  Speed only.
