@@ -498,3 +498,39 @@ def test_quantised_nodes_stay_conservative_far_from_the_origin(kind):
     assert not lost.any(), int(lost.sum())
     assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 2e-4
     r.destroy()
+
+
+@pytest.mark.parametrize("direction", [(0.0, -1.0, 0.0), (1.0, 0.0, 0.0), (0.0, -1.0, -1.0)])
+def test_axis_parallel_sun_rays(direction):
+    """Shadow rays with exact zeros in their direction (a sun straight overhead or level with an axis, no disk: every ray is
+    the same vector): 1/d is infinite on those axes and a plane distance becomes inf - inf.  The box test must then ignore
+    the axis (v_min3 / v_max3 drop NaNs) -- conservatively, in the quantised decode (q * inf + (origin * inf - o * inf)) as
+    in the float one: visibility and radiance equal the oracle's."""
+    make, cam, W, H = scenes()["cornell"]
+    sc = make()
+    o = OracleTracer(sc)
+    gb = o.gbuffer(W, H, cam)
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.sun.direction = direction
+    r.sun.rough_diameter = 0.0
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=7))
+    upload_gbuffer(r, gb)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    r.set_debug_hits(True)
+    r.submit_commands_gi_pathtrace()
+    got, hits = r.svgf.download(PLANE_RADIANCE), r.download_hits()
+    want, ohits, _ = o.gi(gb, r.global_constants())
+    same = (hits["geometry"] == ohits["geometry"]) & (hits["primitive"] == ohits["primitive"]) & ((hits["flags"] & 1) == (ohits["flags"] & 1))
+    assert 1.0 - same.mean() <= 2e-4, f"hit / visibility mismatch fraction {1.0 - same.mean():.2e}"
+    assert rel_l2(got[same][:, :3], want[same][:, :3]) <= 2e-5
+    # the direct-light pass traces the same kind of ray from the primary surfaces
+    r.submit_commands_pbr_lighting()
+    direct = r.svgf.download(PLANE_RADIANCE)
+    from oracle_lib import oracle_pbr_direct
+    dwant, _ = oracle_pbr_direct(o, gb, r.global_constants())
+    lit_same = (direct[..., 0] > 0) == (dwant[..., 0] > 0)
+    assert lit_same.mean() >= 1.0 - 1e-3, f"direct-light visibility mismatch fraction {1.0 - lit_same.mean():.2e}"
+    if (dwant[..., 0] > 0).any():  # (a level sun leaves the closed box dark)
+        assert rel_l2(direct[lit_same][:, :3], dwant[lit_same][:, :3]) <= 2e-5
+    r.destroy()
