@@ -11,14 +11,14 @@ Workload at N=1: BASELINE.json configs[2] -- 1920x1080, 1 spp, 5 a-trous levels 
 matches Sponza.gltf's statistics: 103 submeshes, 262 k triangles, 25 materials, 69 textures of 1024^2).
 The G-buffer is produced once, outside the timed region, by neb_gbuffer_raycast (static camera).
 
-N > 1 (`value`, weak scaling): the frame grows with N -- rank r owns a 1080p-equivalent row strip of a
-(1920*a) x (1080*b) image, a*b = N (N=4 is BASELINE.json configs[3], 3840x2160) -- and the strips
-exchange a-trous halo rows over RCCL (nebulae_amd/strips.py).  `value` is in 1080p-frame
-equivalents per second: N x (global frames/s).  Two more legs ride in the same JSON line for N > 1:
-  "strong_1080p_frames_per_s"  the metric's own curve: ONE 1920x1080 frame cut into N strips;
-  "config5"                    (N = 8, or --config5) BASELINE.json configs[4]: 3840x2160 in N strips, 4 spp, the camera
-                               orbiting for half the frames and still for the rest -- the reference's policy (SVGF
-                               skipped while moving, history reset on the first still frame) and "always-on".
+N > 1 (`value`, strong scaling = the metric's own curve): the SAME 1920x1080 frame cut into N row strips, one per GPU,
+which exchange a-trous halo rows over RCCL (nebulae_amd/strips.py); `value` = frames/s of that frame.  Two more legs ride in
+the same JSON line for N > 1:
+  "weak_scaling"  the frame grows with N -- rank r owns a 1080p-equivalent row strip of a (1920*a) x (1080*b) image,
+                  a*b = N (N=4 is BASELINE.json configs[3], 3840x2160) -- in 1080p-frame equivalents per second;
+  "config5"       (N = 8, or --config5) BASELINE.json configs[4]: 3840x2160 in N strips, 4 spp, the camera
+                  orbiting for half the frames and still for the rest -- the reference's policy (SVGF
+                  skipped while moving, history reset on the first still frame) and "always-on".
 
 Prints ONE JSON line (rank 0) with "roofline" (dominant SVGF kernel = a-trous level, HBM bound,
 algorithmic 46 B/px/level) and "cpu_baseline" (the scalar C/C++ oracle on the host cores).
@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TEMPORAL_BYTES_PX = 82  # 60 B read + 22 B written
 ATROUS_BYTES_PX = 46    # per level: 30 B read + 16 B written
 GI_STREAM_BYTES_PX = 56  # 24 B G-buffer read + 32 B radiance read-modify-write
-PROFILE_ROUND = "r02"   # only PMC summaries of this round's kernels are quoted (profiles/r02*_*.json)
+PROFILE_ROUND = "r03"   # only PMC summaries of this round's kernels are quoted (profiles/r03*_*.json), and only of this very build
 
 
 def parse():
@@ -57,61 +57,94 @@ def parse():
     ap.add_argument("--sort-rays", type=int, default=-1, help="GI ray sorting mask: bit 0 shadow rays, bit 1 bounce rays (-1 = library default)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the GI stages of frame f+1 on a side stream while frame f is denoised (measured: +1 %%, off by default)")
-    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling leg (one 1080p frame in N strips)")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (the frame that grows with N)")
+    ap.add_argument("--scene", default=None, help="a .gltf / .glb file to render instead of the procedural Sponza stand-in "
+                    "(e.g. a real sponza-gltf-pbr/Sponza.glb, the reference's default scene: src/Nebulae.cpp:36)")
+    ap.add_argument("--exchange", choices=("torch", "rccl"), default=None,
+                    help="N > 1: halo transport -- torch.distributed P2P on the planes, or the library's own neb_strips_exchange (RCCL); "
+                         "default: NEB_STRIPS_EXCHANGE or torch")
+    ap.add_argument("--scheme", choices=("once", "per_level", "auto"), default="auto",
+                    help="N > 1: halo exchange scheme (auto: the cheaper one by strips.choose_scheme's cost table)")
     ap.add_argument("--config5", action="store_true", help="also run BASELINE.json configs[4] (default: only when N = 8)")
     ap.add_argument("--config5-frames", type=int, default=32, help="frames of the config-5 sequence (half moving, half still)")
     return ap.parse_args()
 
 
+def library_build_id():
+    """sha1 over the sources the HIP library is built from: a committed counter summary is only quoted for the build it was
+    taken on (tools/profile_round.sh stamps it into the summaries)."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in (os.path.join(ROOT, "nebulae_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h", ".hpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_profile(pattern):
-    """Newest committed profile summary of THIS round matching profiles/<round>*<pattern>, or None: PMC counters need their
-    own rocprofv3 passes (one counter group per pass), so bench.py quotes the committed summary of the same workload."""
+    """Newest committed profile summary of THIS round AND THIS BUILD matching profiles/<round>*<pattern>, or None: PMC
+    counters need their own rocprofv3 passes (one counter group per pass), so bench.py quotes the committed summary of the
+    same workload -- never one taken on other kernels."""
     import glob
-    best = None
+    best, bid = None, library_build_id()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}*{pattern}"))):
         try:
-            best = (json.load(open(f)), os.path.basename(f))
+            d = json.load(open(f))
         except Exception:
             continue
+        if d.get("build_id") == bid:
+            best = (d, os.path.basename(f))
     return best
 
 
+def _pure_level(name):
+    """a kernel-stats name of a pure a-trous level (not the launch that carries the temporal pass: template argument IN = 2)"""
+    import re
+    m = re.search(r"svgf_atrous_lds_kernel<\d+, \d+, (\d+)", name)
+    return "svgf_atrous" in name and (m is None or m.group(1) != "2")
+
+
 def measured_traffic(width, height, levels):
-    """HBM bytes per a-trous launch (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections, tools/traffic_from_pmc.py)."""
+    """HBM bytes per a-trous launch (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections, tools/traffic_from_pmc.py),
+    mean over the pure levels; the fused temporal + level-0 launch apart."""
     got = committed_profile("hbm_traffic.json")
     if not got:
         return None
     d, name = got
     if d.get("width") != width or d.get("height") != height:
         return None
-    per = [v["total"] for k, v in d["kernels"].items() if "svgf_atrous" in k]
-    if len(per) != levels:
+    per = [v["total"] for k, v in d["kernels"].items() if _pure_level(k)]
+    fused = [v["total"] for k, v in d["kernels"].items() if "svgf_atrous" in k and not _pure_level(k)]
+    if not per:
         return None
-    return sum(per) / len(per), name
+    return sum(per) / len(per), name, (fused[0] if fused else None)
 
 
 def measured_valu(width, height, levels):
-    """f32 VALU occupancy of the a-trous launches (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU), or None."""
+    """f32 VALU instructions of the pure a-trous launches (SQ_INSTS_VALU), or None."""
     got = committed_profile("sq_counters.json")
     if not got:
         return None
     d, name = got
-    per = [v for k, v in d.get("kernels", {}).items() if "svgf_atrous" in k]
-    if len(per) != levels:
+    per = [v for k, v in d.get("kernels", {}).items() if _pure_level(k)]
+    if not per:
         return None
     insts = sum(v["SQ_INSTS_VALU"] for v in per) / len(per)
-    # priced at the measured issue cost of a wave64 f32 instruction with 3-4 waves per SIMD (tools/ubench_exec.hip,
-    # tools/ubench_valu.hip: 1.0-1.3 ns; v_exp / v_log 3.5 ns) -- NOT at SQ_ACTIVE_INST_VALU, which charges 4 cycles per
-    # instruction where the pipe needs about 2.5 (DESIGN.md 3)
+    # priced at the measured issue cost of this kernel's own instruction mix with three waves per SIMD (tools/ubench_bank.hip:
+    # 1.25 ns per three-operand wave-instruction, + 3.4 ns for each v_exp / v_log) -- NOT at SQ_ACTIVE_INST_VALU, which
+    # charges 4 cycles per instruction (DESIGN.md 3)
     transcendental = 2 * 25 * width * height / 64.0
     return {"lane_instructions_per_pixel": insts * 64.0 / (width * height),
-            "issue_us_per_launch": ((insts - transcendental) * 1.2e-3 + transcendental * 3.5e-3) / 1024.0,
-            "ns_per_wave_instruction": 1.2, "source": name}
+            "issue_us_per_launch": (insts * 1.25e-3 + transcendental * 3.4e-3) / 1024.0,
+            "ns_per_wave_instruction": 1.25, "ns_extra_per_transcendental": 3.4, "source": name}
 
 
 def host_cores():
+    """(threads the CPU leg uses, cores this process may run on): a 1-GPU box shares its host and gpurun's share is 16 cores."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(n, 16))  # a 1-GPU box shares its host: 16 cores is this job's CPU share
+    return max(1, min(n, 16)), n
 
 
 def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
@@ -123,7 +156,7 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
 
     import numpy as np
     from oracle_lib import OracleSVGF, OracleTracer, SvgfParams, lib
-    cores = host_cores()
+    cores, cores_available = host_cores()
     med = lambda v: float(np.median(v))  # noqa: E731
     # ---- all cores: `frames` GI frames + `frames` SVGF frames, median of each ----
     t_gi, rays = [], 0
@@ -175,7 +208,8 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
     t1_svgf = time.perf_counter() - t0
     o.close()
     dt_one = (t1_gi + t1_svgf) * scale
-    return {"value": 1.0 / dt_all, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / dt_all, "unit": "frames/s", "cores": cores, "cores_available": cores_available,
+            "cores_note": f"{cores} of the {cores_available} cores this process may run on (host has {os.cpu_count()})", "kind": "port",
             "gi_mrays_per_s": (rays / med(t_gi) / 1e6) if do_gi else None,
             "sample": (f"median of {frames} full {W}x{H} GI frames ({rays} rays, {med(t_gi) * 1e3:.0f} ms) of oracle/trace_ref.cpp + " if do_gi else "")
                       + f"median of {len(t_svgf)} full {W}x{H} SVGF frames (temporal + {L} a-trous levels, {med(t_svgf) * 1e3:.0f} ms) of "
@@ -188,15 +222,20 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
 class Workload:
     """One strip renderer of a GW x GH frame cut into `world` row strips, its static G-buffer and direct-light term."""
 
-    def __init__(self, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True):
+    def __init__(self, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True, scheme=None):
         import torch
         from nebulae_amd import strips, synth
         from nebulae_amd.renderer import RenderInfo
         from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE
         self.torch, self.RenderInfo = torch, RenderInfo
         self.args, self.GW, self.GH, self.L, self.sc, self.cam, self.rank, self.world, self.do_gi = args, GW, GH, L, sc, cam, rank, world, do_gi
-        self.part = strips.StripPartition(GW, GH, world, L)
-        self.r = r = strips.StripRenderer(self.part, rank, device=local_rank, group=group)
+        self.part = strips.StripPartition(GW, GH, world, L, scheme=scheme)
+        self.r = r = strips.StripRenderer(self.part, rank, device=local_rank, group=group, exchange=args.exchange)
+        # one strip = the whole frame: temporal + a-trous run as the library's fused chain when every pixel is covered by both
+        self.fused_chain = (world == 1 and GW % 8 == 0 and GH % 8 == 0 and 1 <= L <= 6 and args.atrous_variant == 1
+                            and not os.environ.get("NEB_BENCH_NO_FUSE"))
+        if os.environ.get("NEB_BENCH_NO_FUSE"):
+            r.svgf.set_option("svgf_fuse", 0)
         r.svgf.set_option("atrous_variant", args.atrous_variant)
         r.gi_ui.gi_samples_per_pixel = spp
         self.own = self.part.owned(rank)
@@ -304,11 +343,19 @@ class Workload:
         rays = self.r.ray_count(reset=True) if self.do_gi else 0
         return self.reduce_max_sum(dt, rays)
 
+    def parallelism_label(self):
+        p = self.part
+        if self.world == 1:
+            return "single GPU"
+        return (f"row-strips x{self.world} of {p.H // p.N} rows + halo exchange over RCCL: scheme '{p.scheme}' ({p.scheme_reason}; "
+                f"{'one exchange per frame' if p.scheme == 'once' else 'one exchange per a-trous level'}, {p.exchanged_bytes_per_frame() / 1e6:.1f} MB sent "
+                f"per rank and frame), transport '{self.r.exchange}' ({'neb_strips_exchange: grouped ncclSend / ncclRecv' if self.r.exchange == 'rccl' else 'torch.distributed batch_isend_irecv on the planes'})")
+
     def destroy(self):
         self.r.destroy()
 
 
-def run_config5(args, sc, rank, world, local_rank, group):
+def run_config5(args, sc, rank, world, local_rank, group, scheme=None):
     """BASELINE.json configs[4]: 3840x2160 in `world` strips, 4 spp, 5 levels; the camera orbits
     (yaw += 0.5 deg per frame) for the first half of the sequence and stands still for the second.  Two runs: the
     reference's policy (SVGF skipped while moving, history reset on the first still frame) and always-on (beyond the
@@ -319,10 +366,10 @@ def run_config5(args, sc, rank, world, local_rank, group):
 
     def cam_at(k):
         return S.orbit_camera(origin=(0.0, 2.0, 0.0), yaw_deg=12.0 + 0.5 * min(k + 1, half), pitch_deg=60.0, distance=9.0)
-    out = {"workload": f"sponza-standin 3840x2160, 4 spp one-bounce GI + SVGF temporal + 5 a-trous levels, {world} row strips of {2160 // world} rows, "
+    out = {"workload": f"3840x2160, 4 spp one-bounce GI + SVGF temporal + 5 a-trous levels, {world} row strips of {2160 // world} rows, "
                        f"{half} frames with the camera orbiting (yaw += 0.5 deg per frame; G-buffer and direct term re-rendered) then {n - half} still frames"}
     for mode in ("reference_policy", "always_on"):
-        w = Workload(args, 3840, 2160, 5, 4, sc, cam_at(-1), rank, world, local_rank, group)
+        w = Workload(args, 3840, 2160, 5, 4, sc, cam_at(-1), rank, world, local_rank, group, scheme=scheme)
         w.r.denoise_while_moving = mode == "always_on"
         w.step()  # one still frame first, so that the sequence starts from a settled state
         w.step()
@@ -365,12 +412,26 @@ def main():
 
     L = args.levels
     do_gi = not args.svgf_only
-    # weak scaling: the global frame is (W*a) x (H*b) with a*b = world; every rank owns W*H pixels of it
-    a, b = strips.frame_factors(world)
-    GW, GH = args.width * a, args.height * b
-    sc = S.atrium_standin(target_triangles=args.triangles, tex_size=args.tex_size)
+    if args.scene:
+        # a real scene file (e.g. the reference's default sponza-gltf-pbr/Sponza.glb, stripped from its checkout) through the
+        # same loader the tests use; the camera stays the reference's Sponza view
+        sc = S.load_gltf(args.scene)
+        scene_label = f"{os.path.basename(args.scene)}"
+    else:
+        sc = S.atrium_standin(target_triangles=args.triangles, tex_size=args.tex_size)
+        scene_label = "sponza-standin"
     cam = S.sponza_camera()
-    w = Workload(args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi)
+    scheme = None if args.scheme == "auto" else args.scheme
+
+    def workload_label(gw, gh, spp, levels, gi=True):
+        tex = sorted({t.shape[0] for t in sc.textures}) if sc.textures else []
+        return (f"{scene_label} {gw}x{gh} ({sc.num_triangles} triangles, {len(sc.geometries)} submeshes, {len(sc.materials)} materials, "
+                f"{len(sc.textures)} textures" + (f" of {tex[-1]}^2" if tex else "") + f"), {spp} spp one-bounce GI + SVGF temporal + {levels} a-trous levels"
+                + ("" if gi else " [GI skipped: --svgf-only]"))
+
+    # ---- the primary workload: ONE width x height frame (BASELINE.json configs[2]) on `world` GPUs = `world` row strips ----
+    GW, GH = args.width, args.height
+    w = Workload(args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme)
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
     bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth()} if do_gi else None
@@ -382,17 +443,24 @@ def main():
     fps_with_gather = None
     if args.gather and world > 1:
         dtg, _ = w.timed(args.steps, 0, lambda k: (w.step(), r.gather_frame(dst=0)))
-        fps_with_gather = args.steps / dtg * world
+        fps_with_gather = args.steps / dtg
 
     # ---- per-kernel durations: HIP events on the launch stream, 8 extra frames with an event pair per pass, and 8 more in
-    # which the L a-trous launches are bracketed by ONE pair (every event is a packet of its own between two launches: the
-    # roofline's mean level duration is taken where there are fewest of them) ----
-    ev, ev2 = [], []
+    # which the SVGF chain is bracketed by ONE pair (every event is a packet of its own between two launches).  One GPU: the
+    # chain is the library's own (temporal pass fused into level 0) and the per-kernel marks are its own events on the
+    # launch stream (option svgf_profile -> neb_svgf_level_times); N > 1: the strip renderer's per-level events. ----
+    ev, ev2, lt = [], [], []
+    if world == 1:
+        r.svgf.set_option("svgf_profile", 1)
     for _ in range(8):
-        e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1")}
+        e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1", "a1")}
         e["levels"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
         w.step(e)
+        if world == 1:
+            lt.append(r.svgf.level_times())
         ev.append(e)
+    if world == 1:
+        r.svgf.set_option("svgf_profile", 0)
     for _ in range(8):
         e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1", "a1")}
         w.step(e)
@@ -400,14 +468,25 @@ def main():
     torch.cuda.synchronize()
     rays_ev = (r.ray_count(reset=True) if do_gi else 0) // 2  # (two batches of 8 frames)
     t_gi = float(np.mean([e["gi0"].elapsed_time(e["gi1"]) for e in ev])) * 1e-3
-    t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev])) * 1e-3
-    per_level = [float(np.mean([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev])) * 1e-3 for i in range(L)]
-    # (with N > 1 the first level's interval also holds the halo exchange it overlaps with, and every level but the last
-    # filters a few extra rows: the roofline line is then taken over the levels after the first)
-    t_atrous = float(np.mean(per_level if (world == 1 or L == 1) else per_level[1:]))
-    if world == 1 and L > 0:
-        t_atrous = float(np.mean([e["t1"].elapsed_time(e["a1"]) for e in ev2])) * 1e-3 / L
-    own_px = (w.own[1] - w.own[0]) * GW                      # pixels a rank owns (= one 1080p frame)
+    fused = False
+    if world == 1:
+        per_level = [float(np.mean([x[i] for x in lt])) * 1e-6 for i in range(L)]
+        t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev2])) * 1e-3
+        fused = w.fused_chain
+        if fused:
+            t_temporal = 0.0  # (the held-back call: the pass runs inside level 0's kernel)
+        t_svgf_chain = float(np.mean([e["t0"].elapsed_time(e["a1"]) for e in ev2])) * 1e-3  # temporal + all levels, two events
+        # the roofline's kernel = a pure a-trous level (levels 1.. of the fused chain; every level otherwise)
+        pure = per_level[1:] if (fused and L > 1) else per_level
+        t_atrous = float(np.mean(pure)) if pure else 0.0
+    else:
+        t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev])) * 1e-3
+        per_level = [float(np.mean([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev])) * 1e-3 for i in range(L)]
+        # (with N > 1 the first level's interval also holds the halo exchange it overlaps with, and every level but the last
+        # filters a few extra rows: the roofline line is then taken over the levels after the first)
+        t_atrous = float(np.mean(per_level if L == 1 else per_level[1:]))
+        t_svgf_chain = t_temporal + sum(per_level)
+    own_px = (w.own[1] - w.own[0]) * GW                      # pixels a rank owns
     gb = noisy = consts = None
     if rank == 0 and args.cpu_frames > 0 and world == 1:
         gb = {"albedo": r.svgf.download(PLANE_ALBEDO, 0), "rough_metal": r.svgf.download(PLANE_ROUGH_METAL, 0),
@@ -415,66 +494,78 @@ def main():
               "depth": r.svgf.download(PLANE_DEPTH, 0)}
         noisy = w.noisy_dev[0].cpu().numpy() if not do_gi else None
         consts = r.global_constants()
-    exchanged = part.exchanged_bytes_per_frame()
-    scheme = part.scheme
+    parallelism = w.parallelism_label()
+    halo_rows = part.halo
     w.destroy()
 
-    # ---- N > 1: the metric's own curve (strong scaling of ONE 1080p frame) and BASELINE.json configs[4] ----
-    strong = None
-    if world > 1 and not args.no_strong and do_gi:
-        ws = Workload(args, args.width, args.height, L, args.spp, sc, cam, rank, world, local_rank, group)
-        dts, rays_s = ws.timed(args.steps, max(args.warmup, 2))
-        strong = {"frames_per_s": args.steps / dts, "ms_per_frame": dts / args.steps * 1e3, "mrays_per_s": rays_s / dts / 1e6,
-                  "rows_per_strip": args.height // world, "halo_rows": ws.part.halo}
-        ws.destroy()
+    # ---- N > 1: the weak-scaling frame (per-GPU work fixed) and BASELINE.json configs[4] ----
+    weak = None
+    if world > 1 and not args.no_weak and do_gi:
+        a, b = strips.frame_factors(world)
+        ww = Workload(args, args.width * a, args.height * b, L, args.spp, sc, cam, rank, world, local_rank, group, scheme=scheme)
+        dtw, rays_w = ww.timed(args.steps, max(args.warmup, 2))
+        weak = {"frames_per_s_1080p_equivalents": args.steps / dtw * world, "global_frames_per_s": args.steps / dtw, "ms_per_frame": dtw / args.steps * 1e3,
+                "mrays_per_s": rays_w / dtw / 1e6, "global_width": args.width * a, "global_height": args.height * b,
+                "rows_per_strip": args.height * b // world, "parallelism": ww.parallelism_label()}
+        ww.destroy()
     config5 = None
     if do_gi and (args.config5 or world == 8):
-        config5 = run_config5(args, sc, rank, world, local_rank, group)
+        config5 = run_config5(args, sc, rank, world, local_rank, group, scheme)
 
     if rank == 0:
-        fps_equiv = args.steps / dt * world               # 1080p-frame equivalents per second, whole job
-        achieved = ATROUS_BYTES_PX * own_px / t_atrous / 1e9
+        fps = args.steps / dt                                 # whole-job frames per second of the ONE frame
+        achieved = ATROUS_BYTES_PX * own_px / t_atrous / 1e9 if t_atrous > 0 else 0.0
         traffic = measured_traffic(GW, GH, L) if world == 1 else None
         valu = measured_valu(GW, GH, L) if world == 1 else None
-        if valu:
-            valu["busy_frac"] = valu["issue_us_per_launch"] / (sum(per_level) / len(per_level) * 1e6)
-        t_svgf = t_temporal + sum(per_level)
+        if valu and t_atrous > 0:
+            valu["busy_frac"] = valu["issue_us_per_launch"] / (t_atrous * 1e6)
         svgf_bytes = (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L) * own_px
-        frame_gbps = svgf_bytes * world * (args.steps / dt) / 1e9
+        # the fused chain's own byte model: temporal reads 60 B + moments / variance writes 6 B + level 0's output 16 B = 82 B/px for
+        # temporal + level 0 together (the accumulated radiance is neither written nor re-read: 46 B/px less), then 46 B/px per level
+        fused_bytes = (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * max(L - 1, 0)) * own_px
+        frame_gbps = svgf_bytes * world * fps / 1e9
         out = {
-            "metric": "denoised frames/s (1920x1080-frame equivalents: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
-                      "denoised frames/s (1920x1080-frame equivalents: SVGF temporal + a-trous only)",
-            "value": fps_equiv, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"sponza-standin {GW}x{GH} ({sc.num_triangles} triangles, {len(sc.geometries)} submeshes, {len(sc.materials)} materials, "
-                                   f"{len(sc.textures)} textures of {args.tex_size}^2), "
-                                   f"{args.spp} spp one-bounce GI + SVGF temporal + {L} a-trous levels"
-                                   + ("" if do_gi else " [GI skipped: --svgf-only]"),
+            "metric": ("denoised frames/s (1920x1080: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
+                       "denoised frames/s (1920x1080: SVGF temporal + a-trous only)"),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic" if not args.scene else f"scene file {os.path.basename(args.scene)}; synthetic camera",
+            "config": {"workload": workload_label(GW, GH, args.spp, L, do_gi),
                        "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
-                       "parallelism": (f"row-strips x{world} + RCCL halo exchange ({'one per frame' if scheme == 'once' else 'one per a-trous level'}, "
-                                       f"{exchanged / 1e6:.1f} MB sent per rank and frame)") if world > 1 else "single GPU",
+                       "parallelism": parallelism, "halo_rows": halo_rows, "rows_per_strip": GH // world,
                        "frames_in_flight": 2 if (do_gi and args.overlap) else 1,
-                       "scene_device_bytes": scene_bytes, "bvh": bvh},
+                       "scene_device_bytes": scene_bytes, "bvh": bvh, "library_build_id": library_build_id()},
             "frames_per_s_with_final_gather": fps_with_gather,
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
             "gi_kernel_mrays_per_s": (rays_ev / 8 / t_gi / 1e6) if do_gi else None,
-            "strong_1080p_frames_per_s": strong["frames_per_s"] if strong else (fps_equiv if world == 1 else None),
-            "strong_1080p": strong,
+            "weak_scaling": weak,
             "config5": config5,
-            "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": t_temporal * 1e6, "atrous_levels": [t * 1e6 for t in per_level]},
-            "roofline": {"bound": "hbm", "kernel": "svgf_atrous_lds_kernel (mean over the levels of a frame: HIP events around the L launches / L)",
+            "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": None if fused else t_temporal * 1e6,
+                          "fused_temporal_level0": per_level[0] * 1e6 if (fused and L > 0) else None,
+                          "atrous_levels": [t * 1e6 for t in per_level], "svgf_chain": t_svgf_chain * 1e6},
+            "roofline": {"bound": "hbm",
+                         "kernel": ("svgf_atrous_lds_kernel, a pure level (mean over levels 1.. of the fused chain: the library's own HIP events on the launch stream)"
+                                    if fused else "svgf_atrous_lds_kernel (mean over the levels of a frame)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
-                         # the contract prices this kernel against HBM; what a level's time is made of in fact (timing-only
-                         # builds): ~15 us tap arithmetic + ~12 us LDS reads / staging / barriers + ~7 us exposed memory
-                         "limiter": "on-chip work (VALU + LDS issue), memory time only partly hidden" if valu else None, "valu": valu},
-            "temporal_roofline": {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9 / HBM_PEAK_GBPS},
-            # the same byte model over longer intervals: all of SVGF (temporal + L levels, kernel time), and the whole frame
-            # (GI included in the time, SVGF's algorithmic bytes only -- the GI stage is not HBM-priced)
-            "svgf_roofline": {"achieved": svgf_bytes / t_svgf / 1e9, "frac": svgf_bytes / t_svgf / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s"},
+                         # the contract prices this kernel against HBM; what binds it in fact is instruction issue
+                         "limiter": "VALU issue: 25 taps x (12 three-operand instructions + v_log + v_exp) per pixel" if valu else None, "valu": valu},
+            "temporal_roofline": (None if (fused or t_temporal <= 0) else
+                                  {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9 / HBM_PEAK_GBPS}),
+            # the same byte model over longer intervals: all of SVGF (temporal + L levels: SURVEY 8d's (82 + 46 L) B/px over the
+            # chain's time), the chain's own fused byte model beside it, and the whole frame (GI included in the time, SVGF's
+            # algorithmic bytes only -- the GI stage is not HBM-priced)
+            "svgf_roofline": {"achieved": svgf_bytes / t_svgf_chain / 1e9, "frac": svgf_bytes / t_svgf_chain / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s",
+                              "bytes_per_px": TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * L, "us": t_svgf_chain * 1e6},
+            "svgf_fused_model": ({"bytes_per_px": TEMPORAL_BYTES_PX + ATROUS_BYTES_PX * max(L - 1, 0), "achieved": fused_bytes / t_svgf_chain / 1e9,
+                                  "frac": fused_bytes / t_svgf_chain / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "fused_launch": {"bytes_per_px": TEMPORAL_BYTES_PX, "us": per_level[0] * 1e6,
+                                                   "frac": TEMPORAL_BYTES_PX * own_px / per_level[0] / 1e9 / HBM_PEAK_GBPS,
+                                                   "traffic": traffic[2] if traffic else None},
+                                  "note": "temporal + level 0 as one launch: 60 B read + 6 B moments / variance + 16 B level-0 output = 82 B/px; "
+                                          "the accumulated radiance is never written or re-read"} if (fused and L > 0) else None),
             "frame_roofline": {"achieved": frame_gbps, "frac": frame_gbps / HBM_PEAK_GBPS, "unit": "GB/s",
                                "note": "SVGF algorithmic bytes / whole-frame time (GI included)"},
             "frame_algorithmic_GBps": frame_gbps,

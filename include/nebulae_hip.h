@@ -107,8 +107,8 @@ int neb_svgf_default_params(neb_svgf_params* out);
 int neb_svgf_set_params(neb_ctx* ctx, const neb_svgf_params* p);
 int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
 /* Implementation knobs with no reference counterpart (A/B arms for profiling):
- *   "atrous_variant": 1 = LDS row-lattice kernel (default; 4 rows per lane for steps <= 4, 2 for wider steps),
- *                     2 / 3 = LDS kernel with 2 / 4 rows per lane everywhere, 0 = direct-load kernel;
+ *   "atrous_variant": 1 = LDS row-lattice kernel (default; 4 rows per lane for steps <= 4, 2 for steps 8..32; wider steps take the
+ *                     direct kernel), 0 = direct-load kernel;
  *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene);
  *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (default on),
  *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
@@ -119,7 +119,8 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "gi_exact_shade":   1 = hit shading in the C arithmetic of the CPU oracle (IEEE division, sqrt, powf, sinf / cosf) instead of
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;
- *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3). */
+ *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);
+ *   "svgf_fuse":        1 (default) / 0, see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1, see neb_svgf_level_times. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
 /* ---- resource sharing: the ~25 getters of SVGFDenoiser.h:24-70 collapse into one call.
@@ -140,8 +141,22 @@ int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream);
  * reference: the a-trous levels of the frame read the decoded copy this pass (or, for rows it did not cover, a lazy decode) made. */
 int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream);
 /* SVGFDenoiser::SubmitATrousComputeWavelet (SVGFDenoiser.cpp:133-203): all levels, all rows.
- * Only valid when the context holds the full image (row_begin == 0, row_end == height). */
+ * Only valid when the context holds the full image (row_begin == 0, row_end == height).
+ *
+ * The two calls above, made in this order on the same stream with nothing between them -- what
+ * DeferredRenderer::SubmitCommandsSVGFDenoising does (src/DeferredRenderer.cpp:593-614) -- run as ONE chain on a whole-frame
+ * context whose width and height are multiples of 8: neb_svgf_temporal only notes the request, and neb_svgf_atrous runs the
+ * temporal pass inside the staging phase of level 0 (the accumulated radiance is never written to memory: quirk 5 makes the
+ * FILTERED image the next frame's history), carries the luminance between the levels and writes radiance[cur], moments[cur] and
+ * variance exactly as the separate passes do -- the same bits.  Any other call in between (a plane pointer, an upload or
+ * download, a row-range form, neb_end_frame ...) first submits the noted pass as its own kernel, so callers never observe the
+ * difference, except in radiance[hist] and the scratch plane, which hold intermediate levels afterwards (as radiance[hist] does
+ * in the reference), here with the luminance in .w.  Option "svgf_fuse" = 0 always runs the separate kernels. */
 int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream);
+/* With option "svgf_profile" = 1, neb_svgf_atrous brackets each of its kernels with events on `stream`; this call waits for the
+ * last chain submitted and returns the kernels' durations in microseconds (entry 0 = level 0, fused with the temporal pass when
+ * the chain ran fused), *n_out = how many. */
+int neb_svgf_level_times(neb_ctx* ctx, float* out_us, uint32_t capacity, uint32_t* n_out);
 /* Row-range forms for multi-GPU row strips (no reference counterpart):
  * image rows [row0,row1) must be resident, and for the a-trous level so must every
  * (globally clamped) tap row.  `level` picks step = 1 << level and the source/destination
@@ -171,6 +186,12 @@ typedef struct neb_halo_swap {
 int neb_strips_unique_id(void* id128);
 int neb_strips_comm_create(int device, int n_ranks, int rank, const void* id128, void** out_comm);
 int neb_strips_comm_destroy(void* comm);
+/* ncclGroupStart / ncclGroupEnd.  A host with ONE process (or thread) per GPU never needs them.  A host that drives several GPUs
+ * from one thread must bracket the neb_strips_comm_create calls of all its ranks in one group (ncclCommInitRank blocks until every
+ * rank has joined: RCCL's rule for one thread with several devices; *out_comm is then valid once the group has ended), and likewise
+ * the neb_strips_exchange calls of all its contexts for one exchange (the group each call opens nests inside the caller's). */
+int neb_strips_group_begin(void);
+int neb_strips_group_end(void);
 /* For every listed plane and every swap: send rows [send_row0, send_row1), receive rows [recv_row0, recv_row1), all in ONE RCCL group,
  * enqueued on `stream` (ordered after the kernels that produced the rows, before the ones that read the halo).  Every rank of the
  * communicator must make the matching call.  comm = the ncclComm_t from neb_strips_comm_create (or the host's own). */

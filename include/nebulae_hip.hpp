@@ -121,9 +121,14 @@ namespace Neb
 
     // Halo exchange between the row strips of a multi-GPU frame (no reference counterpart: Nebulae is single-GPU).
     // One communicator per strip group; Exchange() enqueues one RCCL group of sends / receives on the caller's stream.
+    // Threading: with one process or thread per GPU nothing else is needed.  ONE thread that drives several GPUs must put
+    // the Init() calls of all its ranks, and the Exchange() calls of all its strips for one exchange, between
+    // GroupBegin() and GroupEnd() (RCCL's rule for one thread with several devices; otherwise Init blocks for ever).
     class StripExchange
     {
     public:
+        static void GroupBegin() { Check(neb_strips_group_begin(), "neb_strips_group_begin"); }
+        static void GroupEnd() { Check(neb_strips_group_end(), "neb_strips_group_end"); }
         StripExchange() = default;
         StripExchange(const StripExchange&) = delete;
         StripExchange& operator=(const StripExchange&) = delete;

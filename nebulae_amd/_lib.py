@@ -58,6 +58,7 @@ _SIGS = {
     "neb_download_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "neb_stream_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "neb_svgf_reset_history": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neb_svgf_level_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "neb_svgf_temporal": (C.c_int, [C.c_void_p, C.c_void_p]),
     "neb_svgf_atrous": (C.c_int, [C.c_void_p, C.c_void_p]),
     "neb_svgf_temporal_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
@@ -66,6 +67,8 @@ _SIGS = {
     "neb_strips_unique_id": (C.c_int, [C.c_void_p]),
     "neb_strips_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "neb_strips_comm_destroy": (C.c_int, [C.c_void_p]),
+    "neb_strips_group_begin": (C.c_int, []),
+    "neb_strips_group_end": (C.c_int, []),
     "neb_strips_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(HaloPlane), C.c_uint32, C.POINTER(HaloSwap), C.c_uint32, C.c_void_p]),
     "neb_strips_last_error": (C.c_char_p, []),
 }

@@ -175,6 +175,7 @@ int neb_resize(neb_ctx* ctx, uint32_t width, uint32_t height)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_resize: bad argument");
     if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
         return fail(ctx, NEB_ERR_STATE, "neb_resize: only a full-image context can be resized");
+    ctx->pending_temporal = false; // (the planes it would have written are about to be freed)
     NEB_GUARD(ctx);
     NEB_HIP(ctx, hipDeviceSynchronize());
     free_planes(ctx);
@@ -193,6 +194,8 @@ int neb_destroy(neb_ctx* ctx)
     DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();
     free_planes(ctx);
+    for (hipEvent_t e : ctx->prof_events)
+        (void)hipEventDestroy(e);
     gi_destroy(ctx->gi);
     delete ctx;
     return NEB_OK;
@@ -216,13 +219,15 @@ int neb_begin_frame(neb_ctx* ctx, uint32_t frame_index)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     ctx->cur = (int)(frame_index & 1u); // SVGFDenoiser.cpp:41-42
     ctx->hist = ctx->cur ^ 1;
     geometry_invalidate(ctx); // a new frame has a new G-buffer
     return NEB_OK;
 }
 
-int neb_end_frame(neb_ctx* ctx) { return ctx ? NEB_OK : NEB_ERR_INVALID_ARG; } // SVGFDenoiser.cpp:45-47
+int neb_end_frame(neb_ctx* ctx) { return ctx ? svgf_flush_pending(ctx) : NEB_ERR_INVALID_ARG; } // SVGFDenoiser.cpp:45-47
 
 int neb_current_index(const neb_ctx* ctx) { return ctx ? ctx->cur : NEB_ERR_INVALID_ARG; }
 int neb_history_index(const neb_ctx* ctx) { return ctx ? ctx->hist : NEB_ERR_INVALID_ARG; }
@@ -246,6 +251,8 @@ int neb_svgf_set_params(neb_ctx* ctx, const neb_svgf_params* p)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_set_params: null argument");
     if (!(p->depthSigma > 0.f) || !(p->phiDepth > 0.f) || !(p->phiNormal > 0.f))
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_set_params: depthSigma, phiDepth, phiNormal must be > 0");
+    if (int rc = svgf_flush_pending(ctx)) // (a held-back temporal pass was submitted with the constants of its own call)
+        return rc;
     ctx->params = *p;
     return NEB_OK;
 }
@@ -262,10 +269,25 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
 {
     if (!ctx || !key)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: null argument");
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     if (!strcmp(key, "atrous_variant")) {
-        if (value < 0 || value > 3)
-            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: atrous_variant must be 0..3");
+        if (value < 0 || value > 1)
+            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: atrous_variant must be 0 (direct kernel) or 1 (LDS kernel)");
         ctx->atrous_variant = value;
+        return NEB_OK;
+    }
+    if (!strcmp(key, "svgf_profile")) {
+        if (value < 0 || value > 1)
+            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: svgf_profile must be 0 or 1");
+        ctx->profile = value;
+        ctx->prof_recorded = 0;
+        return NEB_OK;
+    }
+    if (!strcmp(key, "svgf_fuse")) {
+        if (value < 0 || value > 1)
+            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: svgf_fuse must be 0 or 1");
+        ctx->fuse = value;
         return NEB_OK;
     }
     if (!strcmp(key, "gi_sort_rays")) {
@@ -321,6 +343,8 @@ int neb_get_plane(neb_ctx* ctx, int plane, int slot, void** dptr, size_t* pitch_
     const int s = resolve_slot(ctx, plane, slot);
     if (s < 0)
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_get_plane: bad plane/slot");
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     if (plane == NEB_PLANE_NORMAL || plane == NEB_PLANE_DEPTH)
         geometry_invalidate(ctx); // the caller may write through the pointer: decode again before the next a-trous level
     *dptr = ctx->planes[plane][s];
@@ -341,6 +365,8 @@ static int copy_rows(neb_ctx* ctx, int plane, int slot, uint32_t row0, uint32_t 
         return fail(ctx, NEB_ERR_INVALID_ARG, "copy rows: bad plane/slot");
     if (row0 < ctx->row_begin || row0 + nrows > ctx->row_end)
         return fail(ctx, NEB_ERR_OUT_OF_RANGE, "copy rows: rows not resident in this context");
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     const size_t pitch = (size_t)ctx->W * kPlaneInfo[plane].bytes_per_px;
     char* d = (char*)ctx->planes[plane][s] + (size_t)(row0 - ctx->row_begin) * pitch;
     NEB_GUARD(ctx);
@@ -367,6 +393,8 @@ int neb_stream_synchronize(neb_ctx* ctx, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     NEB_GUARD(ctx);
     NEB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return NEB_OK;
@@ -379,6 +407,8 @@ int neb_svgf_reset_history(neb_ctx* ctx, neb_stream stream)
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
     // CopyResource(history <- current); moments/variance are NOT reset (SVGFDenoiser.cpp:57).
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     NEB_GUARD(ctx);
     const size_t bytes = (size_t)ctx->W * (ctx->row_end - ctx->row_begin) * 16;
     NEB_HIP(ctx, hipMemcpyAsync(ctx->planes[NEB_PLANE_RADIANCE][ctx->hist], ctx->planes[NEB_PLANE_RADIANCE][ctx->cur],
@@ -427,6 +457,21 @@ static hipError_t geometry_ensure(neb_ctx* ctx, uint32_t row0, uint32_t row1, hi
     return e;
 }
 
+// option svgf_profile: event k is recorded in front of the k-th kernel of neb_svgf_atrous's chain (k = levels: behind the last)
+static void profile_mark(neb_ctx* ctx, uint32_t k, hipStream_t stream)
+{
+    if (!ctx->profile)
+        return;
+    while (ctx->prof_events.size() <= k) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess)
+            return;
+        ctx->prof_events.push_back(e);
+    }
+    if (hipEventRecord(ctx->prof_events[k], stream) == hipSuccess && ctx->prof_recorded < k + 1)
+        ctx->prof_recorded = k + 1;
+}
+
 static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
 {
     SvgfLaunch L;
@@ -442,12 +487,16 @@ static SvgfLaunch make_launch(const neb_ctx* ctx, uint32_t row0, uint32_t row1)
     return L;
 }
 
+static int svgf_fused_chain(neb_ctx* ctx, hipStream_t stream);
+
 int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
     if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
         return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_temporal_rows: rows not resident");
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     const int c = ctx->cur, h = ctx->hist;
     NEB_GUARD(ctx);
     ScopedRange range("SVGF: Temporal Accumulation"); // SVGFDenoiser.cpp:69
@@ -471,10 +520,30 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
     return NEB_OK;
 }
 
+// Can this context's next frame run as the fused chain (temporal pass inside level 0, intermediate planes carrying the
+// luminance)?  A whole frame whose every pixel both passes cover (Dispatch(W/8, H/8) floors), every level on the LDS kernel.
+static bool fused_chain_possible(const neb_ctx* ctx)
+{
+    if (!ctx->fuse || ctx->row_begin != 0 || ctx->row_end != ctx->H || (ctx->W % 8u) || (ctx->H % 8u) || ctx->levels == 0)
+        return false;
+    const SvgfLaunch L = make_launch(ctx, 0, ctx->H);
+    for (uint32_t i = 0; i < ctx->levels; ++i)
+        if (!atrous_lds_serves(L, ctx->atrous_variant, 1u << i))
+            return false;
+    return true;
+}
+
 int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
+    if (fused_chain_possible(ctx)) { // held back: neb_svgf_atrous runs it inside level 0; anything else submits it first
+        ctx->pending_temporal = true;
+        ctx->pending_stream = (hipStream_t)stream;
+        return NEB_OK;
+    }
     return neb_svgf_temporal_rows(ctx, ctx->row_begin, ctx->row_end, stream);
 }
 
@@ -524,6 +593,8 @@ int neb_svgf_atrous_level_rows(neb_ctx* ctx, uint32_t level, uint32_t row0, uint
         return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_atrous_level_rows: level >= atrous_levels");
     if (row0 < ctx->row_begin || row1 > ctx->row_end || row0 > row1)
         return fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_svgf_atrous_level_rows: rows not resident");
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     const uint32_t step = 1u << level;
     // every (globally clamped) tap row must be resident: rows [row0 - 2*step, row1 - 1 + 2*step] clamped to the image
     const uint32_t Hd = (ctx->H / 8u) * 8u;
@@ -561,12 +632,18 @@ int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream)
         return NEB_ERR_INVALID_ARG;
     if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
         return fail(ctx, NEB_ERR_STATE, "neb_svgf_atrous: context holds a row strip; use neb_svgf_atrous_level_rows");
+    if (ctx->pending_temporal && ctx->pending_stream == (hipStream_t)stream && fused_chain_possible(ctx))
+        return svgf_fused_chain(ctx, (hipStream_t)stream);
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
     ScopedRange range("SVGF: A-Trous Wavelet"); // SVGFDenoiser.cpp:136
     for (uint32_t i = 0; i < ctx->levels; ++i) {
+        profile_mark(ctx, i, (hipStream_t)stream);
         int rc = neb_svgf_atrous_level_rows(ctx, i, 0, ctx->H, stream);
         if (rc != NEB_OK)
             return rc;
     }
+    profile_mark(ctx, ctx->levels, (hipStream_t)stream);
     if (ctx->levels == 1) {
         const size_t bytes = (size_t)ctx->W * ctx->H * 16;
         NEB_GUARD(ctx);
@@ -576,4 +653,87 @@ int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream)
     return NEB_OK;
 }
 
+int neb_svgf_level_times(neb_ctx* ctx, float* out_us, uint32_t capacity, uint32_t* n_out)
+{
+    if (!ctx || !out_us || !n_out)
+        return fail(ctx, NEB_ERR_INVALID_ARG, "neb_svgf_level_times: null argument");
+    *n_out = 0;
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
+    if (!ctx->profile || ctx->prof_recorded < 2)
+        return fail(ctx, NEB_ERR_STATE, "neb_svgf_level_times: set option svgf_profile = 1 and run neb_svgf_atrous first");
+    NEB_GUARD(ctx);
+    const uint32_t n = ctx->prof_recorded - 1;
+    NEB_HIP(ctx, hipEventSynchronize(ctx->prof_events[n]));
+    for (uint32_t k = 0; k < n && k < capacity; ++k) {
+        float ms = 0.f;
+        NEB_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[k], ctx->prof_events[k + 1]));
+        out_us[k] = ms * 1e3f;
+    }
+    *n_out = n < capacity ? n : capacity;
+    return NEB_OK;
+}
+
 } // extern "C"
+
+int neb::svgf_flush_pending(neb_ctx* ctx)
+{
+    if (!ctx || !ctx->pending_temporal)
+        return NEB_OK;
+    ctx->pending_temporal = false;
+    return neb_svgf_temporal_rows(ctx, ctx->row_begin, ctx->row_end, (neb_stream)ctx->pending_stream);
+}
+
+// The whole-frame denoise as one chain (same results, bit for bit, as the stand-alone temporal kernel followed by the
+// levels): level 0 with the temporal pass as its staging phase -- the accumulated radiance is never written --
+//   (radiance[cur], radiance[hist], ...) -> scratch {r, g, b, lum}
+// then levels 1 .. L-2 between radiance[hist] and scratch, luminance carried in .w so that a level's staging is two
+// verbatim LDS-DMAs, and the last level into radiance[cur], which until that store holds the frame's input and supplies the
+// alpha the output carries.  radiance[cur] ends up as SubmitATrousComputeWavelet leaves it (SVGFDenoiser.cpp:146-196: the
+// filtered image = next frame's history), moments[cur] / variance as SubmitTemporalAccumulation does; radiance[hist] and
+// scratch hold intermediate levels (as radiance[hist] does in the reference), here with the luminance in .w.
+static int svgf_fused_chain(neb_ctx* ctx, hipStream_t stream)
+{
+    ctx->pending_temporal = false;
+    NEB_GUARD(ctx);
+    const int c = ctx->cur, h = ctx->hist;
+    const uint32_t L = ctx->levels;
+    const SvgfLaunch launch = make_launch(ctx, 0, ctx->H);
+    float4* const rad_cur = (float4*)ctx->planes[NEB_PLANE_RADIANCE][c];
+    float4* const rad_hist = (float4*)ctx->planes[NEB_PLANE_RADIANCE][h];
+    float4* const scratch = (float4*)ctx->planes[NEB_PLANE_SCRATCH][0];
+    const uint16_t* variance = (const uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0];
+    float4* const geometry = (float4*)ctx->planes[NEB_PLANE_GEOMETRY][0];
+    {
+        ScopedRange range("SVGF: Temporal Accumulation + A-Trous compute 0 (step 1)"); // SVGFDenoiser.cpp:69,155
+        profile_mark(ctx, 0, stream);
+        hipError_t e = launch_atrous_fused_temporal(launch, L == 1, rad_cur, rad_hist, (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][c],
+                                                    (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][h], (const uint2*)ctx->planes[NEB_PLANE_NORMAL][c],
+                                                    (const uint2*)ctx->planes[NEB_PLANE_NORMAL][h], (const uint32_t*)ctx->planes[NEB_PLANE_MOMENTS][h],
+                                                    (uint32_t*)ctx->planes[NEB_PLANE_MOMENTS][c], (uint16_t*)ctx->planes[NEB_PLANE_VARIANCE][0], geometry,
+                                                    scratch, stream);
+        if (e != hipSuccess)
+            return fail(ctx, NEB_ERR_HIP, "svgf fused temporal + a-trous launch", e);
+        geometry_mark(ctx, 0, ctx->H);
+    }
+    ScopedRange range("SVGF: A-Trous Wavelet"); // SVGFDenoiser.cpp:136
+    const float4* src = scratch;
+    for (uint32_t i = 1; i < L; ++i) {
+        const bool last = i + 1 == L;
+        float4* dst = last ? rad_cur : (src == scratch ? rad_hist : scratch);
+        char range_name[64];
+        snprintf(range_name, sizeof(range_name), "SVGF: A-Trous compute %u (step %u)", i, 1u << i); // SVGFDenoiser.cpp:155
+        ScopedRange level_range(range_name);
+        profile_mark(ctx, i, stream);
+        hipError_t e = launch_atrous_lum(launch, 1u << i, last, src, dst, variance, geometry, stream);
+        if (e != hipSuccess)
+            return fail(ctx, NEB_ERR_HIP, "svgf_atrous launch", e);
+        src = dst;
+    }
+    profile_mark(ctx, L, stream);
+    if (L == 1) {
+        const size_t bytes = (size_t)ctx->W * ctx->H * 16;
+        NEB_HIP(ctx, hipMemcpyAsync(rad_cur, scratch, bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    return NEB_OK;
+}

@@ -780,6 +780,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
 {
     if (!ctx || !c)
         return ctx ? gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: null constants") : NEB_ERR_INVALID_ARG;
+    if (int rc = neb::svgf_flush_pending(ctx)) // (a held-back temporal pass reads / writes the planes this call touches)
+        return rc;
     GiState* g = ctx->gi;
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
@@ -957,6 +959,8 @@ int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
+    if (int rc = neb::svgf_flush_pending(ctx))
+        return rc;
     GiState* g = ctx->gi;
     if (!g || !g->d_records || !g->defer_resolve)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
@@ -976,6 +980,8 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
 {
     if (!ctx || !c)
         return ctx ? gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_pbr_direct: null constants") : NEB_ERR_INVALID_ARG;
+    if (int rc = neb::svgf_flush_pending(ctx)) // (a held-back temporal pass reads / writes the planes this call touches)
+        return rc;
     GiState* g = ctx->gi;
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_pbr_direct: scene/BVH not ready (neb_gi_set_scene + neb_gi_build_bvh)");
@@ -1016,6 +1022,8 @@ int neb_tonemap(neb_ctx* ctx, neb_stream stream)
 {
     if (!ctx)
         return NEB_ERR_INVALID_ARG;
+    if (int rc = neb::svgf_flush_pending(ctx))
+        return rc;
     GI_GUARD(ctx);
     const size_t n = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
     hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1087,6 +1095,8 @@ int neb_gbuffer_raycast(neb_ctx* ctx, const neb_camera* cam, neb_stream stream)
 {
     if (!ctx || !cam)
         return NEB_ERR_INVALID_ARG;
+    if (int rc = neb::svgf_flush_pending(ctx))
+        return rc;
     GiState* g = ctx->gi;
     if (!g || !g->built)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gbuffer_raycast: scene/BVH not ready");

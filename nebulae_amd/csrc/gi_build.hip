@@ -606,10 +606,19 @@ __global__ void collapse_emit_kernel(CollapseArgs a)
         a.level_state[0] = a.inner_scan[k] + a.inner_count[k];
 }
 
-// The 64-byte copy of the wide nodes that any-hit rays walk (Bvh4NodeQ, gi_internal.h): per node and axis, origin =
-// the lower corner of the used children, scale = extent / 255 nudged up until 255 steps reach the upper corner; every
-// child plane is rounded away from the child (floor for lower planes, ceil for upper ones) and then checked in the
-// decoder's own arithmetic, fmaf(q, scale, origin), so the decoded box is never inside the exact one.
+// The 64-byte copy of the wide nodes that every ray walks (Bvh4NodeQ, gi_internal.h): per node and axis, origin = the
+// lower corner of the used children moved out by a pad of 2^-20 of the node's largest coordinate (16 ulps), scale =
+// padded extent / 255 nudged up until 255 steps reach the padded upper corner; every child plane is rounded away from
+// the child (floor for lower planes, ceil for upper ones) and then checked in the reference decoding fmaf(q, scale,
+// origin) with STRICT inequalities, so every decoded plane lies strictly outside the exact one -- by at least the pad
+// at the node's own faces (q = 0 / 255), by a rounding step of the coordinate elsewhere.  What that proves: the decoded
+// box contains the exact box in fmaf(q, scale, origin) arithmetic, with margin.  The traversal does NOT evaluate that
+// expression: it folds the ray in, t = fmaf(q, scale * inv, fmaf(origin, inv, -o * inv)) (gi_device.h), three more
+// roundings of about 2^-24 of max(|node coordinate|, |ray origin coordinate|) each.  The pad covers them for rays that
+// start within the scene's own coordinate range (every ray of this path does: origins are G-buffer positions and hit
+// points); like any two fp32 slab tests -- the 128-byte walk against the oracle's, say -- this one and an exact walk can
+// still disagree on a ray that grazes a box face at the rounding level, which is also where the triangle test itself is
+// decided by an ulp.
 __global__ void quantise_nodes_kernel(const Bvh4Node* __restrict__ nodes, uint32_t n, Bvh4NodeQ* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -629,6 +638,11 @@ __global__ void quantise_nodes_kernel(const Bvh4Node* __restrict__ nodes, uint32
             }
         if (!(mn <= mx))
             mn = mx = 0.0f; // (a node without children does not occur; keep the record finite)
+        {
+            const float pad = fmaxf(fmaxf(fabsf(mn), fabsf(mx)), mx - mn) * 0x1p-20f;
+            mn -= pad;
+            mx += pad;
+        }
         // scale: 255 steps must reach the upper corner in the decoder's arithmetic.  (mx - mn) and the division round by
         // 2^-24 each, so a 2^-21 margin makes 255 * sc >= mx - mn exactly, and fmaf rounds monotonically: no search
         // (the loop is a bounded safeguard -- a node at 1e4 with an extent of 1e-4 must not spin here)
@@ -642,10 +656,10 @@ __global__ void quantise_nodes_kernel(const Bvh4Node* __restrict__ nodes, uint32
             uint32_t l = 255u, h = 0u; // unused: inverted
             if (lo[ax][q] <= hi[ax][q]) {
                 l = (uint32_t)fminf(floorf((lo[ax][q] - mn) / sc), 255.0f);
-                while (l > 0u && fmaf((float)l, sc, mn) > lo[ax][q])
+                while (l > 0u && fmaf((float)l, sc, mn) >= lo[ax][q]) // strictly outside (l == 0 decodes to the padded corner)
                     --l;
                 h = (uint32_t)fminf(ceilf((hi[ax][q] - mn) / sc), 255.0f);
-                while (h < 255u && fmaf((float)h, sc, mn) < hi[ax][q])
+                while (h < 255u && fmaf((float)h, sc, mn) <= hi[ax][q])
                     ++h;
             }
             qlo[ax] |= l << (8 * q);

@@ -63,9 +63,11 @@ struct Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 128 && offsetof(Bvh4Node, hix) == offsetof(Bvh4Node, lox) + 64, "node layout");
 // The same tree in 64 bytes per node, for the rays that only ask "is anything in the way" (any-hit: sun visibility).
-// The child boxes are 8-bit offsets from the node's own lower corner in units of scale = extent / 255, rounded OUTWARDS:
-// a decoded box contains the exact one, so such a ray can only visit more nodes, never fewer -- and the triangle tests
-// behind them are the exact ones, so the answer is the same bit.  Child c of axis a: byte c of qlo[a] / qhi[a]; an unused
+// The child boxes are 8-bit offsets from the node's own (padded) lower corner in units of scale = extent / 255, rounded
+// OUTWARDS with margin (quantise_nodes_kernel, gi_build.hip, says exactly what is proven): a decoded box contains the exact
+// one, so a ray visits the nodes an exact walk would plus possibly more, and the triangle tests behind them are the exact
+// ones -- up to rays that graze a box face at the rounding level of the folded slab arithmetic, where any two fp32
+// traversals may differ.  Child c of axis a: byte c of qlo[a] / qhi[a]; an unused
 // slot is the inverted box 255 / 0 (scale > 0 always).  Four 16-byte loads per node visit instead of seven, and half
 // the cache footprint: the traversal passes are bound by the texture-address unit.
 struct Bvh4NodeQ {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/nebulae_hip.h"
 
@@ -64,9 +65,21 @@ hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* r
                            const uint32_t* depth_hist, const uint2* normal_cur, const uint2* normal_hist,
                            const uint32_t* mom_hist, uint32_t* mom_cur, uint16_t* variance, float4* geometry, hipStream_t s);
 
-// `geometry`: {decoded shading normal.xyz, depth} per pixel (NEB_PLANE_GEOMETRY), valid for every tap row
+// `geometry`: {decoded shading normal.xyz, depth} per pixel (NEB_PLANE_GEOMETRY), valid for every tap row.
+// variant 0 = direct-load kernel, 1 = LDS row-lattice kernel (steps <= 32; wider steps take the direct kernel)
 hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
                          const uint16_t* variance, const float4* geometry, hipStream_t s);
+// true when launch_atrous(L, variant, step, ...) runs the LDS kernel (what the whole-frame fast path below requires of every level)
+bool atrous_lds_serves(const SvgfLaunch& L, int variant, uint32_t step);
+// Whole-frame denoise, levels after the first: src holds {r, g, b, lum} (written by the level before); dst gets {r, g, b, lum},
+// or -- last -- {r, g, b, alpha} with the alpha dst itself holds (radiance[cur] = the frame's input until that store)
+hipError_t launch_atrous_lum(const SvgfLaunch& L, uint32_t step, bool last, const float4* src, float4* dst, const uint16_t* variance,
+                             const float4* geometry, hipStream_t s);
+// Whole-frame denoise, level 0 with the temporal pass as its staging phase: reads the frame's planes, writes moments[cur],
+// variance, the geometry plane and the filtered level-0 radiance ({r, g, b, lum}; {r, g, b, alpha} when it is the only level) to dst
+hipError_t launch_atrous_fused_temporal(const SvgfLaunch& L, bool only_level, const float4* rad_cur, const float4* rad_hist, const uint32_t* depth_cur,
+                                        const uint32_t* depth_hist, const uint2* normal_cur, const uint2* normal_hist, const uint32_t* mom_hist,
+                                        uint32_t* mom_cur, uint16_t* variance, float4* geometry, float4* dst, hipStream_t s);
 // decodes depth / normal rows [row0, row1) (all W columns) into the geometry plane
 hipError_t launch_decode_geometry(uint32_t W, uint32_t row_begin, uint32_t row0, uint32_t row1, const uint32_t* depth, const uint2* normal,
                                   float4* geometry, hipStream_t s);
@@ -75,6 +88,11 @@ hipError_t launch_decode_geometry(uint32_t W, uint32_t row_begin, uint32_t row0,
 size_t ray_sort_scratch_bytes(size_t n);
 hipError_t ray_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t* vals_out, size_t n, int bits,
                           void* scratch, hipStream_t stream);
+
+// A neb_svgf_temporal call on a whole-frame context is held back until the neb_svgf_atrous call that normally follows it
+// (they then run as one fused chain); every other entry point that reads, writes or orders work on the planes calls this
+// first, which submits the held-back pass on its own (the stand-alone kernel) -- NEB_OK or the failing status.
+int svgf_flush_pending(neb_ctx* ctx);
 
 struct GiState;               // gi.hip / gi_build.hip: scene tables, BVH, counters
 void gi_destroy(GiState* g);
@@ -97,6 +115,12 @@ struct neb_ctx {
     uint32_t geom_lo = 0, geom_hi = 0; // image rows [geom_lo, geom_hi) of the geometry plane hold this frame's decoded normal / depth
     neb_svgf_params params{};
     int atrous_variant = 1; // 0 = direct-load kernel, 1 = LDS row-lattice kernel
+    int fuse = 1;           // option svgf_fuse: run temporal + a-trous of a whole frame as the fused chain (0: always the separate kernels)
+    bool pending_temporal = false; // a neb_svgf_temporal held back for the fused chain
+    hipStream_t pending_stream = nullptr;
+    int profile = 0;                   // option svgf_profile: neb_svgf_atrous brackets its kernels with events (neb_svgf_level_times)
+    std::vector<hipEvent_t> prof_events; // levels + 1 of them once profiling has run
+    uint32_t prof_recorded = 0;
     neb::GiState* gi = nullptr;
     std::string last_error;
 };

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -42,13 +43,23 @@ std::once_flag g_rccl_once;
 void load_rccl()
 {
     void* h = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    std::string tried;
+    // NEB_RCCL_LIBRARY names the library to open instead (a site's own RCCL build; the tests use it to reach the not-found path)
+    const char* override_name = getenv("NEB_RCCL_LIBRARY");
+    const char* defaults[] = {"librccl.so.1", "librccl.so"};
+    for (const char* name : defaults) {
+        if (override_name)
+            name = override_name;
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h)
             break;
+        const char* e = dlerror(); // (read once: the call clears the message)
+        tried += std::string(tried.empty() ? "" : "; ") + (e ? e : name);
+        if (override_name)
+            break;
     }
     if (!h) {
-        g_rccl.why = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + ")";
+        g_rccl.why = "librccl not found (" + tried + ")";
         return;
     }
     auto sym = [&](const char* n) {
@@ -125,12 +136,29 @@ int neb_strips_comm_create(int device, int n_ranks, int rank, const void* id128,
         return strip_fail(nullptr, NEB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
     RcclUniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
-    RcclComm comm = nullptr;
-    const int rc = r.CommInitRank(&comm, n_ranks, id, rank);
+    // RCCL writes the handle straight into the caller's variable: inside neb_strips_group_begin / _end it may do so only when the group closes
+    const int rc = r.CommInitRank(reinterpret_cast<RcclComm*>(out_comm), n_ranks, id, rank);
     if (rc != kRcclSuccess)
         return rccl_fail(nullptr, "ncclCommInitRank", rc);
-    *out_comm = comm;
     return NEB_OK;
+}
+
+int neb_strips_group_begin(void)
+{
+    const RcclApi& r = rccl();
+    if (!r.ok)
+        return strip_fail(nullptr, NEB_ERR_STATE, "neb_strips_group_begin: " + r.why);
+    const int rc = r.GroupStart();
+    return rc == kRcclSuccess ? NEB_OK : rccl_fail(nullptr, "ncclGroupStart", rc);
+}
+
+int neb_strips_group_end(void)
+{
+    const RcclApi& r = rccl();
+    if (!r.ok)
+        return strip_fail(nullptr, NEB_ERR_STATE, "neb_strips_group_end: " + r.why);
+    const int rc = r.GroupEnd();
+    return rc == kRcclSuccess ? NEB_OK : rccl_fail(nullptr, "ncclGroupEnd", rc);
 }
 
 int neb_strips_comm_destroy(void* comm)
@@ -175,11 +203,16 @@ int neb_strips_exchange(neb_ctx* ctx, void* comm, const neb_halo_plane* planes, 
             s.recv_row0 < ctx->row_begin || s.recv_row1 > ctx->row_end || s.peer < 0)
             return strip_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_strips_exchange: rows not resident in this context");
     }
+    if (int frc = neb::svgf_flush_pending(ctx))
+        return frc;
     neb::DeviceGuard guard(ctx->device);
     if (guard.err != hipSuccess)
         return strip_fail(ctx, NEB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
     neb::ScopedRange range("Strips: halo exchange (RCCL)");
-    int rc = r.GroupStart();
+    for (uint32_t p = 0; p < n_planes; ++p) // rows of normal[cur] / depth[cur] are about to change: their decoded copy is stale
+        if (planes[p].plane == NEB_PLANE_NORMAL || planes[p].plane == NEB_PLANE_DEPTH)
+            ctx->geom_lo = ctx->geom_hi = 0;
+    int rc = r.GroupStart(); // (nests inside a caller's neb_strips_group_begin / _end: RCCL merges nested groups)
     if (rc != kRcclSuccess)
         return rccl_fail(ctx, "ncclGroupStart", rc);
     int first_bad = kRcclSuccess;

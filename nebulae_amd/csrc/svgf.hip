@@ -1,14 +1,15 @@
 // svgf.hip -- SVGF temporal accumulation and edge-stopping a-trous wavelet for gfx950.
 //
 // Reference arithmetic (paths relative to the reference checkout):
-//   assets/shaders/svgf_temporal.hlsl:24-68  -> svgf_temporal_kernel
+//   assets/shaders/svgf_temporal.hlsl:24-68  -> svgf_temporal_kernel, and the staging phase of the fused level-0 kernel
 //   assets/shaders/svgf_atrous.hlsl:29-85    -> svgf_atrous_direct_kernel / svgf_atrous_lds_kernel
 // This is not a transliteration of the 8x8-threadgroup texture-fetch shaders: the temporal
 // pass is a coalesced stream (one pixel per lane, 16-B radiance accesses); the a-trous pass
 // is tiled on the row lattice {r + step*j} so that a workgroup's taps are whole, contiguous
 // image-row segments whatever the step, staged once into LDS with depth and normals already
 // decoded, and each lane filters a column of R lattice rows so every staged texel is
-// read from LDS once per R outputs.  See DESIGN.md "Kernels".
+// read from LDS once per R outputs.  A whole frame's denoise (neb_svgf_temporal followed by neb_svgf_atrous) runs
+// the temporal pass INSIDE the staging phase of level 0 and never writes the accumulated radiance.  See DESIGN.md "Kernels".
 #pragma clang fp contract(off) // fused operations are explicit fmaf: see neb_device.h
 
 #include <algorithm>
@@ -16,6 +17,44 @@
 
 #include "neb_device.h"
 #include "neb_internal.h"
+
+// Tuning / diagnostic switches (tools/build_variant.sh): the product is built with none of them set.
+#ifndef NEB_ATROUS_NOTRANS // timing only (wrong results): v_log / v_exp replaced by full-rate instructions
+#define NEB_ATROUS_NOTRANS 0
+#endif
+#ifndef NEB_ATROUS_PRIO // 0: no s_setprio; 1: a workgroup's priority = the tiles it still has to do (default)
+#define NEB_ATROUS_PRIO 1
+#endif
+#ifndef NEB_ATROUS_R_NARROW // rows per lane of the LDS kernel at steps <= 4: 4; 3 = A/B arm (4 workgroups per CU: measured the same, 34.5 against 34.1 us)
+#define NEB_ATROUS_R_NARROW 4
+#endif
+#ifndef NEB_ATROUS_STORE // how the LDS kernel stores its output: 1 write-through (sc1, default), 0 plain, 2 non-temporal (A/B arms)
+#define NEB_ATROUS_STORE 1
+#endif
+#ifndef NEB_ATROUS_STAMPS // diagnostic builds only (tools/atrous_stamps.py): per-wave phase times from s_memtime
+#define NEB_ATROUS_STAMPS 0
+#endif
+#if NEB_ATROUS_NOTRANS
+#define NEB_TAP_LOG2(x) ((x) - 1.0f)
+#define NEB_TAP_EXP2(x) fmaf((x), 0.001f, 1.0f)
+#else
+#define NEB_TAP_LOG2(x) fast_log2(x)
+#define NEB_TAP_EXP2(x) fast_exp2(x)
+#endif
+#if NEB_ATROUS_STAMPS
+#define NEB_STAMP(i)                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        const uint64_t tn_ = __builtin_amdgcn_s_memtime();  \
+        st[i] += tn_ - tprev;                               \
+        tprev = tn_;                                        \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+#else
+#define NEB_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
 
 namespace neb {
 
@@ -37,6 +76,47 @@ struct TemporalArgs {
     float neg_inv_two_sigma2_log2e, alpha, varianceEps;
 };
 
+// The temporal pass's arithmetic, shared word for word by svgf_temporal_kernel and by the staging phase of the fused
+// level-0 a-trous kernel (so a frame denoised through either gives the same bits).
+// lerp parameter of svgf_temporal.hlsl:44-51; also returns the decoded shading normal and depth of the current frame
+__device__ __forceinline__ float temporal_blend(uint32_t dc, uint32_t dh, uint32_t nc, uint32_t nh, float neg_inv_two_sigma2_log2e, float alpha_param,
+                                                float3& Nc, float& zc)
+{
+    Nc = oct16_unpack_zw(nc);
+    const float3 Nh = oct16_unpack_zw(nh);
+    zc = depth_unorm24(dc);
+    const float dz = fabsf(zc - depth_unorm24(dh));
+    // SVGF_DWeight: exp(-dz^2 / (2 sigma^2))   (svgf_common.hlsli:11-15)
+    const float wDepth = fast_exp2(dz * dz * neg_inv_two_sigma2_log2e);
+    // SVGF_NWeight: saturate(dot)               (svgf_common.hlsli:4-7)
+    const float wNormal = __saturatef(fmaf(Nc.z, Nh.z, fmaf(Nc.y, Nh.y, Nc.x * Nh.x)));
+    const float w = wDepth * wNormal;
+    return fmaf(w, alpha_param - 1.0f, 1.0f); // lerp(1, alpha, w)  (:51)
+}
+
+// Caccum = lerp(Ccurr, Chist, alpha)  (:55); alpha channel carried from the current frame
+__device__ __forceinline__ float4 temporal_accumulate(float4 Cc, float4 Ch, float alpha)
+{
+    float4 out;
+    out.x = fmaf(alpha, Ch.x - Cc.x, Cc.x);
+    out.y = fmaf(alpha, Ch.y - Cc.y, Cc.y);
+    out.z = fmaf(alpha, Ch.z - Cc.z, Cc.z);
+    out.w = Cc.w;
+    return out;
+}
+
+// moments and variance (:57-67), as the typed R16G16_FLOAT / R16_FLOAT stores leave them: {moments bits, variance bits}
+__device__ __forceinline__ uint2 temporal_moments(float4 Cc, uint32_t mh, float alpha, float varianceEps)
+{
+    const float Y = luminance(Cc.x, Cc.y, Cc.z);
+    const float Mh0 = half_bits_to_float(mh & 0xffffu), Mh1 = half_bits_to_float(mh >> 16);
+    const float M1 = fmaf(alpha, Mh0 - Y, Y);
+    const float Y2 = Y * Y;
+    const float M2 = fmaf(alpha, Mh1 - Y2, Y2);
+    const float var = fmaxf(fmaf(-M1, M1, M2), varianceEps);
+    return make_uint2(float_to_half_bits(M1) | (float_to_half_bits(M2) << 16), float_to_half_bits(var));
+}
+
 __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
 {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
@@ -52,34 +132,15 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     const uint32_t nc = a.normal_cur[i].y, nh = a.normal_hist[i].y; // .zw = shading normal
     const uint32_t mh = a.mom_hist[i];
 
-    const float3 Nc = oct16_unpack_zw(nc);
-    const float3 Nh = oct16_unpack_zw(nh);
-    const float zc = depth_unorm24(dc);
+    float3 Nc;
+    float zc;
+    const float alpha = temporal_blend(dc, dh, nc, nh, a.neg_inv_two_sigma2_log2e, a.alpha, Nc, zc);
     if (a.geometry) // decoded once here instead of once per a-trous level and staged texel
         a.geometry[i] = make_float4(Nc.x, Nc.y, Nc.z, zc);
-    const float dz = fabsf(zc - depth_unorm24(dh));
-    // SVGF_DWeight: exp(-dz^2 / (2 sigma^2))   (svgf_common.hlsli:11-15)
-    const float wDepth = fast_exp2(dz * dz * a.neg_inv_two_sigma2_log2e);
-    // SVGF_NWeight: saturate(dot)               (svgf_common.hlsli:4-7)
-    const float wNormal = __saturatef(fmaf(Nc.z, Nh.z, fmaf(Nc.y, Nh.y, Nc.x * Nh.x)));
-    const float w = wDepth * wNormal;
-    const float alpha = fmaf(w, a.alpha - 1.0f, 1.0f); // lerp(1, alpha, w)  (:51)
-
-    const float Y = luminance(Cc.x, Cc.y, Cc.z);
-    const float Mh0 = half_bits_to_float(mh & 0xffffu), Mh1 = half_bits_to_float(mh >> 16);
-    const float M1 = fmaf(alpha, Mh0 - Y, Y);
-    const float Y2 = Y * Y;
-    const float M2 = fmaf(alpha, Mh1 - Y2, Y2);
-    const float var = fmaxf(fmaf(-M1, M1, M2), a.varianceEps);
-
-    float4 out;
-    out.x = fmaf(alpha, Ch.x - Cc.x, Cc.x);
-    out.y = fmaf(alpha, Ch.y - Cc.y, Cc.y);
-    out.z = fmaf(alpha, Ch.z - Cc.z, Cc.z);
-    out.w = Cc.w;
-    a.rad_cur[i] = out;
-    a.mom_cur[i] = float_to_half_bits(M1) | (float_to_half_bits(M2) << 16);
-    a.variance[i] = (uint16_t)float_to_half_bits(var);
+    const uint2 mv = temporal_moments(Cc, mh, alpha, a.varianceEps);
+    a.rad_cur[i] = temporal_accumulate(Cc, Ch, alpha);
+    a.mom_cur[i] = mv.x;
+    a.variance[i] = (uint16_t)mv.y;
 }
 
 hipError_t launch_temporal(const SvgfLaunch& L, float4* rad_cur, const float4* rad_hist, const uint32_t* depth_cur,
@@ -145,6 +206,7 @@ struct AtrousArgs {
     float4* dst;
     const uint16_t* variance;
     const float4* geometry;     // {decoded shading normal.xyz, depth}: NEB_PLANE_GEOMETRY
+    const float4* alpha_src;    // kInLum with OUT_ALPHA: the plane whose centre .w the output carries (the destination itself)
     int W, H, Wd;               // image size and floor-dispatched width
     int row_begin, row_end;     // resident image rows [row_begin, row_end)
     int row0, row1;             // image rows to write (row1 already clipped to (H/8)*8)
@@ -153,16 +215,25 @@ struct AtrousArgs {
     uint32_t nblocks;           // real block count (grid is padded to a multiple of 8)
     float cz;                   // log2e / (phiDepth * step)
     float phiColor, phiNormal;
+    // kInFused only: the temporal pass's own planes (src = radiance[cur] as rendered) and constants
+    const float4* rad_hist;
+    const uint32_t* depth_cur;
+    const uint32_t* depth_hist;
+    const uint2* normal_cur;
+    const uint2* normal_hist;
+    const uint32_t* mom_hist;
+    uint32_t* mom_cur;
+    uint16_t* variance_out;
+    float4* geometry_out;
+    float t_neg_inv_two_sigma2_log2e, t_alpha, t_varianceEps;
+#if NEB_ATROUS_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
-// K[abs(d)] with K = {1/16, 1/4, 3/8, 1/4, 1/16}: centre 1/16, +-1 -> 1/4, +-2 -> 3/8
-// (svgf_atrous.hlsl:35,54,60 -- reproduced as written).
-__host__ __device__ constexpr float atrous_k(int d)
-{
-    return (d < 0 ? -d : d) == 0 ? 0.0625f : ((d < 0 ? -d : d) == 1 ? 0.25f : 0.375f);
-}
-
-// log2(K[abs(dx)] * K[abs(dy)]): the kernel weight folded into the exponent of the edge-stopping exp2
+// log2(K[abs(dx)] * K[abs(dy)]) with K = {1/16, 1/4, 3/8, 1/4, 1/16} indexed by abs(d): centre 1/16, +-1 -> 1/4, +-2 -> 3/8
+// (svgf_atrous.hlsl:35,54,60 -- reproduced as written): the kernel weight is folded into the exponent
+// of the edge-stopping exp2.
 __host__ __device__ constexpr float atrous_log2k(int dx, int dy)
 {
     // log2(1/16) = -4, log2(1/4) = -2, log2(3/8) = log2(3) - 3
@@ -174,7 +245,7 @@ __host__ __device__ constexpr float atrous_log2k(int dx, int dy)
 // max(0, dot(n0, n)) of svgf_atrous.hlsl:74, saturated: the [0, 1] clamp is the free output modifier of the dot
 // product's last fma (a bare max(x, 0) is a separate v_max per tap).  Two unit normals can give 1 + 2 ulp, where the
 // reference's pow(d, 128) would be 1 + 3e-5 and this is 1 -- a deliberate divergence, the same in both
-// kernels so that every variant and every level is one function.
+// kernels so that every path and every level is one function.
 __device__ __forceinline__ float normal_dot_sat(float d) { return fminf(fmaxf(d, 0.0f), 1.0f); }
 
 __device__ __forceinline__ float lum_scale(float var_f, float phiColor)
@@ -183,8 +254,37 @@ __device__ __forceinline__ float lum_scale(float var_f, float phiColor)
     return kLog2e * fast_rcp(fmaxf(varScale, 1e-6f));                  // :75 (as log2e / denom)
 }
 
-// Variant 0: one pixel per lane, 25 taps straight from global memory (L1/L2 absorb the reuse).
-// Used for steps too wide for the LDS tile and as the in-library A/B arm.
+// One tap (svgf_atrous.hlsl:67-81): w = Kx*Ky * exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) as ONE
+// exp2: exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d == 0 -> -inf -> weight 0)
+__device__ __forceinline__ float tap_weight(float n0x, float n0y, float n0z, float z0, float lum0, float cl, float4 tA, float4 tB, float phiN, float cz,
+                                            float lk)
+{
+    const float d = normal_dot_sat(fmaf(n0z, tB.z, fmaf(n0y, tB.y, n0x * tB.x)));
+    float e = fmaf(phiN, NEB_TAP_LOG2(d), lk);
+    e = fmaf(-fabsf(z0 - tB.w), cz, e);
+    e = fmaf(-fabsf(lum0 - tA.w), cl, e);
+    return NEB_TAP_EXP2(e);
+}
+
+// The a-trous output store.  A plain store leaves its line dirty in the XCD's L2, and what is dirty when the kernel ends is
+// written back before the next kernel starts (MI355X_MICROARCH.md, "boundary"); written through (sc1) the 33 MB of a level
+// leave beside the arithmetic: 32.4-33.5 us per level against 34.4 (non-temporal stores: 34.5).
+typedef float neb_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_output(float4* p, float4 v)
+{
+#if NEB_ATROUS_STORE == 1
+    const neb_f4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+#elif NEB_ATROUS_STORE == 2
+    const neb_f4 d = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(d, reinterpret_cast<neb_f4*>(p));
+#else
+    *p = v;
+#endif
+}
+
+// Direct kernel: one pixel per lane, 25 taps straight from global memory (L1/L2 absorb the reuse).
+// Used for steps too wide for the LDS tile (>= 64) and as the in-library A/B arm (option atrous_variant = 0).
 __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -196,8 +296,6 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
     const float lum0 = luminance(c0.x, c0.y, c0.z);
     const float cl = lum_scale(half_bits_to_float(a.variance[i]), a.phiColor);
     const float4 g0 = a.geometry[i];
-    const float z0 = g0.w;
-    const float3 n0 = make_float3(g0.x, g0.y, g0.z);
     float sr = 0.f, sg = 0.f, sb = 0.f, sw = 0.f;
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
@@ -208,14 +306,8 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
             const int qx = min(max(x + dx * a.step, 0), a.W - 1);
             const float4 c = a.src[rowoff + qx];
             const float4 g = a.geometry[rowoff + qx];
-            const float z = g.w;
-            const float3 n = make_float3(g.x, g.y, g.z);
-            const float lum = luminance(c.x, c.y, c.z);
-            const float d = normal_dot_sat(fmaf(n0.z, n.z, fmaf(n0.y, n.y, n0.x * n.x)));
-            float e = fmaf(a.phiNormal, fast_log2(d), atrous_log2k(dx, dy));
-            e = fmaf(-fabsf(z0 - z), a.cz, e);
-            e = fmaf(-fabsf(lum0 - lum), cl, e);
-            const float w = fast_exp2(e);
+            const float w = tap_weight(g0.x, g0.y, g0.z, g0.w, lum0, cl, make_float4(c.x, c.y, c.z, luminance(c.x, c.y, c.z)), g, a.phiNormal, a.cz,
+                                       atrous_log2k(dx, dy));
             sr = fmaf(w, c.x, sr);
             sg = fmaf(w, c.y, sg);
             sb = fmaf(w, c.z, sb);
@@ -226,37 +318,62 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
     a.dst[i] = make_float4(sr * inv, sg * inv, sb * inv, c0.w);
 }
 
-// Variant 1: LDS row-lattice tile, persistent workgroups with register prefetch.
+// LDS kernel: row-lattice tiles, persistent workgroups.
 //   Workgroup = 256 lanes = 4 waves.  Output tile = BW (64) consecutive columns x BH (= 4R)
 //   rows of the lattice {r + S*j}.  Taps of a lattice row are lattice rows j-2..j+2, so the
 //   tile needs only BH+4 image rows (each a contiguous, coalesced segment of BW+4S texels)
 //   for any step S: read amplification (1 + 4/BH)(1 + 4S/BW) instead of (1 + 4S/T)^2.
-//   Staging reads the radiance and the frame's decoded geometry plane {n.xyz, z} (written once by the temporal pass) and
-//   keeps {r,g,b,z} and {nx,ny,nz,lum} as two float4 LDS planes (ds_read_b128, lane-contiguous,
-//   conflict-free).  Wave w filters lattice rows [w*R, w*R+R): a lane walks its column's R+4
-//   staged rows once and feeds each staged texel to every output row it is a tap of.
-//   Each workgroup walks several tiles: the global loads of the NEXT tile are issued into
-//   registers before the current tile is filtered, so their latency hides under ~1.6k VALU
-//   instructions per wave instead of stalling an empty SIMD (the first version spent 36 % of
-//   wave time in s_waitcnt).
-template <int S, int R>
+//   Two float4 LDS planes, lane-contiguous (ds_read_b128, conflict-free): A = {r, g, b, lum} and B = {nx, ny, nz, z}
+//   (= the texels of the frame's decoded geometry plane).  Wave w filters lattice rows [w*R, w*R+R): a lane walks its
+//   column's R+4 staged rows once and feeds each staged texel to every output row it is a tap of.
+//
+//   How a tile's texels reach LDS -- template parameter IN:
+//   kInClassic  the source plane holds {r, g, b, alpha} (any radiance plane of the ABI).  The radiance of the NEXT tile is
+//               loaded into registers while the current tile is filtered (its latency hides under ~1.6k VALU
+//               instructions per wave); staging adds the luminance and writes A; B comes by LDS-DMA
+//               (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform base + lane * 16 B = exactly
+//               the staging order; no registers, no VALU).
+//   kInLum      the source plane holds {r, g, b, lum}: an intermediate plane of a whole-frame denoise, written by the level
+//               before with OUT_ALPHA = false.  Both planes are verbatim copies: two LDS-DMAs per staged texel, no staging
+//               arithmetic and no staging registers at all.
+//   kInFused    level 0 of a whole-frame denoise (S = 1): src = radiance[cur] as rendered.  Staging IS the temporal pass
+//               (svgf_temporal.hlsl:24-68): cur / history radiance arrive by LDS-DMA in the slots of A / B, depth and normals of
+//               both frames in registers; every staged texel (halo included) is accumulated and decoded in place; the
+//               tile's own pixels also write moments, variance and the decoded geometry plane -- and the accumulated
+//               radiance is never written to memory (the filtered output is the next frame's history).
+//   OUT_ALPHA: the output's .w is the centre pixel's alpha (the ABI's radiance planes) -- false: lum(output), for a
+//   following kInLum level.  The alpha comes from src (kInClassic), from alpha_src = the destination itself (kInLum: the
+//   last level writes radiance[cur], which still holds the frame's input) or from the fused staging (kInFused).
+enum : int { kInClassic = 0, kInLum = 1, kInFused = 2 };
+
+template <int S, int R, int IN>
 struct AtrousTile {
     static constexpr int BW = 64, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4, TOTAL = ROWS * COLS;
     static constexpr int NLOAD = (TOTAL + 255) / 256;
+    // kInFused keeps {variance, alpha} of the tile's own pixels in a third, small plane
+    static constexpr int LDS_BYTES = TOTAL * 2 * 16 + (IN == kInFused ? BH * BW * 8 : 0);
     // workgroups per CU: what the 160 KB of LDS hold, at most 5 (R <= 2) / 3 -- also the register budget the kernel is compiled for
-    static constexpr int LDS_BYTES = TOTAL * 2 * 16;
-    static constexpr int PER_CU = (R <= 2 ? 5 : 3) < (160 * 1024) / LDS_BYTES ? (R <= 2 ? 5 : 3) : (160 * 1024) / LDS_BYTES;
+    static constexpr int PER_CU = (R <= 2 ? 5 : (R == 3 ? 4 : 3)) < (160 * 1024) / LDS_BYTES ? (R <= 2 ? 5 : (R == 3 ? 4 : 3)) : (160 * 1024) / LDS_BYTES;
 };
 
-template <int S, int R>
-__global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_lds_kernel(AtrousArgs a)
+template <int S, int R, int IN, bool OUT_ALPHA>
+__global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atrous_lds_kernel(AtrousArgs a)
 {
-    using T = AtrousTile<S, R>;
+    using T = AtrousTile<S, R, IN>;
     constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD;
+    static_assert(IN != kInFused || S == 1, "the fused temporal staging is level 0");
     extern __shared__ float4 lds[];
     float4* __restrict__ A = lds;               // {r, g, b, lum}
-    float4* __restrict__ B = lds + ROWS * COLS; // {nx, ny, nz, z}: the geometry plane's texels, copied by LDS-DMA
+    float4* __restrict__ B = lds + ROWS * COLS; // {nx, ny, nz, z}
+    float2* __restrict__ V = reinterpret_cast<float2*>(lds + 2 * ROWS * COLS); // kInFused: {variance as stored (fp16), alpha} [BH][BW]
 
+#if NEB_ATROUS_STAMPS
+    uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t t_begin_real = __builtin_amdgcn_s_memrealtime();
+    uint64_t tprev = __builtin_amdgcn_s_memtime();
+    const uint64_t t_begin = tprev;
+    uint32_t ntiles = 0;
+#endif
     const float4* __restrict__ src = a.src;
     const float4* __restrict__ geometry = a.geometry;
     const int lane = threadIdx.x & 63;
@@ -278,7 +395,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
     // plane's first element; the next interior tile puts the regular ones back.
     uint32_t toff[NLOAD];
     bool toff_regular = false;
-    float4 pc[NLOAD];
+    float4 pc[IN == kInClassic ? NLOAD : 1];
 
     struct Tile {
         int r, jbase, x0;
@@ -326,45 +443,45 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
             }
         }
     };
+    // kInClassic: the next tile's radiance, into registers
     auto issue_load = [&](int k, const Tile& o) {
-        if (threadIdx.x + 256 * k < TOTAL)
-            pc[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + o.first) + toff[k]);
+        if constexpr (IN == kInClassic) {
+            if (threadIdx.x + 256 * k < TOTAL)
+                pc[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + o.first) + toff[k]);
+        }
     };
-    // The geometry texels go global -> LDS directly (global_load_lds_dwordx4: per-lane source address, destination =
-    // wave-uniform base + lane * 16 B, which is exactly this staging order), no registers and no VALU.  Issued once the
-    // whole workgroup has finished reading the previous tile, and complete before the barrier that precedes the filter.
-    auto issue_geometry_dma = [&](const Tile& o) {
+    // a 16-byte plane's texels of the tile, global -> LDS directly.  Issued once the whole workgroup has finished reading
+    // the previous tile, and complete before the barrier that precedes the filter.
+    auto issue_dma = [&](const float4* plane, float4* dst_lds, const Tile& o) {
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             if (threadIdx.x + 256 * k < TOTAL) {
-                const char* g = reinterpret_cast<const char*>(geometry + o.first) + toff[k];
+                const char* g = reinterpret_cast<const char*>(plane + o.first) + toff[k];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(B + 256 * k + 64 * wv), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst_lds + 256 * k + 64 * wv), 16, 0, 0);
             }
         }
     };
-    auto issue_loads = [&](const Tile& o) {
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k)
-            issue_load(k, o);
-    };
 
-    // The centre pixel's variance and alpha (the only per-pixel inputs that are not staged) are fetched one tile ahead as
+    // The centre pixel's variance and alpha (the per-pixel inputs that are not staged) are fetched one tile ahead as
     // well: loaded at the start of the filter phase they were a dependent global round trip in front of every tile's
-    // arithmetic (2.5 us per level).
+    // arithmetic (2.5 us per level).  (kInFused has both in LDS.)
     uint32_t nvar[R];
     float nalpha[R];
     auto issue_centre_loads = [&](const Tile& o) {
-        const int xo = o.x0 + lane;
+        if constexpr (IN != kInFused) {
+            const int xo = o.x0 + lane;
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int yo = o.r + S * (o.jbase + wv * R + k);
-            nvar[k] = 0u;
-            nalpha[k] = 0.f;
-            if (xo < a.Wd && yo < a.row1) {
-                const size_t i = (size_t)(yo - a.row_begin) * a.W + xo;
-                nvar[k] = a.variance[i];
-                nalpha[k] = reinterpret_cast<const float*>(src)[4 * i + 3];
+            for (int k = 0; k < R; ++k) {
+                const int yo = o.r + S * (o.jbase + wv * R + k);
+                nvar[k] = 0u;
+                nalpha[k] = 0.f;
+                if (xo < a.Wd && yo < a.row1) {
+                    const size_t i = (size_t)(yo - a.row_begin) * a.W + xo;
+                    nvar[k] = a.variance[i];
+                    if constexpr (OUT_ALPHA)
+                        nalpha[k] = reinterpret_cast<const float*>(IN == kInClassic ? src : a.alpha_src)[4 * i + 3];
+                }
             }
         }
     };
@@ -376,28 +493,107 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
         t += wgs_per_xcd;
     if (have) {
         tile_offsets(nt);
-        issue_loads(nt);
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k)
+            issue_load(k, nt);
         issue_centre_loads(nt);
     }
 
+    // per-launch constants of the tap arithmetic as VGPR operands (in isolation an SGPR source costs a v_fma about 0.6 ns more
+    // than a third VGPR source does, tools/ubench_bank.hip: 1.83 against 1.25 ns per wave-instruction at three waves per SIMD;
+    // in this kernel the difference does not show: 192.5 against 192.0 us per frame)
+    float cz = a.cz, phiN = a.phiNormal;
+    asm volatile("" : "+v"(cz), "+v"(phiN));
+
+    NEB_STAMP(0);
     while (have) {
-        // ---- stage the tile: radiance (prefetched into registers during the previous tile) + its luminance -> plane A;
-        // geometry -> plane B by DMA (normal and depth arrive decoded: the temporal pass did that once per frame) ----
-        issue_geometry_dma(nt); // first: its flight overlaps the wait for the prefetched radiance and the luminance arithmetic
-        float lum[NLOAD];
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k)
-            lum[k] = luminance(pc[k].x, pc[k].y, pc[k].z);
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            if (i < TOTAL)
-                A[i] = make_float4(pc[k].x, pc[k].y, pc[k].z, lum[k]);
+#if NEB_ATROUS_PRIO
+        // The SIMD's arbiter serves its oldest wave first: of the three workgroups of a CU the first-dispatched one races
+        // ahead and the youngest is left to finish alone, one wave per SIMD, at half the issue rate.  Priority = tiles still
+        // to do lets the workgroups finish together.
+        {
+            const uint32_t remaining = (t_end - t + wgs_per_xcd - 1u) / wgs_per_xcd; // (this tile included)
+            if (remaining >= 3u)
+                __builtin_amdgcn_s_setprio(3);
+            else if (remaining == 2u)
+                __builtin_amdgcn_s_setprio(2);
+            else
+                __builtin_amdgcn_s_setprio(1);
         }
+#endif
+        const int cr = nt.r, cjbase = nt.jbase, cx0 = nt.x0;
+        // ---- stage the tile ----
+        if constexpr (IN == kInClassic) {
+            issue_dma(geometry, B, nt); // first: its flight overlaps the wait for the prefetched radiance and the luminance arithmetic
+            float lum[NLOAD];
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k)
+                lum[k] = luminance(pc[k].x, pc[k].y, pc[k].z);
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                const int i = threadIdx.x + 256 * k;
+                if (i < TOTAL)
+                    A[i] = make_float4(pc[k].x, pc[k].y, pc[k].z, lum[k]);
+            }
+        } else if constexpr (IN == kInLum) {
+            issue_dma(src, A, nt);
+            issue_dma(geometry, B, nt);
+        } else {
+            // temporal accumulation as the staging step: cur -> A's slots, history -> B's slots by DMA; depth and normals of
+            // both frames (and the moments history of the tile's own pixels) through registers; then every thread turns ITS
+            // texels (the ones its own wave's DMA wrote: no barrier needed, only the wave's own vmcnt) into {accumulated
+            // rgb, lum} and {decoded normal, depth} in place.
+            issue_dma(src, A, nt);
+            issue_dma(a.rad_hist, B, nt);
+            uint32_t dc[NLOAD], dh[NLOAD], nc[NLOAD], nh[NLOAD], mh[NLOAD];
+            bool own[NLOAD];
+            size_t gi[NLOAD];
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                const int i = threadIdx.x + 256 * k;
+                own[k] = false;
+                if (i < TOTAL) {
+                    const size_t e = nt.first + (toff[k] >> 4);
+                    gi[k] = e;
+                    dc[k] = a.depth_cur[e];
+                    dh[k] = a.depth_hist[e];
+                    nc[k] = a.normal_cur[e].y; // .zw = shading normal
+                    nh[k] = a.normal_hist[e].y;
+                    const int lr = i / COLS, lc = i - lr * COLS;
+                    const int x = cx0 + lc - 2 * S, y = cr + S * (cjbase + lr - 2);
+                    // one of the tile's own output pixels (never a clamped position: those lie outside the image)
+                    own[k] = lr >= 2 && lr < BH + 2 && lc >= 2 * S && lc < BW + 2 * S && x < a.Wd && y >= a.row0 && y < a.row1;
+                    mh[k] = own[k] ? a.mom_hist[e] : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                const int i = threadIdx.x + 256 * k;
+                if (i < TOTAL) {
+                    const float4 Cc = A[i], Ch = B[i];
+                    float3 Nc;
+                    float zc;
+                    const float alpha = temporal_blend(dc[k], dh[k], nc[k], nh[k], a.t_neg_inv_two_sigma2_log2e, a.t_alpha, Nc, zc);
+                    const float4 acc = temporal_accumulate(Cc, Ch, alpha);
+                    const float4 geo = make_float4(Nc.x, Nc.y, Nc.z, zc);
+                    A[i] = make_float4(acc.x, acc.y, acc.z, luminance(acc.x, acc.y, acc.z));
+                    B[i] = geo;
+                    if (own[k]) {
+                        const uint2 mv = temporal_moments(Cc, mh[k], alpha, a.t_varianceEps);
+                        a.mom_cur[gi[k]] = mv.x;
+                        a.variance_out[gi[k]] = (uint16_t)mv.y;
+                        a.geometry_out[gi[k]] = geo;
+                        const int lr = i / COLS, lc = i - lr * COLS;
+                        V[(lr - 2) * BW + (lc - 2 * S)] = make_float2(half_bits_to_float(mv.y), Cc.w); // (the variance as the levels read it back)
+                    }
+                }
+            }
+        }
+        NEB_STAMP(1);
         __syncthreads(); // (also waits for this wave's DMA: an LDS-DMA is a pending LDS write on the VM counter)
+        NEB_STAMP(2);
 
         // ---- next tile: issue its loads now, consume them after this tile is filtered ----
-        const int cr = nt.r, cjbase = nt.jbase, cx0 = nt.x0;
         uint32_t cvar[R];
         float calpha[R];
 #pragma unroll
@@ -420,6 +616,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
                 issue_load(k, nt);
         }
 
+        NEB_STAMP(3);
         // ---- filter the current tile ----
         const int xo = cx0 + lane;
         float z0[R], n0x[R], n0y[R], n0z[R], lum0[R], cl[R], alpha0[R];
@@ -437,33 +634,57 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
             lum0[k] = cA.w;
             const int yo = cr + S * (cjbase + wv * R + k);
             valid[k] = (xo < a.Wd) && (yo < a.row1);
-            alpha0[k] = calpha[k];
-            cl[k] = lum_scale(half_bits_to_float((uint16_t)cvar[k]), a.phiColor); // (an invalid pixel holds 0: never stored)
+            if constexpr (IN == kInFused) {
+                const float2 va = V[(wv * R + k) * BW + lane]; // (a pixel that is not valid holds stale values: never stored)
+                alpha0[k] = va.y;
+                cl[k] = lum_scale(va.x, a.phiColor);
+            } else {
+                alpha0[k] = calpha[k];
+                cl[k] = lum_scale(half_bits_to_float((uint16_t)cvar[k]), a.phiColor); // (an invalid pixel holds 0: never stored)
+            }
             sr[k] = sg[k] = sb[k] = sw[k] = 0.f;
         }
-        const float cz = a.cz, phiN = a.phiNormal;
+        // LDS reads software-pipelined by hand: a row's ten ds_read_b128 go out in two groups (dx = -2..0, dx = 1..2), each
+        // one group ahead of its taps, into the registers the group before last has just released -- left to itself the
+        // compiler (at its register budget) issues each read right in front of its use and every wave pays the LDS round
+        // trip five times per row.
+        float4 gA[2][3], gB[2][3];
+        auto load_group = [&](int g) {
+            const int ir = g >> 1, lrow_base = (wv * R + ir) * COLS + lane + 2 * S;
+            if ((g & 1) == 0) {
 #pragma unroll
-        for (int ir = 0; ir < R + 4; ++ir) {
-            if (ir < NLOAD && have_next)
+                for (int j = 0; j < 3; ++j) {
+                    gA[0][j] = A[lrow_base + (j - 2) * S];
+                    gB[0][j] = B[lrow_base + (j - 2) * S];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    gA[1][j] = A[lrow_base + (j + 1) * S];
+                    gB[1][j] = B[lrow_base + (j + 1) * S];
+                }
+            }
+        };
+        load_group(0);
+#pragma unroll
+        for (int g = 0; g < 2 * (R + 4); ++g) {
+            const int ir = g >> 1;
+            if ((g & 1) == 0 && ir < NLOAD && have_next)
                 issue_load(ir, nt);
-            const int lrow_base = (wv * R + ir) * COLS + lane + 2 * S;
+            if (g + 1 < 2 * (R + 4))
+                load_group(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dx = -2; dx <= 2; ++dx) {
-                const float4 tA = A[lrow_base + dx * S];
-                const float4 tB = B[lrow_base + dx * S];
+            for (int j = 0; j < ((g & 1) ? 2 : 3); ++j) {
+                const int dx = (g & 1) ? j + 1 : j - 2;
+                const float4 tA = gA[g & 1][j];
+                const float4 tB = gB[g & 1][j];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const int dy = ir - k - 2;
                     if (dy < -2 || dy > 2)
                         continue;
-                    // w = Kx*Ky * exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) as ONE exp2:
-                    // exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d == 0 -> -inf -> weight 0)
-                    const float lk = atrous_log2k(dx, dy);
-                    const float d = normal_dot_sat(fmaf(n0z[k], tB.z, fmaf(n0y[k], tB.y, n0x[k] * tB.x)));
-                    float e = fmaf(phiN, fast_log2(d), lk);
-                    e = fmaf(-fabsf(z0[k] - tB.w), cz, e);
-                    e = fmaf(-fabsf(lum0[k] - tA.w), cl[k], e);
-                    const float w = fast_exp2(e);
+                    const float w = tap_weight(n0x[k], n0y[k], n0z[k], z0[k], lum0[k], cl[k], tA, tB, phiN, cz, atrous_log2k(dx, dy));
                     sr[k] = fmaf(w, tA.x, sr[k]);
                     sg[k] = fmaf(w, tA.y, sg[k]);
                     sb[k] = fmaf(w, tA.z, sb[k]);
@@ -472,40 +693,88 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R>::PER_CU)) void svgf_atrous_l
             }
             // Pin the partial sums here: they only feed the predicated store below, so LLVM would
             // otherwise sink ALL the arithmetic under that branch and keep every staged texel live
-            // (spilling ~1.3 KB per lane).  The sched_barrier keeps one row's ds_reads per region.
+            // (spilling ~1.3 KB per lane).  The sched_barrier keeps one group's ds_reads per region.
 #pragma unroll
             for (int k = 0; k < R; ++k)
                 asm volatile("" : "+v"(sr[k]), "+v"(sg[k]), "+v"(sb[k]), "+v"(sw[k]));
             __builtin_amdgcn_sched_barrier(0);
         }
+        NEB_STAMP(4);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             if (!valid[k])
                 continue;
             const int yo = cr + S * (cjbase + wv * R + k);
             const float inv = fast_rcp(fmaxf(sw[k], 1e-4f)); // :84
-            a.dst[(size_t)(yo - a.row_begin) * a.W + xo] = make_float4(sr[k] * inv, sg[k] * inv, sb[k] * inv, alpha0[k]);
+            const float r = sr[k] * inv, g = sg[k] * inv, b = sb[k] * inv;
+            store_output(a.dst + ((size_t)(yo - a.row_begin) * a.W + xo), make_float4(r, g, b, OUT_ALPHA ? alpha0[k] : luminance(r, g, b)));
         }
+        NEB_STAMP(5);
         have = have_next;
         if (have)
             __syncthreads(); // everyone is done reading LDS before the next tile overwrites it
+        NEB_STAMP(6);
+#if NEB_ATROUS_STAMPS
+        ++ntiles;
+#endif
     }
+#if NEB_ATROUS_STAMPS
+    if (lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wv) * 16;
+        for (int i = 0; i < 7; ++i)
+            o[i] = st[i];
+        o[7] = __builtin_amdgcn_s_memtime() - t_begin;
+        o[8] = t_begin_real;
+        o[9] = __builtin_amdgcn_s_memrealtime();
+        o[10] = ntiles;
+        o[11] = __builtin_amdgcn_s_getreg(6164 /* HW_REG_XCC_ID (20), offset 0, size 4: ((4-1)<<11)|20 */);
+        o[12] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4 /* HW_REG_HW_ID */);
+        o[13] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 6 /* HW_REG_LDS_ALLOC */);
+    }
+#endif
 }
+
+#if NEB_ATROUS_STAMPS
+// one stamp block per step (log2 S = 0..5): 2048 workgroups x 4 waves x 16 words; read back by neb_debug_atrous_stamps
+static unsigned long long* g_stamp_buf = nullptr;
+static uint32_t g_stamp_grid[6] = {0, 0, 0, 0, 0, 0};
+static constexpr size_t kStampWords = 2048 * 4 * 16;
+static unsigned long long* atrous_stamp_buffer(int S, uint32_t grid)
+{
+    if (!g_stamp_buf && hipMalloc(&g_stamp_buf, 6 * kStampWords * 8) != hipSuccess)
+        return nullptr;
+    int l = 0;
+    while ((1 << l) < S)
+        ++l;
+    g_stamp_grid[l] = grid;
+    return g_stamp_buf + (size_t)l * kStampWords;
+}
+extern "C" int neb_debug_atrous_stamps(unsigned long long* host, uint32_t* grids)
+{
+    if (!g_stamp_buf)
+        return -1;
+    (void)hipDeviceSynchronize();
+    for (int l = 0; l < 6; ++l)
+        grids[l] = g_stamp_grid[l];
+    return hipMemcpy(host, g_stamp_buf, 6 * kStampWords * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // (Measured and dropped: a double-buffered LDS variant that weaves the staging of tile i+1 into the row loop of
 // tile i, one barrier per tile -- 45-94 us per level against 41-49 us for the kernel above; the longer live
-// ranges cost more than the barrier and the exposed decode they remove.)
-template <int S, int R>
+// ranges cost more than the barrier and the exposed decode they remove.  Round 3: the geometry texels prefetched into
+// registers like the radiance instead of the DMA at the tile boundary: 45 us per level against 35.)
+template <int S, int R, int IN, bool OUT_ALPHA>
 static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t s)
 {
-    using T = AtrousTile<S, R>;
-    constexpr size_t lds_bytes = (size_t)T::TOTAL * 2 * sizeof(float4);
+    using T = AtrousTile<S, R, IN>;
+    constexpr size_t lds_bytes = (size_t)T::LDS_BYTES;
     // the dynamic-LDS limit is a per-device function attribute: remember which devices have it (one bit each; a
     // device ordinal beyond the mask just sets it on every launch)
     static std::atomic<uint64_t> attr_set{0};
     const uint64_t bit = (device >= 0 && device < 64) ? (1ull << device) : 0ull;
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&svgf_atrous_lds_kernel<S, R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&svgf_atrous_lds_kernel<S, R, IN, OUT_ALPHA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
@@ -516,25 +785,50 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
     a.tiles_j = (max_lattice_rows + T::BH - 1) / T::BH;
     a.nblocks = (uint32_t)a.tiles_x * (uint32_t)S * (uint32_t)a.tiles_j;
     // persistent grid: as many workgroups as fit (LDS-limited, at most 3 per CU by the launch bounds)
-    static_assert(T::LDS_BYTES == (int)lds_bytes && T::PER_CU >= 1, "tile too large for the LDS");
+    static_assert(T::PER_CU >= 1, "tile too large for the LDS");
     const uint32_t per_cu = (uint32_t)T::PER_CU;
     uint32_t grid = (uint32_t)num_cus * (per_cu ? per_cu : 1u);
     if (grid > a.nblocks)
         grid = a.nblocks;
     grid = ((grid + 7u) / 8u) * 8u;
-    hipLaunchKernelGGL((svgf_atrous_lds_kernel<S, R>), dim3(grid), dim3(256), lds_bytes, s, a);
+#if NEB_ATROUS_STAMPS
+    a.stamps = atrous_stamp_buffer(S, grid);
+#endif
+    hipLaunchKernelGGL((svgf_atrous_lds_kernel<S, R, IN, OUT_ALPHA>), dim3(grid), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
-                         const uint16_t* variance, const float4* geometry, hipStream_t s)
+// R = 4 rows per lane for steps <= 4 (43.5 KB LDS tile, 3 workgroups per CU), R = 2 for steps 8..32 (the tile is 64 + 4 S
+// columns wide), as measured
+template <int IN, bool OUT_ALPHA>
+static hipError_t launch_lds_step(const AtrousArgs& a, uint32_t step, int device, int num_cus, hipStream_t s)
 {
-    const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
+    switch (step) {
+    case 1: return launch_lds<1, NEB_ATROUS_R_NARROW, IN, OUT_ALPHA>(a, device, num_cus, s);
+    case 2: return launch_lds<2, NEB_ATROUS_R_NARROW, IN, OUT_ALPHA>(a, device, num_cus, s);
+    case 4: return launch_lds<4, NEB_ATROUS_R_NARROW, IN, OUT_ALPHA>(a, device, num_cus, s);
+    case 8: return launch_lds<8, 2, IN, OUT_ALPHA>(a, device, num_cus, s);
+    case 16: return launch_lds<16, 2, IN, OUT_ALPHA>(a, device, num_cus, s);
+    case 32: return launch_lds<32, 2, IN, OUT_ALPHA>(a, device, num_cus, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+bool atrous_lds_serves(const SvgfLaunch& L, int variant, uint32_t step)
+{
+    // wider steps do not fit the LDS tile; the LDS kernel addresses a plane with 32-bit byte offsets: a resident plane of
+    // 4 GB or more -- 16 k x 16 k -- takes the direct kernel
+    return variant >= 1 && step <= 32u && (step & (step - 1u)) == 0u && (uint64_t)(L.row_end - L.row_begin) * L.W < (1ull << 28);
+}
+
+static bool atrous_args(const SvgfLaunch& L, uint32_t step, const float4* src, float4* dst, const uint16_t* variance, const float4* geometry,
+                        AtrousArgs& a)
+{
     const uint32_t Wd = (L.W / 8u) * 8u, Hd = (L.H / 8u) * 8u; // SVGFDenoiser.cpp:185
     const uint32_t row1 = L.row1 < Hd ? L.row1 : Hd;
     if (L.row0 >= row1 || Wd == 0)
-        return hipSuccess;
-    AtrousArgs a;
+        return false;
+    a = AtrousArgs{};
     a.src = src;
     a.dst = dst;
     a.variance = variance;
@@ -547,28 +841,57 @@ hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const 
     a.row0 = (int)L.row0;
     a.row1 = (int)row1;
     a.step = (int)step;
-    a.tiles_x = a.tiles_j = 0;
-    a.nblocks = 0;
     a.cz = kLog2e / (L.p.phiDepth * (float)step);
     a.phiColor = L.p.phiColor;
     a.phiNormal = L.p.phiNormal;
-    // variant 1 (default): R = 4 rows per lane for steps <= 4, R = 2 (smaller LDS tile, 5 waves/SIMD) for steps >= 8,
-    // as measured; 2 / 3 force R = 2 / R = 4 everywhere (A/B arms)
-    // (the LDS kernel addresses a plane with 32-bit byte offsets: a resident plane of 4 GB or more -- 16 k x 16 k -- takes the direct kernel)
-    if (variant >= 1 && (uint64_t)(L.row_end - L.row_begin) * L.W < (1ull << 28)) {
-        switch (step) {
-        case 1: return (variant == 2) ? launch_lds<1, 2>(a, L.device, num_cus, s) : launch_lds<1, 4>(a, L.device, num_cus, s);
-        case 2: return (variant == 2) ? launch_lds<2, 2>(a, L.device, num_cus, s) : launch_lds<2, 4>(a, L.device, num_cus, s);
-        case 4: return (variant == 2) ? launch_lds<4, 2>(a, L.device, num_cus, s) : launch_lds<4, 4>(a, L.device, num_cus, s);
-        case 8: return (variant == 3) ? launch_lds<8, 4>(a, L.device, num_cus, s) : launch_lds<8, 2>(a, L.device, num_cus, s);
-        case 16: return (variant == 3) ? launch_lds<16, 4>(a, L.device, num_cus, s) : launch_lds<16, 2>(a, L.device, num_cus, s);
-        case 32: return (variant == 3) ? launch_lds<32, 4>(a, L.device, num_cus, s) : launch_lds<32, 2>(a, L.device, num_cus, s);
-        default: break; // wider steps do not fit the LDS tile: direct kernel
-        }
-    }
-    dim3 grid((Wd + 63) / 64, (row1 - L.row0 + 3) / 4);
+    return true;
+}
+
+hipError_t launch_atrous(const SvgfLaunch& L, int variant, uint32_t step, const float4* src, float4* dst,
+                         const uint16_t* variance, const float4* geometry, hipStream_t s)
+{
+    AtrousArgs a;
+    if (!atrous_args(L, step, src, dst, variance, geometry, a))
+        return hipSuccess;
+    if (atrous_lds_serves(L, variant, step))
+        return launch_lds_step<kInClassic, true>(a, step, L.device, L.num_cus > 0 ? L.num_cus : 256, s);
+    dim3 grid((a.Wd + 63) / 64, (a.row1 - a.row0 + 3) / 4);
     hipLaunchKernelGGL(svgf_atrous_direct_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_atrous_lum(const SvgfLaunch& L, uint32_t step, bool last, const float4* src, float4* dst, const uint16_t* variance,
+                             const float4* geometry, hipStream_t s)
+{
+    AtrousArgs a;
+    if (!atrous_args(L, step, src, dst, variance, geometry, a))
+        return hipSuccess;
+    a.alpha_src = dst; // the last level writes the plane that still holds the frame's input: its alpha is carried
+    const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
+    return last ? launch_lds_step<kInLum, true>(a, step, L.device, num_cus, s) : launch_lds_step<kInLum, false>(a, step, L.device, num_cus, s);
+}
+
+hipError_t launch_atrous_fused_temporal(const SvgfLaunch& L, bool only_level, const float4* rad_cur, const float4* rad_hist, const uint32_t* depth_cur,
+                                        const uint32_t* depth_hist, const uint2* normal_cur, const uint2* normal_hist, const uint32_t* mom_hist,
+                                        uint32_t* mom_cur, uint16_t* variance, float4* geometry, float4* dst, hipStream_t s)
+{
+    AtrousArgs a;
+    if (!atrous_args(L, 1u, rad_cur, dst, variance, geometry, a))
+        return hipSuccess;
+    a.rad_hist = rad_hist;
+    a.depth_cur = depth_cur;
+    a.depth_hist = depth_hist;
+    a.normal_cur = normal_cur;
+    a.normal_hist = normal_hist;
+    a.mom_hist = mom_hist;
+    a.mom_cur = mom_cur;
+    a.variance_out = variance;
+    a.geometry_out = geometry;
+    a.t_neg_inv_two_sigma2_log2e = -kLog2e / (2.0f * L.p.depthSigma * L.p.depthSigma);
+    a.t_alpha = L.p.alpha;
+    a.t_varianceEps = L.p.varianceEps;
+    const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
+    return only_level ? launch_lds<1, 4, kInFused, true>(a, L.device, num_cus, s) : launch_lds<1, 4, kInFused, false>(a, L.device, num_cus, s);
 }
 
 } // namespace neb

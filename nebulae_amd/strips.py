@@ -42,12 +42,54 @@ def frame_factors(n):
     return a, n // a
 
 
+# Cost table behind the choice of the exchange scheme (microseconds; measured on one MI355X where a kernel is involved,
+# conservative guesses for the xGMI side until an N > 1 run replaces them -- override with NEB_STRIPS_EXCHANGE_LATENCY_US /
+# NEB_STRIPS_LINK_GBPS):
+ATROUS_US_PER_MPX_LEVEL = 16.0   # one a-trous level over a megapixel (33 us per 2.07 Mpx level at 1080p, profiles/r03*)
+EXCHANGE_LATENCY_US = 12.0       # one grouped send + receive with a neighbour, launch to completion, message size aside
+LINK_GBPS = 60.0                 # sustained one-direction rate of one xGMI link for row blocks of a few hundred KB
+
+
+def scheme_costs(width, height, world, levels):
+    """-> {"once": us, "per_level": us}: what each exchange scheme ADDS to a frame of a middle strip.
+    once: sum_l 2 e_l redundant row-levels of a-trous + ONE exchange of h = sum 2*2^l rows x 18 B/px (the exchange runs beside
+    the interior of level 0: only what exceeds that level's own time is charged); per_level: L exchanges of 2*2^l rows x 16 B/px,
+    each a sync point in front of its level (nothing to overlap with)."""
+    import os
+    lat = float(os.environ.get("NEB_STRIPS_EXCHANGE_LATENCY_US", EXCHANGE_LATENCY_US))
+    gbps = float(os.environ.get("NEB_STRIPS_LINK_GBPS", LINK_GBPS))
+    rows = height // world
+    halo = sum(2 * (1 << l) for l in range(levels))
+    redundant_rows = sum(2 * sum(2 * (1 << m) for m in range(l + 1, levels)) for l in range(levels))
+    once_x = lat + halo * width * 18 / (gbps * 1e3)                       # us (bytes / (GB/s * 1e3) = us)
+    level0 = rows * width * 1e-6 * ATROUS_US_PER_MPX_LEVEL
+    once = redundant_rows * width * 1e-6 * ATROUS_US_PER_MPX_LEVEL + max(0.0, once_x - level0)
+    per_level = sum(lat + 2 * (1 << l) * width * 16 / (gbps * 1e3) for l in range(levels))
+    return {"once": once, "per_level": per_level}
+
+
+def choose_scheme(width, height, world, levels):
+    """-> (scheme, reason): the cheaper scheme by scheme_costs; "once" needs strips at least as tall as its halo."""
+    if world == 1 or levels == 0:
+        return "once", "single strip"
+    c = scheme_costs(width, height, world, levels)
+    halo_once = 2 * ((1 << levels) - 1)
+    if height // world < halo_once:
+        return "per_level", f"strips of {height // world} rows are shorter than the {halo_once}-row halo of 'once'"
+    pick = "once" if c["once"] <= c["per_level"] else "per_level"
+    return pick, f"cost table: once +{c['once']:.0f} us, per_level +{c['per_level']:.0f} us per frame at {height // world}-row strips"
+
+
 class StripPartition:
     def __init__(self, width, height, world, levels, scheme=None):
         import os
         if height % world:
             raise ValueError(f"image height {height} is not divisible by {world} strips")
-        self.scheme = scheme or os.environ.get("NEB_STRIPS_SCHEME") or "once"
+        scheme = scheme or os.environ.get("NEB_STRIPS_SCHEME") or "auto"
+        if scheme == "auto":
+            self.scheme, self.scheme_reason = choose_scheme(width, height, world, levels)
+        else:
+            self.scheme, self.scheme_reason = scheme, "requested"
         if self.scheme not in ("once", "per_level"):
             raise ValueError(f"unknown exchange scheme {self.scheme!r}")
         self.W, self.H, self.N, self.L = width, height, world, levels
@@ -306,6 +348,19 @@ class StripRenderer(DeferredRenderer):
         if self.reset_history:
             self.reset_history = False
             self.svgf.reset_history(st)
+        if self.part.N == 1:
+            # one strip = the whole frame: the two whole-frame calls of SubmitCommandsSVGFDenoising (DeferredRenderer.cpp:593-614),
+            # which the library runs as one fused chain (the temporal call is held back: "t0".."t1" brackets nothing then,
+            # and per-level times come from option svgf_profile / SVGFDenoiser.level_times)
+            if events is not None:
+                events["t0"].record()
+            self.svgf.submit_temporal_accumulation(st)
+            if events is not None:
+                events["t1"].record()
+            self.svgf.submit_atrous_compute_wavelet(st)
+            if events is not None and "a1" in events:
+                events["a1"].record()
+            return True
         if events is not None:
             events["t0"].record()
         self.svgf.submit_temporal_accumulation(st, rows=own)

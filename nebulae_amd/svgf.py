@@ -170,6 +170,14 @@ class SVGFDenoiser:
     def submit_atrous_compute_wavelet(self, stream=0):
         self._check(self._lib.neb_svgf_atrous(self._ctx, C.c_void_p(stream)), "neb_svgf_atrous")
 
+    def level_times(self):
+        """Durations (us) of the kernels of the last submit_atrous_compute_wavelet chain (option svgf_profile = 1): entry 0 is
+        level 0 -- fused with the temporal pass when the two calls ran as one chain."""
+        out = (C.c_float * 32)()
+        n = C.c_uint32()
+        self._check(self._lib.neb_svgf_level_times(self._ctx, out, 32, C.byref(n)), "neb_svgf_level_times")
+        return [float(out[k]) for k in range(n.value)]
+
     def submit_atrous_level(self, level, rows, stream=0):
         self._check(self._lib.neb_svgf_atrous_level_rows(self._ctx, level, rows[0], rows[1], C.c_void_p(stream)),
                     "neb_svgf_atrous_level_rows")

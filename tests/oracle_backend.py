@@ -98,6 +98,13 @@ class OracleDenoiser:
                                o.variance.ctypes.data, o.depth[o.cur].ctypes.data, o.normal[o.cur].ctypes.data,
                                1 << level, C.byref(self.params))
 
+    def submit_atrous_compute_wavelet(self, stream=0):
+        """all levels over the whole image (one strip = the whole frame: strips.py then makes the two whole-frame calls)"""
+        for level in range(self.levels):
+            self.submit_atrous_level(level, (0, self.height))
+        if self.levels == 1:
+            self.o.radiance[self.o.cur][...] = self.scratch
+
     def destroy(self):
         if self.o:
             self.o.close()

@@ -60,6 +60,27 @@ def test_strip_exchange_entry_points_validate_arguments_without_a_gpu():
     assert lib.neb_strips_exchange(None, None, None, 0, None, 0, None) == -1
 
 
+def test_strip_calls_report_a_missing_rccl_instead_of_crashing():
+    """A box without librccl: the strip entry points return NEB_ERR_STATE with the loader's message (the library itself still
+    loads).  The not-found path is forced with NEB_RCCL_LIBRARY in a child process (the lookup happens once per process)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys\n"
+            "from nebulae_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "buf = (C.c_char * 128)()\n"
+            "rc = lib.neb_strips_unique_id(buf)\n"
+            "msg = lib.neb_strips_last_error()\n"
+            "rc2 = lib.neb_strips_group_begin()\n"
+            "print(rc, rc2, msg.decode())\n")
+    env = dict(os.environ, NEB_RCCL_LIBRARY="libneb_no_such_rccl.so", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) == -4 and int(rc2) == -4
+    assert "librccl not found" in msg and "libneb_no_such_rccl.so" in msg
+
+
 def test_no_cpu_fallback_when_no_device():
     import torch
     if torch.cuda.is_available():

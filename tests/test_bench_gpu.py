@@ -23,11 +23,18 @@ def test_single_gpu_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _last_json(p.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "svgf_roofline", "frame_roofline", "strong_1080p_frames_per_s"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "svgf_roofline", "svgf_fused_model", "frame_roofline", "kernel_us"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
+    # one GPU: temporal + level 0 ran as one launch, the pure levels are timed by the library's own events
+    ku = d["kernel_us"]
+    assert ku["temporal"] is None and ku["fused_temporal_level0"] > 0 and len(ku["atrous_levels"]) == 5 and all(t > 0 for t in ku["atrous_levels"])
+    assert abs(ku["svgf_chain"] - sum(ku["atrous_levels"])) < 0.25 * ku["svgf_chain"]
+    assert d["svgf_fused_model"]["bytes_per_px"] == 82 + 46 * 4 and d["svgf_roofline"]["bytes_per_px"] == 82 + 46 * 5
+    assert len(d["config"]["library_build_id"]) == 16
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["cpu_baseline"]["cores_available"] >= d["cpu_baseline"]["cores"]
     one = d["cpu_baseline"]["single_thread"]
     assert one["cores"] == 1 and 0 < one["value"] <= d["cpu_baseline"]["value"] * 1.5
     assert "workload" in d["config"] and "69 textures of 1024^2" in d["config"]["workload"]
@@ -44,10 +51,12 @@ def test_two_rank_rehearsal(scheme):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["global_height"] == 2160
-    assert ("one per frame" if scheme == "once" else "one per a-trous level") in d["config"]["parallelism"]
+    # `value` = the metric's own curve: ONE 1920x1080 frame in two strips; the weak-scaling frame rides beside it
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["config"]["global_height"] == 1080 and d["config"]["rows_per_strip"] == 540
+    assert ("one exchange per frame" if scheme == "once" else "one exchange per a-trous level") in d["config"]["parallelism"]
+    assert f"scheme '{scheme}'" in d["config"]["parallelism"] and "transport 'torch'" in d["config"]["parallelism"]
     assert d["frames_per_s_with_final_gather"] > 0
-    assert d["strong_1080p"]["rows_per_strip"] == 540 and d["strong_1080p_frames_per_s"] > 0
+    assert d["weak_scaling"]["global_height"] == 2160 and d["weak_scaling"]["rows_per_strip"] == 1080 and d["weak_scaling"]["frames_per_s_1080p_equivalents"] > 0
     if scheme == "once":
         c5 = d["config5"]
         assert c5["reference_policy"]["frames_denoised"] == 2 and c5["always_on"]["frames_denoised"] == 4

@@ -65,14 +65,17 @@ def test_c_entry_point_exchanges_rows_over_rccl():
     d.upload(PLANE_RADIANCE, SLOT_CURRENT, rad)
     d.upload(PLANE_VARIANCE, 0, var)
     planes = (_lib.HaloPlane * 2)(_lib.HaloPlane(PLANE_RADIANCE, SLOT_CURRENT), _lib.HaloPlane(PLANE_VARIANCE, 0))
-    swaps = (_lib.HaloSwap * 2)(_lib.HaloSwap(0, 12, 16, 8, 12), _lib.HaloSwap(0, 30, 36, 34, 40))  # (peer, send rows, recv rows)
+    swaps = (_lib.HaloSwap * 2)(_lib.HaloSwap(0, 12, 16, 8, 12), _lib.HaloSwap(0, 28, 34, 34, 40))  # (peer, send rows, recv rows: disjoint)
     stream = torch.cuda.current_stream().cuda_stream
+    # (inside the caller's own group bracket, as a one-thread multi-GPU host makes the call: the inner group nests)
+    assert lib.neb_strips_group_begin() == 0
     d._check(lib.neb_strips_exchange(d._ctx, comm, planes, 2, swaps, 2, C.c_void_p(stream)), "neb_strips_exchange")
+    assert lib.neb_strips_group_end() == 0
     torch.cuda.synchronize()
     got_r, got_v = d.download(PLANE_RADIANCE), d.download(PLANE_VARIANCE)
     want_r, want_v = rad.copy(), var.copy()
     want_r[0:4], want_v[0:4] = rad[4:8], var[4:8]          # image rows 8..12 <- 12..16
-    want_r[26:32], want_v[26:32] = rad[22:28], var[22:28]  # image rows 34..40 <- 30..36
+    want_r[26:32], want_v[26:32] = rad[20:26], var[20:26]  # image rows 34..40 <- 28..34
     assert np.array_equal(got_r, want_r) and np.array_equal(got_v, want_v)
     # rows outside the resident range are refused before any RCCL call is made
     bad = (_lib.HaloSwap * 1)(_lib.HaloSwap(0, 0, 4, 8, 12))

@@ -3,7 +3,9 @@
 #   bench line, rocprofv3 --kernel-trace --stats, and three separate --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ counters).
 # usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r02a [extra bench.py flags]
 set -o pipefail
-tag=$1; shift
+tag=$1
+[ -n "$tag" ] || { echo "usage: $0 <tag> [bench.py flags]"; exit 2; }
+shift
 extra="$@"
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
@@ -31,6 +33,17 @@ cp $(ls "$out"/stats/*/*kernel_stats.csv | head -1) "profiles/${tag}_kernel_stat
 python tools/traffic_from_pmc.py "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "profiles/${tag}_hbm_traffic.json" 1920 1080 > /dev/null
 python tools/sq_from_pmc.py "$out/pmc_sq" "profiles/${tag}_sq_counters.json" > /dev/null
 python tools/mem_from_pmc.py "$out/pmc_mem1" "$out/pmc_mem2" "$out/pmc_mem3" "profiles/${tag}_kernel_stats.csv" "profiles/${tag}_mem_counters.json" > /dev/null
+# stamp the library build the counters were taken on into every summary (bench.py quotes a summary only for its own build)
+python - "$tag" <<'PY'
+import glob, json, sys
+tag = sys.argv[1]
+bid = json.load(open(f"profiles/{tag}_bench.json"))["config"]["library_build_id"]
+for f in glob.glob(f"profiles/{tag}_*.json"):
+    d = json.load(open(f))
+    if isinstance(d, dict) and "build_id" not in d:
+        d["build_id"] = bid
+        json.dump(d, open(f, "w"), indent=1)
+PY
 mkdir -p "$out/profiles" && cp profiles/${tag}_* "$out/profiles/"
 python - "$tag" <<'PY'
 import csv, sys

@@ -1,0 +1,88 @@
+// Microbenchmark: what a wave64 v_fma_f32 costs on gfx950 by the number of VGPR source operands and by which register-file
+// banks (register index mod 4) they come from, and what v_exp_f32 / v_log_f32 cost beside plain instructions.
+// usage: hipcc -O3 --offload-arch=gfx950 tools/ubench_bank.hip -o tools/ubench_bank && tools/ubench_bank
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#pragma clang diagnostic ignored "-Wunused-result"
+
+#define REP8(x) x x x x x x x x
+// MODE 0: fma v, v, s, const (one VGPR source)            MODE 1: three VGPR sources in three different banks
+// MODE 2: three VGPR sources, all in the same bank          MODE 3: two VGPR sources (different banks) + SGPR
+// MODE 4: the tap mix: 12 three-source fmas + v_log + v_exp MODE 5: the same with the two transcendentals replaced by fmas
+// MODE 6: v_mul / v_fmac two-source VOP2 forms (different banks)
+#define INIT_REGS                                                                                                                                          \
+    "v_mov_b32 v8, %1\n v_mov_b32 v9, %1\n v_mov_b32 v10, %1\n v_mov_b32 v11, %1\n v_mov_b32 v12, %1\n v_mov_b32 v13, %1\n v_mov_b32 v14, %1\n v_mov_b32 v15, %1\n" \
+    "v_mov_b32 v16, 0.5\n v_mov_b32 v17, 0.5\n v_mov_b32 v18, 0.5\n v_mov_b32 v19, 0.5\n v_mov_b32 v20, 0.5\n v_mov_b32 v21, 0.5\n v_mov_b32 v22, 0.5\n v_mov_b32 v23, 0.5\n" \
+    "v_mov_b32 v24, 0.5\n v_mov_b32 v25, 0.5\n v_mov_b32 v26, 0.5\n v_mov_b32 v27, 0.5\n v_mov_b32 v28, 0.5\n v_mov_b32 v29, 0.5\n v_mov_b32 v30, 0.5\n v_mov_b32 v31, 0.5\n" \
+    "s_mov_b32 s20, %2\n"                                                                                                                                   \
+    "1:\n"
+#define LOOP_END "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc1 1b\n v_add_f32 %0, v8, v9\n v_add_f32 %0, %0, v10\n v_add_f32 %0, %0, v24\n v_add_f32 %0, %0, v25\n"
+#define CLOBBERS "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "s20", "scc"
+// The whole loop is ONE asm statement (the compiler must not place anything of its own inside it).
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters, float s)
+{
+    float r = threadIdx.x, res = 0.f;
+    if constexpr (MODE == 0)
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v8, %3, 1.0\n v_fma_f32 v9, v9, %3, 1.0\n v_fma_f32 v10, v10, %3, 1.0\n v_fma_f32 v11, v11, %3, 1.0\n"
+                                    "v_fma_f32 v12, v12, %3, 1.0\n v_fma_f32 v13, v13, %3, 1.0\n v_fma_f32 v14, v14, %3, 1.0\n v_fma_f32 v15, v15, %3, 1.0\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 1) // dst/src2 vN (bank N%4), src0 bank (N+1)%4, src1 bank (N+2)%4
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, v26, v8\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v24, v10\n v_fma_f32 v11, v16, v25, v11\n"
+                                    "v_fma_f32 v12, v21, v30, v12\n v_fma_f32 v13, v22, v31, v13\n v_fma_f32 v14, v23, v28, v14\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 2) // all three sources in the bank of the destination
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v16, v24, v8\n v_fma_f32 v9, v17, v25, v9\n v_fma_f32 v10, v18, v26, v10\n v_fma_f32 v11, v19, v27, v11\n"
+                                    "v_fma_f32 v12, v20, v28, v12\n v_fma_f32 v13, v21, v29, v13\n v_fma_f32 v14, v22, v30, v14\n v_fma_f32 v15, v23, v31, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 3)
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, %3, v8\n v_fma_f32 v9, v18, %3, v9\n v_fma_f32 v10, v19, %3, v10\n v_fma_f32 v11, v16, %3, v11\n"
+                                    "v_fma_f32 v12, v21, %3, v12\n v_fma_f32 v13, v22, %3, v13\n v_fma_f32 v14, v23, %3, v14\n v_fma_f32 v15, v20, %3, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 4) // per "tap": 12 plain + log + exp = 14 instructions
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, v26, v8\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v24, v10\n v_log_f32 v24, v16\n v_fma_f32 v11, v16, v25, v11\n v_fma_f32 v12, v21, v30, v12\n v_fma_f32 v13, v22, v31, v13\n"
+                                    "v_fma_f32 v14, v23, v28, v14\n v_fma_f32 v15, v20, v29, v15\n v_fma_f32 v8, v17, v26, v8\n v_exp_f32 v25, v17\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v28, v10\n v_fma_f32 v11, v16, v29, v11\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 5)
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, v26, v8\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v24, v10\n v_fma_f32 v24, v16, v16, v16\n v_fma_f32 v11, v16, v25, v11\n v_fma_f32 v12, v21, v30, v12\n v_fma_f32 v13, v22, v31, v13\n"
+                                    "v_fma_f32 v14, v23, v28, v14\n v_fma_f32 v15, v20, v29, v15\n v_fma_f32 v8, v17, v26, v8\n v_fma_f32 v25, v17, v17, v17\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v28, v10\n v_fma_f32 v11, v16, v29, v11\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 6)
+        asm volatile(INIT_REGS REP8("v_fmac_f32 v8, v17, v26\n v_fmac_f32 v9, v18, v27\n v_fmac_f32 v10, v19, v24\n v_fmac_f32 v11, v16, v25\n"
+                                    "v_fmac_f32 v12, v21, v30\n v_fmac_f32 v13, v22, v31\n v_fmac_f32 v14, v23, v28\n v_fmac_f32 v15, v20, v29\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    out[blockIdx.x * 256 + threadIdx.x] = res;
+}
+
+template <int MODE>
+static void run(const char* name, int blocks_per_cu, int per_iter)
+{
+    float* out;
+    const int nb = 256 * blocks_per_cu, iters = 20000;
+    hipMalloc(&out, nb * 256 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<nb, 256>>>(out, 100, 0.999f);
+    hipEventRecord(e0);
+    k<MODE><<<nb, 256>>>(out, iters, 0.999f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double instr_per_simd = (double)iters * per_iter * blocks_per_cu;
+    printf("%-52s waves/SIMD=%d  %.3f ms -> %.2f ns per wave-instruction per SIMD\n", name, blocks_per_cu, ms, ms * 1e6 / instr_per_simd);
+    hipFree(out);
+}
+
+int main()
+{
+    for (int w : {1, 2, 3, 4, 6}) {
+        run<0>("fma v, v, s, const (1 VGPR source)", w, 64);
+        run<3>("fma v, v, s, v (2 VGPR sources, 2 banks)", w, 64);
+        run<1>("fma v, v, v, v (3 VGPR sources, 3 banks)", w, 64);
+        run<2>("fma v, v, v, v (3 VGPR sources, 1 bank)", w, 64);
+        run<6>("fmac v, v, v (VOP2; 3 VGPR sources, 3 banks)", w, 64);
+        run<4>("tap mix: 12 three-source fma + v_log + v_exp", w, 112);
+        run<5>("tap mix with the transcendentals as fma", w, 112);
+    }
+    return 0;
+}
