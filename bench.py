@@ -39,7 +39,7 @@ GI_STREAM_BYTES_PX = 56  # 24 B G-buffer read + 32 B radiance read
 PROFILE_ROUND = "r03"   # only PMC summaries of this round's kernels are quoted (profiles/r03*_*.json), and only of this very build
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -67,7 +67,9 @@ def parse():
                     help="N > 1: halo exchange scheme (auto: the cheaper one by strips.choose_scheme's cost table)")
     ap.add_argument("--config5", action="store_true", help="also run BASELINE.json configs[4] (default: only when N = 8)")
     ap.add_argument("--config5-frames", type=int, default=32, help="frames of the config-5 sequence (half moving, half still)")
-    return ap.parse_args()
+    ap.add_argument("--config5-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"),
+                    help="frame of the config-5 leg (BASELINE.json configs[4]: 3840 2160; the CPU dry run shrinks it)")
+    return ap.parse_args(argv)
 
 
 def library_build_id():
@@ -219,18 +221,61 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
                                         f"scaled by {scale:.2f} to the whole frame"}}
 
 
+class GpuRuntime:
+    """What the control flow below needs from the device side.  bench.py always runs with this one; tests/test_bench_dryrun.py
+    substitutes a CPU stand-in (no-op events, an oracle-backed strip renderer) to rehearse the N = 8 control flow under gloo."""
+    name = "hip"
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+
+    def available(self):
+        return self.torch.cuda.is_available()
+
+    def set_device(self, local_rank):
+        self.torch.cuda.set_device(local_rank)
+
+    def init_process_group(self, dist, local_rank):
+        backend = os.environ.get("NEB_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": self.torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+
+    def current_stream(self):
+        return self.torch.cuda.current_stream()
+
+    def stream_handle(self, stream):
+        return stream.cuda_stream
+
+    def new_stream(self):
+        return self.torch.cuda.Stream()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def event(self, timing=True):
+        return self.torch.cuda.Event(enable_timing=timing)
+
+    def to_device(self, t):
+        return t.cuda()
+
+    def make_renderer(self, part, rank, local_rank, group, exchange):
+        from nebulae_amd import strips
+        return strips.StripRenderer(part, rank, device=local_rank, group=group, exchange=exchange)
+
+
 class Workload:
     """One strip renderer of a GW x GH frame cut into `world` row strips, its static G-buffer and direct-light term."""
 
-    def __init__(self, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True, scheme=None):
+    def __init__(self, rt, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True, scheme=None):
         import torch
         from nebulae_amd import strips, synth
+        self.rt = rt
         from nebulae_amd.renderer import RenderInfo
         from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE
         self.torch, self.RenderInfo = torch, RenderInfo
         self.args, self.GW, self.GH, self.L, self.sc, self.cam, self.rank, self.world, self.do_gi = args, GW, GH, L, sc, cam, rank, world, do_gi
         self.part = strips.StripPartition(GW, GH, world, L, scheme=scheme)
-        self.r = r = strips.StripRenderer(self.part, rank, device=local_rank, group=group, exchange=args.exchange)
+        self.r = r = rt.make_renderer(self.part, rank, local_rank, group, args.exchange)
         # one strip = the whole frame: temporal + a-trous run as the library's fused chain when every pixel is covered by both
         self.fused_chain = (world == 1 and GW % 8 == 0 and GH % 8 == 0 and 1 <= L <= 6 and args.atrous_variant == 1
                             and not os.environ.get("NEB_BENCH_NO_FUSE"))
@@ -240,25 +285,25 @@ class Workload:
         r.gi_ui.gi_samples_per_pixel = spp
         self.own = self.part.owned(rank)
         self.res = self.part.resident(rank)
-        self.stream = torch.cuda.current_stream()
-        self.sh = self.stream.cuda_stream
+        self.stream = rt.current_stream()
+        self.sh = rt.stream_handle(self.stream)
         r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=self.sh))
         r.submit_commands_gbuffer()          # G-buffer of this rank's resident rows, slot "current" of frame 1
-        torch.cuda.synchronize()
+        rt.synchronize()
         for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: the other slot holds the same G-buffer
             r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
         self.rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
         if args.sort_rays >= 0:
             r.svgf.set_option("gi_sort_rays", args.sort_rays)
         r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
-        torch.cuda.synchronize()
+        rt.synchronize()
         self.direct = self.rad_view[r.svgf.get_current_resource_index()].clone()
         self.noisy_dev = None
         if do_gi:
             r.ray_count(reset=True)
         else:
             g = synth.synth_gbuffer(GW, GH)
-            self.noisy_dev = [torch.from_numpy(synth.synth_radiance(g["base"][self.res[0]:self.res[1]], f + 1)).cuda() for f in range(4)]
+            self.noisy_dev = [rt.to_device(torch.from_numpy(synth.synth_radiance(g["base"][self.res[0]:self.res[1]], f + 1))) for f in range(4)]
         self.frame = 1
         self.ran_svgf = []
         # Optional frames in flight (the reference keeps 3, src/nri/Swapchain.h:15): the GI stages of frame f+1 touch only
@@ -266,7 +311,7 @@ class Workload:
         # main stream; the two meet at neb_gi_resolve (the reference's separate nrc Resolve step, DeferredRenderer.cpp:586).
         # Measured on MI355X: +1 % (the GI kernels already occupy every wave slot), so it is off by default.
         self.overlap = do_gi and args.overlap
-        self.side = torch.cuda.Stream() if self.overlap else None
+        self.side = rt.new_stream() if self.overlap else None
         self.resolved = None
         if self.overlap:
             r.set_defer_resolve(True)
@@ -290,28 +335,28 @@ class Workload:
         if self.do_gi:
             if pipelined and self.resolved is not None:
                 self.side.wait_event(self.resolved)  # the previous frame's resolve has consumed the GI records
-            r.submit_commands_gi_pathtrace(stream=gi_stream.cuda_stream)
+            r.submit_commands_gi_pathtrace(stream=self.rt.stream_handle(gi_stream))
         if timed_events is not None:
             timed_events["gi1"].record(stream)
         if self.overlap:
             self.rad_view[cur].copy_(self.direct, non_blocking=True)
             if pipelined:
-                done = torch.cuda.Event()
+                done = self.rt.event(timing=False)
                 done.record(self.side)
                 stream.wait_event(done)
             r.submit_commands_gi_resolve()
             if pipelined:
-                self.resolved = torch.cuda.Event()
+                self.resolved = self.rt.event(timing=False)
                 self.resolved.record(stream)
         self.ran_svgf.append(r.submit_commands_svgf_denoising(timed_events))
         r.end_frame()
 
     def barrier(self):
         import torch.distributed as dist
-        self.torch.cuda.synchronize()
+        self.rt.synchronize()
         if self.world > 1:
             dist.barrier()
-        self.torch.cuda.synchronize()
+        self.rt.synchronize()
 
     def reduce_max_sum(self, dt, rays):
         """-> (max over ranks of dt, sum over ranks of rays)"""
@@ -319,7 +364,7 @@ class Workload:
         torch = self.torch
         if self.world == 1:
             return dt, float(rays)
-        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"  # (the MAX / SUM over ranks travels on the job's own backend)
         mx = torch.tensor([dt], dtype=torch.float64, device=dev)
         sm = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -355,7 +400,7 @@ class Workload:
         self.r.destroy()
 
 
-def run_config5(args, sc, rank, world, local_rank, group, scheme=None):
+def run_config5(rt, args, sc, rank, world, local_rank, group, scheme=None):
     """BASELINE.json configs[4]: 3840x2160 in `world` strips, 4 spp, 5 levels; the camera orbits
     (yaw += 0.5 deg per frame) for the first half of the sequence and stands still for the second.  Two runs: the
     reference's policy (SVGF skipped while moving, history reset on the first still frame) and always-on (beyond the
@@ -363,13 +408,14 @@ def run_config5(args, sc, rank, world, local_rank, group, scheme=None):
     from nebulae_amd import scene as S
     n = max(2, args.config5_frames)
     half = n // 2
+    c5w, c5h = args.config5_size
 
     def cam_at(k):
         return S.orbit_camera(origin=(0.0, 2.0, 0.0), yaw_deg=12.0 + 0.5 * min(k + 1, half), pitch_deg=60.0, distance=9.0)
-    out = {"workload": f"3840x2160, 4 spp one-bounce GI + SVGF temporal + 5 a-trous levels, {world} row strips of {2160 // world} rows, "
+    out = {"workload": f"{c5w}x{c5h}, 4 spp one-bounce GI + SVGF temporal + 5 a-trous levels, {world} row strips of {c5h // world} rows, "
                        f"{half} frames with the camera orbiting (yaw += 0.5 deg per frame; G-buffer and direct term re-rendered) then {n - half} still frames"}
     for mode in ("reference_policy", "always_on"):
-        w = Workload(args, 3840, 2160, 5, 4, sc, cam_at(-1), rank, world, local_rank, group, scheme=scheme)
+        w = Workload(rt, args, c5w, c5h, 5, 4, sc, cam_at(-1), rank, world, local_rank, group, scheme=scheme)
         w.r.denoise_while_moving = mode == "always_on"
         w.step()  # one still frame first, so that the sequence starts from a settled state
         w.step()
@@ -385,25 +431,26 @@ def run_config5(args, sc, rank, world, local_rank, group, scheme=None):
     return out
 
 
-def main():
-    args = parse()
+def main(argv=None, rt=None, emit=None):
+    """argv / rt / emit: None for the real run (sys.argv, the HIP runtime, print); the CPU dry run passes its own."""
+    args = parse(argv)
     import numpy as np
     import torch
     import torch.distributed as dist
+    rt = rt or GpuRuntime()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
+    if not rt.available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if os.environ.get("NEB_BENCH_SHARE_DEVICE"):  # rehearsal of the N > 1 path on a 1-GPU box: every rank on cuda:0
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    rt.set_device(local_rank)
     if world > 1:
-        backend = os.environ.get("NEB_BENCH_BACKEND", "nccl")
-        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+        rt.init_process_group(dist, local_rank)
     group = dist.group.WORLD if world > 1 else None
 
     from nebulae_amd import scene as S
@@ -431,7 +478,7 @@ def main():
 
     # ---- the primary workload: ONE width x height frame (BASELINE.json configs[2]) on `world` GPUs = `world` row strips ----
     GW, GH = args.width, args.height
-    w = Workload(args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme)
+    w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme)
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
     bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth()} if do_gi else None
@@ -453,8 +500,8 @@ def main():
     if world == 1:
         r.svgf.set_option("svgf_profile", 1)
     for _ in range(8):
-        e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1", "a1")}
-        e["levels"] = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(L)]
+        e = {k: rt.event() for k in ("gi0", "gi1", "t0", "t1", "a1")}
+        e["levels"] = [(rt.event(), rt.event()) for _ in range(L)]
         w.step(e)
         if world == 1:
             lt.append(r.svgf.level_times())
@@ -462,10 +509,10 @@ def main():
     if world == 1:
         r.svgf.set_option("svgf_profile", 0)
     for _ in range(8):
-        e = {k: torch.cuda.Event(enable_timing=True) for k in ("gi0", "gi1", "t0", "t1", "a1")}
+        e = {k: rt.event() for k in ("gi0", "gi1", "t0", "t1", "a1")}
         w.step(e)
         ev2.append(e)
-    torch.cuda.synchronize()
+    rt.synchronize()
     rays_ev = (r.ray_count(reset=True) if do_gi else 0) // 2  # (two batches of 8 frames)
     t_gi = float(np.mean([e["gi0"].elapsed_time(e["gi1"]) for e in ev])) * 1e-3
     fused = False
@@ -502,7 +549,7 @@ def main():
     weak = None
     if world > 1 and not args.no_weak and do_gi:
         a, b = strips.frame_factors(world)
-        ww = Workload(args, args.width * a, args.height * b, L, args.spp, sc, cam, rank, world, local_rank, group, scheme=scheme)
+        ww = Workload(rt, args, args.width * a, args.height * b, L, args.spp, sc, cam, rank, world, local_rank, group, scheme=scheme)
         dtw, rays_w = ww.timed(args.steps, max(args.warmup, 2))
         weak = {"frames_per_s_1080p_equivalents": args.steps / dtw * world, "global_frames_per_s": args.steps / dtw, "ms_per_frame": dtw / args.steps * 1e3,
                 "mrays_per_s": rays_w / dtw / 1e6, "global_width": args.width * a, "global_height": args.height * b,
@@ -510,7 +557,7 @@ def main():
         ww.destroy()
     config5 = None
     if do_gi and (args.config5 or world == 8):
-        config5 = run_config5(args, sc, rank, world, local_rank, group, scheme)
+        config5 = run_config5(rt, args, sc, rank, world, local_rank, group, scheme)
 
     if rank == 0:
         fps = args.steps / dt                                 # whole-job frames per second of the ONE frame
@@ -572,7 +619,7 @@ def main():
         }
         if gb is not None:
             out["cpu_baseline"] = cpu_baseline(GW, GH, L, args.cpu_frames, gb, consts, sc, noisy, do_gi)
-        print(json.dumps(out), flush=True)
+        (emit or (lambda line: print(line, flush=True)))(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,163 @@
+"""CPU dry run of bench.py's N > 1 control flow, rank for rank: `python bench.py --gpus 8` as the driver launches it, with
+the device side replaced -- gloo instead of RCCL, an oracle-backed strip renderer instead of the HIP library, no-op events --
+and the frames shrunk.  What it pins is everything the first multi-GPU run can trip over that is NOT a kernel: the partition
+of every leg (the metric's own 1080p-style frame in N strips, the weak-scaling frame, BASELINE.json configs[4] with its
+moving-then-still camera), the collectives every rank must enter in the same order (barriers, MAX / SUM reductions, the halo
+exchanges of both schemes, the final gather), and the shape of the one JSON line.  Test infrastructure: the stand-ins live
+here, bench.py itself never imports them."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Event:
+    def record(self, stream=None):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.05  # ms
+
+
+class _Stream:
+    cuda_stream = 0
+
+    def wait_event(self, e):
+        pass
+
+
+class DryRuntime:
+    """bench.GpuRuntime's interface on the CPU."""
+    name = "dry"
+
+    def available(self):
+        return True
+
+    def set_device(self, local_rank):
+        pass
+
+    def init_process_group(self, dist, local_rank):
+        dist.init_process_group("gloo")
+
+    def current_stream(self):
+        return _Stream()
+
+    def stream_handle(self, stream):
+        return 0
+
+    def new_stream(self):
+        return _Stream()
+
+    def synchronize(self):
+        pass
+
+    def event(self, timing=True):
+        return _Event()
+
+    def to_device(self, t):
+        return t
+
+    def make_renderer(self, part, rank, local_rank, group, exchange):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_backend import OracleDenoiser
+
+        from nebulae_amd import strips, synth
+        from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE
+
+        class DryStripRenderer(strips.StripRenderer):
+            """The strip renderer with every GI / G-buffer entry point of the HIP library replaced by cheap host fills; the
+            SVGF side (what the strips exchange and filter) is the oracle-backed denoiser of the gloo strip tests."""
+
+            def __init__(self):
+                super().__init__(part, rank, device=0, group=group, denoiser_factory=OracleDenoiser, exchange="torch")
+                self._rays = 0
+                self._g = synth.synth_gbuffer(part.W, part.H)
+
+            def init_pathtracer_scene(self, scene, stream=0):
+                self._scene = scene
+
+            def scene_info(self):
+                return 12, 3
+
+            def scene_bytes(self):
+                return {"texture_tables": 0, "triangles": 0, "bvh_nodes": 0}
+
+            def bvh_depth(self):
+                return 2
+
+            def _rows(self):
+                return self.svgf.row_begin, self.svgf.row_end
+
+            def submit_commands_gbuffer(self):
+                r0, r1 = self._rows()
+                cur = self.svgf.get_current_resource_index()
+                self.svgf.plane_tensor(PLANE_DEPTH, cur).copy_(torch.from_numpy(self._g["depth"][r0:r1].view(np.int32)))
+                self.svgf.plane_tensor(PLANE_NORMAL, cur).copy_(torch.from_numpy(self._g["normal"][r0:r1]))
+
+            def submit_commands_pbr_lighting(self):
+                r0, r1 = self._rows()
+                cur = self.svgf.get_current_resource_index()
+                self.svgf.plane_tensor(PLANE_RADIANCE, cur).copy_(torch.from_numpy(synth.synth_radiance(self._g["base"][r0:r1], 1)))
+
+            def submit_commands_gi_pathtrace(self, rows=None, stream=None):
+                own = self.part.owned(self.rank)
+                r0, _ = self._rows()
+                cur = self.svgf.get_current_resource_index()
+                t = self.svgf.plane_tensor(PLANE_RADIANCE, cur)
+                t[own[0] - r0:own[1] - r0, :, :3] += 0.01 * float(self.info.frame_index % 7)  # "adds into radiance[cur]"
+                self._rays += 2 * (own[1] - own[0]) * self.part.W * int(self.gi_ui.gi_samples_per_pixel)
+
+            def ray_count(self, reset=False):
+                v = self._rays
+                if reset:
+                    self._rays = 0
+                return v
+
+        return DryStripRenderer()
+
+
+def _rank_main(rank, world, port, argv, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import bench
+    lines = []
+    bench.main(argv, rt=DryRuntime(), emit=lines.append)
+    if rank == 0:
+        assert len(lines) == 1
+        open(out_path, "w").write(lines[0])
+    else:
+        assert not lines
+
+
+@pytest.mark.parametrize("world,scheme", [(8, "auto"), (2, "per_level")])
+def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
+    # 8 strips need >= 62 rows each for the one-exchange scheme at 5 levels: 64 x 512 frames; the config-5 leg runs at its own
+    # (shrunk) size with its moving-then-still camera; --gather adds the final gather after every frame
+    out = tmp_path / "line.json"
+    argv = ["--gpus", str(world), "--steps", "2", "--warmup", "2", "--width", "64", "--height", "512", "--cpu-frames", "0", "--triangles", "2000",
+            "--tex-size", "16", "--gather", "--scheme", scheme, "--config5", "--config5-frames", "4", "--config5-size", "64", "512"]
+    port = 29900 + (os.getpid() % 1500) + world
+    mp.spawn(_rank_main, args=(world, port, argv, str(out)), nprocs=world, join=True)
+    d = json.loads(out.read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "weak_scaling", "config5", "kernel_us", "svgf_roofline", "frame_roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["vs_baseline"] is None
+    cfg = d["config"]
+    assert cfg["global_width"] == 64 and cfg["global_height"] == 512 and cfg["rows_per_strip"] == 512 // world
+    want_scheme = "once" if scheme == "auto" else scheme
+    assert f"scheme '{want_scheme}'" in cfg["parallelism"] and f"row-strips x{world}" in cfg["parallelism"]
+    a, b = (2, 4) if world == 8 else (1, 2)
+    ws = d["weak_scaling"]
+    assert ws["global_width"] == 64 * a and ws["global_height"] == 512 * b and ws["frames_per_s_1080p_equivalents"] > 0
+    c5 = d["config5"]
+    assert c5["reference_policy"]["frames_denoised"] == 2 and c5["always_on"]["frames_denoised"] == 4  # skip while moving, then reset
+    assert c5["reference_policy"]["mrays_per_s"] > 0
+    assert d["frames_per_s_with_final_gather"] > 0
+    assert d["mrays_per_s"] > 0 and len(d["kernel_us"]["atrous_levels"]) == 5
