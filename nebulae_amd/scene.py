@@ -233,18 +233,30 @@ def _read_uri(base, uri):
     return np.fromfile(os.path.join(base, uri), np.uint8)
 
 
-def load_gltf(path, first_mesh_only=True, tex_upscale=1):
+def load_gltf(path, first_mesh_only=True, tex_upscale=1, missing_buffers="error"):
     """ASCII .gltf (+ .bin / image files) or binary .glb.  Nodes are visited as ImportScene / ImportGLTFNode do
     (GLTFSceneImporter.cpp:86,442-474): the scene's root nodes in order, then children, each mesh node with its OWN
     local transform (the reference does not concatenate parents).  first_mesh_only mirrors InitRTAccelerationStructures,
     which builds the BLAS from the first StaticMesh only (src/DeferredRenderer.cpp:992-995).  tex_upscale > 1 repeats
-    every texel k x k times (fixtures that carry down-sampled maps get their original working-set size back)."""
+    every texel k x k times (fixtures that carry down-sampled maps get their original working-set size back).
+    missing_buffers="zeros": an external .bin that is not there (assets/sponza/Sponza.bin is stripped from the reference
+    checkout) reads as zeros of its declared length -- the file's STRUCTURE (primitives, accessors, materials, images) can
+    then still be loaded and checked; with the .bin beside the .gltf the same call loads the real geometry.
+    The Scene remembers where things came from: Scene.source = {"node": index of the mesh node, "primitives": [...],
+    "images": glTF image index per Scene texture, "materials": glTF material index per Scene material}."""
     import io
 
     from PIL import Image
     base = os.path.dirname(path)
     g, blob = _read_container(path)
-    buffers = [(_read_uri(base, b["uri"]) if "uri" in b else blob) for b in g.get("buffers", [])]
+
+    def read_buffer(b):
+        if "uri" not in b:
+            return blob
+        if missing_buffers == "zeros" and not b["uri"].startswith("data:") and not os.path.exists(os.path.join(base, b["uri"])):
+            return np.zeros(int(b["byteLength"]), np.uint8)
+        return _read_uri(base, b["uri"])
+    buffers = [read_buffer(b) for b in g.get("buffers", [])]
 
     def view_bytes(i):
         bv = g["bufferViews"][i]
@@ -262,6 +274,7 @@ def load_gltf(path, first_mesh_only=True, tex_upscale=1):
         return np.ascontiguousarray(rows).view(dt).reshape(a["count"], n)
 
     sc = Scene(os.path.basename(path))
+    sc.source = {"node": None, "primitives": [], "images": [], "materials": []}
     tex_cache = {}
 
     def texture(ref):
@@ -275,6 +288,7 @@ def load_gltf(path, first_mesh_only=True, tex_upscale=1):
             if tex_upscale > 1:
                 px = np.repeat(np.repeat(px, tex_upscale, axis=0), tex_upscale, axis=1)
             tex_cache[src] = sc.add_texture(px)
+            sc.source["images"].append(src)
         return tex_cache[src]
 
     mat_map = {}
@@ -307,7 +321,11 @@ def load_gltf(path, first_mesh_only=True, tex_upscale=1):
                 mat_map[mi] = sc.add_material(albedo=pbr.get("baseColorFactor", [1, 1, 1, 1]) if tex[0] < 0 else (0, 0, 0, 1),
                                               rm=(pbr.get("roughnessFactor", 1.0), pbr.get("metallicFactor", 1.0))
                                               if tex[2] < 0 else (1.0, 0.0), textures=tex)
+                sc.source["materials"].append(mi)
             sc.add_geometry(pos, nrm, uv, idx, mat_map.get(mi, -1), M=M, tangents=tang)
+            sc.source["primitives"].append({"mesh": node["mesh"], "material": mi, "has_tangents": tang is not None})
+        if sc.source["node"] is None:
+            sc.source["node"] = ni
         if first_mesh_only:
             break
     return sc
