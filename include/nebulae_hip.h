@@ -113,9 +113,6 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (default on),
  *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
  *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it;
- *   "gi_suspend_lanes": 0..8 (default 0 = off): a closest-hit wave whose live lanes drop to this many parks them, and a follow-up
- *                       launch finishes and shades all parked rays in dense waves beside the shade pass (same visits, same hits:
- *                       only where they run changes).  Measured: no net gain;
  *   "gi_exact_shade":   1 = hit shading in the C arithmetic of the CPU oracle (IEEE division, sqrt, powf, sinf / cosf) instead of
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;

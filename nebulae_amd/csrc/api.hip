@@ -300,11 +300,6 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_defer_resolve needs a scene (neb_gi_set_scene)");
         return NEB_OK;
     }
-    if (!strcmp(key, "gi_suspend_lanes")) {
-        if (gi_set_suspend_lanes(ctx, value) != NEB_OK)
-            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_suspend_lanes needs a scene and a value in 0..8");
-        return NEB_OK;
-    }
     if (!strcmp(key, "gi_exact_shade")) {
         if (gi_set_exact_shade(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_exact_shade needs a scene (neb_gi_set_scene)");

@@ -68,7 +68,6 @@ struct GiArgs {
     unsigned long long* ray_counter; // diagnostics: [1..4] traversal steps (only touched when stats != 0)
     uint32_t* bounce_counts;     // per-workgroup bounce-ray counts
     uint32_t* shadow_counts;     // per-workgroup shadow-ray counts
-    uint32_t* resume_counts;     // the same for gi_resume_shade_kernel (it runs beside gi_shade_kernel: its own slots)
     uint32_t W, row_begin, row0, row1, tiles_x;
     uint32_t sample;             // index of the sample this launch handles
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
@@ -82,41 +81,7 @@ struct GiArgs {
     uint32_t raygen_only;        // 1: gi_raygen_trace_kernel only writes the ray record and its key (a sorted trace follows)
     float smin[3], sinv[3];      // scene box for the Morton keys
     uint32_t first_px, n_px;     // dispatched pixel range [first_px, first_px + n_px) of the resident planes
-    // tail suspension of the closest-hit pass (gi_device.h: traverse_core): a wave whose live lanes drop to suspend_lanes
-    // parks them -- 32-dword records, kSuspendSlots per wave -- and gi_resume_trace_kernel finishes them in dense waves
-    uint32_t suspend_lanes;      // 0 = off
-    uint32_t* suspend_records;   // [waves][kSuspendSlots][32]: {pixel, node, sp, node visits, triangle tests, hit t u v tri, stack[23]}
-    uint32_t* suspend_counts;    // [waves]: records parked by each wave of the launch
-    uint32_t n_waves;            // waves of the closest-hit launch
 };
-constexpr uint32_t kSuspendSlots = 8; // upper bound of "gi_suspend_lanes"
-constexpr uint32_t kSuspendRecordDwords = 32;
-static_assert(9 + kSuspendMaxStack == kSuspendRecordDwords, "suspend record layout");
-
-// Parks the suspended lanes of this wave (every lane of the wave calls it; `suspended` is false for the others).
-__device__ __forceinline__ void park_suspended(const GiArgs& a, bool suspended, uint32_t pixel, int node, const TravStack& st, const Hit& hit)
-{
-    const unsigned long long mask = __ballot(suspended);
-    if (threadIdx.x == 0)
-        a.suspend_counts[blockIdx.x] = (uint32_t)__popcll(mask);
-    if (!suspended)
-        return;
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << threadIdx.x) - 1ull));
-    uint32_t* rec = a.suspend_records + ((size_t)blockIdx.x * kSuspendSlots + rank) * kSuspendRecordDwords;
-    rec[0] = pixel;
-    rec[1] = (uint32_t)node;
-    rec[2] = (uint32_t)st.sp;
-    rec[3] = hit.node_visits;
-    rec[4] = hit.tri_tests;
-    rec[5] = __float_as_uint(hit.t); // the best hit so far (t = tmax, triangle = ~0: none yet)
-    rec[6] = __float_as_uint(hit.u);
-    rec[7] = __float_as_uint(hit.v);
-    rec[8] = hit.tri;
-    for (int k = 0; k < st.sp; ++k)
-        rec[9 + k] = (uint32_t)(k < kLdsStack ? st.lds[64 * k] : st.spill[k - kLdsStack]);
-}
-
-
 // Position of this workgroup in the dispatch (tile number, or run of 64 sorted rays).  Workgroups are dealt round-robin
 // over the 8 XCDs, each with its own L2.  With RUNS > 0 the dispatch is cut into RUNS segments and inside a segment each
 // XCD takes one contiguous eighth, so the workgroups resident on an XCD cover a compact piece of the frame.  Speed only,
@@ -173,16 +138,6 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
     size_t i;
     const bool active = gi_pixel<kRaygenRuns>(a, x, y, i);
     uint32_t rays = 0;
-    // traversal state, kept outside the branch: the lanes a suspended wave parks are written out at wave level below
-    Hit hit;
-    hit.t = kTraceMax;
-    hit.u = hit.v = 0.0f;
-    hit.tri = ~0u;
-    hit.node_visits = hit.tri_tests = 0;
-    int spill_mem[kSpillStack];
-    TravStack st{stack_mem + threadIdx.x, spill_mem, 0};
-    int node = kTravDone;
-    bool suspended = false;
     if (active) {
         const float3 albedo = unpack_r11g11b10(a.albedo[i]);
         const uint2 wp = a.world_pos[i];
@@ -222,20 +177,11 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
             a.bsort_vals[i] = (uint32_t)i;
         }
         if (bounce && !a.raygen_only && a.S.n_tris) {
-            bool found = false;
-            node = a.S.root;
-            if (a.suspend_lanes) // (A/B arm, off by default: its per-iteration ballots are kept out of the product path)
-                suspended = a.stats ? traverse_core<false, true, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes)
-                                    : traverse_core<false, false, true>(a.S, org, dir, 0.01f, st, node, hit, found, (int)a.suspend_lanes);
-            else if (a.stats)
-                (void)traverse_core<false, true, false>(a.S, org, dir, 0.01f, st, node, hit, found, 0);
-            else
-                (void)traverse_core<false, false, false>(a.S, org, dir, 0.01f, st, node, hit, found, 0);
-            if (suspended) // parked: gi_resume_shade_kernel owns this pixel from here (its state goes into a record below)
-                h = make_float4(-3.0f, 0.f, 0.f, 0.f);
-            else if (found)
+            Hit hit;
+            const bool found = traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit, a.stats != 0u);
+            if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
-            if (a.stats && !suspended) { // diagnostics only
+            if (a.stats) { // diagnostics only
                 atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
                 atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
                 a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2)); // loop iterations of this ray
@@ -243,8 +189,6 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         }
         a.R.hit[i] = h;
     }
-    if (a.suspend_lanes)
-        park_suspended(a, suspended, (uint32_t)i, node, st, hit);
     count_rays(a.bounce_counts, rays);
 }
 
@@ -391,8 +335,7 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
     }
 }
 
-// One wave per 8x8 pixel tile.  Pixels whose bounce ray was parked by a thinned-out closest-hit wave (hit.x == -3) are not
-// this kernel's: gi_resume_shade_kernel finishes their traversal and shades them, concurrently, on another stream.
+// One wave per 8x8 pixel tile.
 template <bool FAST>
 __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
 {
@@ -400,12 +343,9 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
     size_t i;
     const bool active = gi_pixel<kShadeRuns>(a, x, y, i);
     ShadeOut o;
-    bool parked = false;
     float4 h = make_float4(-2.0f, 0.f, 0.f, 0.f);
-    if (active) {
+    if (active)
         h = a.R.hit[i];
-        parked = a.suspend_lanes != 0u && a.bounce == 1u && h.x == -3.0f;
-    }
     // The 128-byte shading records of the wave's (up to) 64 hit triangles are gathered COOPERATIVELY: eight lanes fetch
     // the eight 16-byte pieces of one record -- one cache line per eight lanes instead of one per lane and load -- straight
     // into LDS (LDS-DMA), eight records per instruction.  The texture-address units, which the scattered per-lane gathers
@@ -413,7 +353,7 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
     // record of lane s lands at [s * 8 + j] and holds global piece j ^ (s & 7): an XOR swizzle that spreads the banks.
     __shared__ float4 smem[64 * 8];
     const uint32_t lane = threadIdx.x;
-    const bool has_hit = active && !parked && h.x >= 0.0f;
+    const bool has_hit = active && h.x >= 0.0f;
     const uint32_t my_tri = has_hit ? __float_as_uint(h.w) : ~0u; // ~0: nothing to fetch for this lane (there may be no record array at all)
 #pragma unroll
     for (uint32_t it = 0; it < 8; ++it) {
@@ -425,9 +365,8 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
         }
     }
     __syncthreads(); // (waits for the DMA: an LDS-DMA is a pending LDS write on the VM counter)
-    if (active && !parked)
+    if (active)
         shade_pixel<FAST, true>(a, i, h, o, smem + lane * 8u, lane & 7u);
-    const unsigned long long parked_mask = __ballot(parked); // lane l <-> pixel (l & 7, l >> 3) of the tile
     // Store the 64-byte records of the wave's 8x8 tile.  Lane-per-pixel stores would write 16 bytes at a 64-byte stride
     // four times over; transposed through LDS, every store instruction writes two 512-byte runs (one tile row each).
     __syncthreads(); // every lane is done with its staged record: the buffer is reused
@@ -443,62 +382,10 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
     for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t row = 2 * k + (lane >> 5), col = (lane & 31u) >> 2, comp = lane & 3u;
         const uint32_t px = tile_x * 8 + col, py = a.row0 + tile_y * 8 + row;
-        if (px < a.W && py < a.row1 && !((parked_mask >> (row * 8 + col)) & 1ull))
+        if (px < a.W && py < a.row1)
             a.R.srec[4 * ((size_t)(py - a.row_begin) * a.W + px) + comp] = xpose[(row * 8 + col) * 4 + comp];
     }
     count_rays(a.shadow_counts, o.rays);
-}
-
-// Finishes the parked rays -- one per lane, dense waves -- and shades them: the second half of tail suspension
-// (traverse_core, gi_device.h: an A/B arm, off by default).  Runs on a side stream beside gi_shade_kernel, which skips
-// exactly these pixels.
-template <bool FAST>
-__global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_resume_shade_kernel(GiArgs a)
-{
-    __shared__ int stack_mem[kLdsStack * 64];
-    // lane j <-> slot (j % suspend_lanes) of wave (j / suspend_lanes): a thinned-out wave parks on average 3.3 of 4 lanes, so
-    // the slots are dense enough as they are (a prefix-sum compaction in one workgroup cost 72 us, more than it could save)
-    const uint32_t j = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t w = j / a.suspend_lanes, k = j - w * a.suspend_lanes;
-    ShadeOut o;
-    if (w < a.n_waves && k < a.suspend_counts[w]) {
-        const uint32_t* rec = a.suspend_records + ((size_t)w * kSuspendSlots + k) * kSuspendRecordDwords;
-        const size_t i = rec[0];
-        int node = (int)rec[1];
-        int spill_mem[kSpillStack];
-        TravStack st{stack_mem + threadIdx.x, spill_mem, 0};
-        const int sp = (int)rec[2];
-        for (int q = 0; q < sp; ++q)
-            st.push((int)rec[9 + q]);
-        const float4 ro = a.R.ray_o[i], rd = a.R.ray_d[i];
-        Hit hit;
-        hit.node_visits = rec[3];
-        hit.tri_tests = rec[4];
-        hit.t = __uint_as_float(rec[5]);
-        hit.u = __uint_as_float(rec[6]);
-        hit.v = __uint_as_float(rec[7]);
-        hit.tri = rec[8];
-        bool found = hit.tri != ~0u;
-        if (a.stats)
-            (void)traverse_core<false, true, false>(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, st, node, hit, found, 0);
-        else
-            (void)traverse_core<false, false, false>(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, st, node, hit, found, 0);
-        // (R.hit[i] keeps its "parked" mark: gi_shade_kernel runs concurrently and must not find a finished hit there and shade
-        // the pixel a second time; nothing else reads the vertex-1 hit record)
-        const float4 h = found ? make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri)) : make_float4(-1.0f, 0.f, 0.f, 0.f);
-        if (a.stats) { // diagnostics only
-            atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
-            atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
-            a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2));
-        }
-        shade_pixel<FAST, false>(a, i, h, o, nullptr, 0u);
-        float4* rec_out = a.R.srec + 4 * i;
-        rec_out[kSrO] = o.rec_o;
-        rec_out[kSrD] = o.shadow_d;
-        rec_out[kSrContrib] = o.rec_c;
-        rec_out[kSrSum] = o.sum;
-    }
-    count_rays(a.resume_counts, o.rays);
 }
 
 // (A persistent-wave variant with per-lane ray refill was measured and dropped: lanes of a wave finish after
@@ -862,9 +749,6 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         }
     }
     a.defer_resolve = g->defer_resolve ? 1u : 0u;
-    a.suspend_lanes = g->sort_bounce ? 0u : g->suspend_lanes; // (a sorted bounce trace runs through gi_bounce_trace_kernel)
-    a.suspend_records = a.suspend_counts = nullptr;
-    a.n_waves = 0;
     g->pending_spp = c->samplesPerPixel;
     g->pending_row0 = row0;
     g->pending_row1 = row1;
@@ -873,33 +757,14 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
     if (!g->d_block_counts) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow rays made by the resume pass}
-        GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t))); // {bounce, shadow} rays per workgroup
+        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
         g->d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
-    a.resume_counts = g->d_block_counts + 2 * g->n_block_counts;
-    if (a.suspend_lanes) {
-        if (!g->d_suspend) { // records for every wave a launch over the resident rows can have, + counts, list, total
-            const size_t words = n_blocks * kSuspendSlots * kSuspendRecordDwords + n_blocks;
-            void* p = nullptr;
-            GI_HIP(ctx, hipMalloc(&p, words * sizeof(uint32_t)));
-            g->allocs.push_back(p);
-            g->d_suspend = (uint32_t*)p;
-        }
-        a.suspend_records = g->d_suspend;
-        a.suspend_counts = g->d_suspend + n_blocks * kSuspendSlots * kSuspendRecordDwords;
-        a.n_waves = grid.x;
-        if (!g->side_stream) { // the resume pass runs beside the shade pass: a stream and two events of the library's own
-            GI_HIP(ctx, hipStreamCreateWithFlags(&g->side_stream, hipStreamNonBlocking));
-            GI_HIP(ctx, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-            GI_HIP(ctx, hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
-        }
-    }
-    bool forked = false;
     const uint32_t n_vertices = c->maxPathVertices > 1 ? c->maxPathVertices - 1 : 1; // path vertices traced per sample
     for (uint32_t s = 0; s < c->samplesPerPixel; ++s) {
         a.sample = s;
@@ -907,17 +772,6 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             a.bounce = b;
             if (b == 1) {
                 hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
-                if (a.suspend_lanes && !a.raygen_only) { // fork: the parked rays are finished and shaded on the side stream
-                    GI_HIP(ctx, hipEventRecord(g->ev_fork, (hipStream_t)stream));
-                    GI_HIP(ctx, hipStreamWaitEvent(g->side_stream, g->ev_fork, 0));
-                    const dim3 rgrid((grid.x * a.suspend_lanes + 63u) / 64u);
-                    if (kFastShade && !g->exact_shade)
-                        hipLaunchKernelGGL(gi_resume_shade_kernel<true>, rgrid, block, 0, g->side_stream, a);
-                    else
-                        hipLaunchKernelGGL(gi_resume_shade_kernel<false>, rgrid, block, 0, g->side_stream, a);
-                    GI_HIP(ctx, hipEventRecord(g->ev_join, g->side_stream));
-                    forked = true;
-                }
             }
             if (g->sort_bounce) {
                 uint32_t* bs = g->d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
@@ -933,10 +787,6 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
                 hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
             else
                 hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
-            if (forked) { // join: the sort and the shadow pass read the records of both
-                GI_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, g->ev_join, 0));
-                forked = false;
-            }
             if (g->sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the
                 // sorted pixel indices land back in vals
@@ -1004,15 +854,14 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
     if (!g->d_block_counts) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow rays made by the resume pass}
-        GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t))); // {bounce, shadow} rays per workgroup
+        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
         g->d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
-    a.resume_counts = g->d_block_counts + 2 * g->n_block_counts;
     hipLaunchKernelGGL(pbr_direct_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
@@ -1048,7 +897,7 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
     GiState* g = ctx->gi;
     GI_GUARD(ctx);
     unsigned long long v[8] = {};
-    std::vector<uint32_t> counts(3 * g->n_block_counts);
+    std::vector<uint32_t> counts(2 * g->n_block_counts);
     GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (g->d_block_counts)
         GI_HIP(ctx, hipMemcpyAsync(counts.data(), g->d_block_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -1157,13 +1006,6 @@ int gi_set_max_bvh_depth(neb_ctx* ctx, int depth)
     if (!ctx->gi || depth < 1 || depth > (kLdsStack + kSpillStack) / 3)
         return NEB_ERR_STATE;
     ctx->gi->max_bvh_depth = (uint32_t)depth;
-    return NEB_OK;
-}
-int gi_set_suspend_lanes(neb_ctx* ctx, int lanes)
-{
-    if (!ctx->gi || lanes < 0 || lanes > (int)kSuspendSlots)
-        return NEB_ERR_STATE;
-    ctx->gi->suspend_lanes = (uint32_t)lanes;
     return NEB_OK;
 }
 int gi_set_exact_shade(neb_ctx* ctx, int on)

@@ -17,7 +17,7 @@ void gi_on_resize(GiState* g)
 {
     if (!g)
         return;
-    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts, g->d_sort, g->d_sort_temp, g->d_suspend};
+    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts, g->d_sort, g->d_sort_temp};
     for (void* p : stale) {
         if (!p)
             continue;
@@ -34,7 +34,6 @@ void gi_on_resize(GiState* g)
     g->n_block_counts = 0;
     g->d_sort = nullptr;
     g->d_sort_temp = nullptr;
-    g->d_suspend = nullptr;
 }
 
 void gi_destroy(GiState* g)
@@ -43,12 +42,6 @@ void gi_destroy(GiState* g)
         return;
     for (void* p : g->allocs)
         (void)hipFree(p);
-    if (g->side_stream) {
-        (void)hipStreamSynchronize(g->side_stream);
-        (void)hipStreamDestroy(g->side_stream);
-        (void)hipEventDestroy(g->ev_fork);
-        (void)hipEventDestroy(g->ev_join);
-    }
     delete g;
 }
 

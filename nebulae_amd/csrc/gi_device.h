@@ -260,23 +260,10 @@ __device__ __forceinline__ bool intersect_tri(const float4* __restrict__ tris, u
     return intersect_tri_regs(tris[3 * ti], tris[3 * ti + 1], tris[3 * ti + 2], o, d, tmin, tmax, t, u, v);
 }
 
-// Entry distance of the ray into box k of a BVH4 node, as an ordered uint key (misses = 0xffffffff).
-// n* / f* are the planes the ray meets first / last on each axis (picked by the sign of the direction when the node
-// is loaded).  One fma per plane: t = plane * (1/d) - o/d.  fminf/fmaxf drop NaNs (inf - inf for axis-parallel
-// rays), which only makes the interval more conservative; hits themselves are decided by the triangle test.
-__device__ __forceinline__ uint32_t slab_key(float nx, float ny, float nz, float fx, float fy, float fz, float3 inv, float3 oinv,
-                                             float tmin, float tmax, uint32_t slot)
-{
-    const float ax = fmaf(nx, inv.x, -oinv.x), bx = fmaf(fx, inv.x, -oinv.x);
-    const float ay = fmaf(ny, inv.y, -oinv.y), by = fmaf(fy, inv.y, -oinv.y);
-    const float az = fmaf(nz, inv.z, -oinv.z), bz = fmaf(fz, inv.z, -oinv.z);
-    const float t0 = fmaxf(fmaxf(ax, ay), fmaxf(az, tmin));
-    const float t1 = fminf(fminf(bx, by), fminf(bz, tmax));
-    // t0 >= tmin >= 0: its bit pattern orders like an unsigned integer; the low 2 bits carry the slot
-    return (t0 <= t1) ? ((__float_as_uint(t0) & ~3u) | slot) : 0xffffffffu;
-}
-
-// the same from entry / exit distances already computed (quantised nodes)
+// Entry distance of the ray into a child box of a BVH4 node, as an ordered uint key (misses = 0xffffffff), from the
+// distances to the planes the ray meets first (a*) and last (b*) on each axis.  fminf / fmaxf drop NaNs (inf - inf for
+// axis-parallel rays), which only makes the interval more conservative; hits themselves are decided by the triangle test.
+// t0 >= tmin >= 0: its bit pattern orders like an unsigned integer; the low 2 bits carry the slot.
 __device__ __forceinline__ uint32_t slab_key_t(float ax, float ay, float az, float bx, float by, float bz, float tmin, float tmax, uint32_t slot)
 {
     const float t0 = fmaxf(fmaxf(ax, ay), fmaxf(az, tmin));
@@ -321,30 +308,16 @@ struct TravStack {
 // round trips per iteration.  Shadow rays skip the front-to-back ordering of the children.
 constexpr int kTravDone = (int)0x80000000;
 
-// Tail suspension (closest-hit rays; option "gi_suspend_lanes", OFF by default).  The lanes of a wave need very different
-// numbers of iterations (p50 16, p99 29, the slowest of 64 lanes ~33), so the last third of a wave's life runs a handful
-// of lanes at full instruction cost.  With SUSPEND, a wave stops as soon as at most `suspend_lanes` of its lanes are still
-// traversing: they leave with their state {node, stack, best hit so far} and gi_resume_shade_kernel finishes all such
-// stragglers in dense waves.  A resumed ray continues exactly where it stopped: same visits, same hits (the parity tests
-// run with it on as well).  Replayed on the host from measured per-ray iteration counts (tools/gi_divergence.py) it
-// promised x0.81 of the wave-iterations at 4 lanes (5 % of the rays parked), x0.78 at 8 -- and the closest-hit launch does
-// drop from 383 to 338 / 322 us.  But the parked rays are the LONGEST ones: their follow-up pass is a chain of ~60
-// dependent node fetches whatever its width -- 56-73 us run alone, 157-189 us run beside the bandwidth-bound shade pass
-// (which it slows from 140 to 155-188 us) -- so the GI dispatch as a whole gets no faster (752 us off, 760-772 us on).
-// Kept as an A/B arm.
-constexpr int kSuspendMaxStack = 23; // stack entries a suspended ray can carry (record = 32 dwords = 128 B: 9 of state + these)
-
-// The traversal loop proper, resumable: starts from (node, st, hit, found) and runs until the ray is done or -- with
-// SUSPEND -- the wave is down to `suspend_lanes` live lanes; returns true when it stopped early (node != kTravDone then).
-template <bool ANY_HIT, bool STATS, bool SUSPEND>
-__device__ __forceinline__ bool traverse_core(const SceneView& S, float3 o, float3 d, float tmin, TravStack& st, int& node, Hit& hit, bool& found,
-                                              int suspend_lanes)
+// The traversal loop proper: starts from (node, st, hit, found) and runs until the ray is done.  Every ray walks the 64-byte
+// quantised nodes (Bvh4NodeQ, gi_internal.h): four 16-byte loads per visit.  (Measured and moved out of the product, round 2:
+// the 128-byte exact-plane walk -- seven loads per visit: closest-hit 377 against 293 us, any-hit 177 against 135 -- and
+// "tail suspension", parking the last lanes of a thinned-out wave for a dense follow-up pass: the closest-hit launch drops
+// from 383 to 338 us, but the parked rays are the longest ones and their follow-up pass costs what was saved)
+template <bool ANY_HIT, bool STATS>
+__device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, float3 d, float tmin, TravStack& st, int& node, Hit& hit, bool& found)
 {
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-    // byte offset of the plane the ray enters through, per axis, inside a Bvh4Node (the exit plane is offset ^ 64)
-    const uint32_t onx = d.x < 0.0f ? 64u : 0u, ony = d.y < 0.0f ? 80u : 16u, onz = d.z < 0.0f ? 96u : 32u;
-    constexpr bool QUANT = ANY_HIT ? (NEB_QUANT_ANYHIT != 0) : (NEB_QUANT_CLOSEST != 0);
     const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
     constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
@@ -353,7 +326,7 @@ __device__ __forceinline__ bool traverse_core(const SceneView& S, float3 o, floa
                 hit.node_visits++;
             uint32_t k0, k1, k2, k3;
             int4 ch;
-            if constexpr (QUANT) {
+            {
                 const char* nodes = reinterpret_cast<const char*>(S.qnodes);
                 const uint32_t nb = (uint32_t)node << 6;
                 const float4 p0 = *reinterpret_cast<const float4*>(nodes + nb);            // {origin.xyz, scale.x}
@@ -373,17 +346,6 @@ __device__ __forceinline__ bool traverse_core(const SceneView& S, float3 o, floa
                                       fmaf(un(qfy), sy, by), fmaf(un(qfz), sz, bz), tmin, hit.t, c);
                 };
                 k0 = key(0u), k1 = key(1u), k2 = key(2u), k3 = key(3u);
-            } else {
-                const char* nodes = reinterpret_cast<const char*>(S.nodes);
-                const uint32_t nb = (uint32_t)node << 7; // 32-bit byte offset (scalar base + vector offset addressing)
-                const float4 nx = *reinterpret_cast<const float4*>(nodes + (nb + onx)), fx = *reinterpret_cast<const float4*>(nodes + (nb + (onx ^ 64u)));
-                const float4 ny = *reinterpret_cast<const float4*>(nodes + (nb + ony)), fy = *reinterpret_cast<const float4*>(nodes + (nb + (ony ^ 64u)));
-                const float4 nz = *reinterpret_cast<const float4*>(nodes + (nb + onz)), fz = *reinterpret_cast<const float4*>(nodes + (nb + (onz ^ 64u)));
-                ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
-                k0 = slab_key(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, inv, oinv, tmin, hit.t, 0u);
-                k1 = slab_key(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, inv, oinv, tmin, hit.t, 1u);
-                k2 = slab_key(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, inv, oinv, tmin, hit.t, 2u);
-                k3 = slab_key(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, inv, oinv, tmin, hit.t, 3u);
             }
             // select by the slot bits without branches (two levels of v_cndmask)
             auto child_of = [&](uint32_t key) -> int {
@@ -469,17 +431,11 @@ __device__ __forceinline__ bool traverse_core(const SceneView& S, float3 o, floa
             }
             if (ANY_HIT && found) {
                 node = kTravDone;
-                return false;
+                return;
             }
             node = st.sp ? st.pop() : kTravDone;
         }
-        if (SUSPEND) { // (all lanes still in the loop see the same ballot: the branch is uniform among them)
-            const unsigned long long live = __ballot(node != kTravDone);
-            if (__popcll(live) <= suspend_lanes && __ballot(node != kTravDone && st.sp > kSuspendMaxStack) == 0ull)
-                return node != kTravDone;
-        }
     }
-    return false;
 }
 
 template <bool ANY_HIT, bool STATS>
@@ -494,7 +450,7 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     int spill_mem[kSpillStack];
     TravStack st{lds_stack, spill_mem, 0};
     int node = S.root;
-    (void)traverse_core<ANY_HIT, STATS, false>(S, o, d, tmin, st, node, hit, found, 0);
+    traverse_core<ANY_HIT, STATS>(S, o, d, tmin, st, node, hit, found);
     return found;
 }
 

@@ -78,13 +78,6 @@ struct Bvh4NodeQ {
     int4 child;           // 48: as Bvh4Node::child
 };
 static_assert(sizeof(Bvh4NodeQ) == 64, "quantised node layout");
-#ifndef NEB_QUANT_ANYHIT
-#define NEB_QUANT_ANYHIT 1
-#endif
-#ifndef NEB_QUANT_CLOSEST
-#define NEB_QUANT_CLOSEST 1 // closest-hit rays too: they order the children by the decoded entry distances and prune against hit.t with
-                            // them -- conservative both ways, the nearest triangle found is the same
-#endif
 #ifndef NEB_TRACE_WAVES
 #define NEB_TRACE_WAVES 8 // waves per SIMD the traversal kernels are register-budgeted for
 #endif
@@ -95,9 +88,6 @@ static_assert(sizeof(Bvh4NodeQ) == 64, "quantised node layout");
 #define NEB_LEAF_BATCH 12
 #endif
 constexpr int kLeafBatch = NEB_LEAF_BATCH;
-#ifndef NEB_SUSPEND_LANES
-#define NEB_SUSPEND_LANES 0 // default of "gi_suspend_lanes" (traverse_core, gi_device.h): off -- measured, it does not pay
-#endif
 #ifndef NEB_FAST_SHADE
 #define NEB_FAST_SHADE 1 // gi_shade_kernel uses the 1-ulp hardware rcp / rsq / sqrt (see fdiv)
 #endif
@@ -141,10 +131,6 @@ struct GiState {
     float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
     unsigned long long last_stats[8] = {};
     bool defer_resolve = false;
-    uint32_t suspend_lanes = NEB_SUSPEND_LANES; // "gi_suspend_lanes": closest-hit waves park their last lanes (0 = off)
-    uint32_t* d_suspend = nullptr;              // parked-ray records + per-wave counts
-    hipStream_t side_stream = nullptr;          // gi_resume_shade_kernel runs here, beside gi_shade_kernel on the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool exact_shade = false; // "gi_exact_shade": gi_shade_kernel<false>, the oracle's C arithmetic
     bool sort_shadow = true;  // "gi_sort_rays" bit 0
     bool sort_bounce = false; // "gi_sort_rays" bit 1

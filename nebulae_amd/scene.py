@@ -331,10 +331,12 @@ def load_gltf(path, first_mesh_only=True, tex_upscale=1, missing_buffers="error"
     return sc
 
 
-def save_glb(scene, path, with_tangents=False):
+def save_glb(scene, path, with_tangents=False, encoded_images=None):
     """Writes a Scene as one binary glTF 2.0 file: one mesh node (matrix = the geometries' shared instance transform), one
     primitive per geometry, textures as embedded PNGs.  The fixtures under tests/golden/ are written with it; tangents
-    are left out by default so the loader regenerates them exactly as it does for a file that has none."""
+    are left out by default so the loader regenerates them exactly as it does for a file that has none.
+    encoded_images: per Scene texture the bytes of an already encoded image file (and its mime type) to embed as they are
+    instead of a PNG of the decoded texels -- [(bytes, "image/jpeg"), ...]: a JPEG-textured asset keeps its original files."""
     import io
 
     from PIL import Image
@@ -370,10 +372,14 @@ def save_glb(scene, path, with_tangents=False):
             pr["material"] = int(gm["material"])
         prims.append(pr)
     images, textures = [], []
-    for t in scene.textures:
-        buf = io.BytesIO()
-        Image.fromarray(t, "RGBA").save(buf, format="PNG", optimize=True)
-        images.append({"bufferView": add_view(buf.getvalue()), "mimeType": "image/png"})
+    for k, t in enumerate(scene.textures):
+        if encoded_images is not None:
+            data, mime = encoded_images[k]
+            images.append({"bufferView": add_view(bytes(data)), "mimeType": mime})
+        else:
+            buf = io.BytesIO()
+            Image.fromarray(t, "RGBA").save(buf, format="PNG", optimize=True)
+            images.append({"bufferView": add_view(buf.getvalue()), "mimeType": "image/png"})
         textures.append({"source": len(images) - 1})
     mats = []
     for m in scene.materials:

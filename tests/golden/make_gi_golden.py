@@ -25,6 +25,8 @@ CASES = {
     "gi_cornell_tex_multibounce_32x24": ("cornell_standin_textured", dict(yaw_deg=10.0, pitch_deg=80.0, distance=2.6), 32, 24, 7, 2, 4, None),
     "gi_cornell_box_real_32x32": ("cornell_box.glb", dict(origin=(0.0, 1.0, 0.0), distance=3.5), 32, 32, 5, 1, 3, (0.725, 0.71, 0.68)),
     "gi_damaged_helmet_48x32": ("DamagedHelmet_256.glb", dict(yaw_deg=15.0, pitch_deg=75.0, distance=2.2), 48, 32, 2, 1, 2, None),
+    # the helmet with its ORIGINAL 2048^2 JPEG maps (the un-filtered texture content: many more mirror-like roughness texels)
+    "gi_damaged_helmet_full_80x64": ("DamagedHelmet_jpeg.glb", dict(yaw_deg=25.0, pitch_deg=80.0, distance=1.7), 80, 64, 4, 1, 2, None),
 }
 GB_KEYS = ("albedo", "rough_metal", "world_pos", "normal", "depth")
 
@@ -49,7 +51,10 @@ def main():
     from nebulae_amd import scene as S
     from oracle import gi_np
     from oracle_lib import OracleTracer
+    only = set(sys.argv[1:])
     for name, (key, camkw, W, H, frame, spp, mv, alb) in CASES.items():
+        if only and name not in only:
+            continue
         sc = case_scene(key)
         cam = S.orbit_camera(**camkw)
         o = OracleTracer(sc)

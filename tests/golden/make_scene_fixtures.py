@@ -14,7 +14,14 @@ are committed and travel:
                                       PNG: a 16 MB-per-map working set does not belong in a repository.  Tests load them
                                       with tex_upscale=8 to restore the 2048^2 footprint (each texel repeated 8x8).
 
-Both are data in the scenes' own on-disk format (glTF 2.0 binary), read back through nebulae_amd.scene.load_gltf -- the
+  tests/golden/DamagedHelmet_jpeg.glb the same geometry with the three maps as the ORIGINAL JPEG files, embedded byte for byte
+                                      (2.75 MB): the real 2048^2 texture content -- with far more mirror-like roughness
+                                      texels than any box-filtered copy keeps -- for BASELINE.json config 2 and the
+                                      gi_damaged_helmet_full golden.  Decoded by PIL wherever the tests run; the
+                                      reference decodes with stb_image: at most 3 grey levels apart, mean 0.02
+                                      (tests/test_scene_ref_cpu.py).
+
+All are data in the scenes' own on-disk format (glTF 2.0 binary), read back through nebulae_amd.scene.load_gltf -- the
 same code path (GLB container parsing included) the reference's default scene takes (src/Nebulae.cpp:36).
 """
 import os
@@ -40,9 +47,15 @@ def main():
     S.save_glb(sc, os.path.join(HERE, "cornell_box.glb"))
     sc = S.load_gltf(os.path.join(ASSETS, "DamagedHelmet", "DamagedHelmet.gltf"))
     assert sc.num_triangles == 15452 and len(sc.geometries) == 1 and [t.shape for t in sc.textures] == [(2048, 2048, 4)] * 3
+    import json
+    doc = json.load(open(os.path.join(ASSETS, "DamagedHelmet", "DamagedHelmet.gltf")))
+    files = [(open(os.path.join(ASSETS, "DamagedHelmet", doc["images"][i]["uri"]), "rb").read(), "image/jpeg") for i in sc.source["images"]]
+    S.save_glb(sc, os.path.join(HERE, "DamagedHelmet_jpeg.glb"), encoded_images=files)
+    full = S.load_gltf(os.path.join(HERE, "DamagedHelmet_jpeg.glb"))
+    assert all(np.array_equal(a, b) for a, b in zip(full.textures, sc.textures)) and np.array_equal(full.geometries[0]["positions"], sc.geometries[0]["positions"])
     sc.textures = [box_downsample(t, 8) for t in sc.textures]
     S.save_glb(sc, os.path.join(HERE, "DamagedHelmet_256.glb"))
-    for f in ("cornell_box.glb", "DamagedHelmet_256.glb"):
+    for f in ("cornell_box.glb", "DamagedHelmet_256.glb", "DamagedHelmet_jpeg.glb"):
         back = S.load_gltf(os.path.join(HERE, f))
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes;", back.num_triangles, "triangles,", len(back.textures), "textures")
 

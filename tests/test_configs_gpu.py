@@ -77,6 +77,8 @@ def _pipeline_vs_oracle(sc, cam, W, H, L, frames, hit_tol, albedo_override=None,
         r.end_frame()
     got = r.svgf.download(PLANE_RADIANCE)
     want = osv.radiance[osv.cur]
+    print(f"[{sc.name} {W}x{H} exact_shade={int(exact_shade)}] hit mismatch {worst_hits:.2e}, GI rel-L2 {worst_rad:.3e} (bar {rad_tol:.0e}), "
+          f"pixels within 1e-4: {worst_px:.5f}, rel-L2 without the rest {worst_trim:.2e}")
     assert worst_hits <= hit_tol, f"hit / visibility mismatch fraction {worst_hits:.2e}"
     assert worst_rad <= rad_tol, worst_rad
     assert worst_px >= 0.999, worst_px  # per-pixel: 1e-4 relative on all but a handful of ill-conditioned highlights ...
@@ -102,18 +104,21 @@ def test_config1_cornell_box_256(albedo):
 
 @pytest.mark.parametrize("exact_shade", [True, False])
 def test_config2_damaged_helmet_720p_three_levels(exact_shade):
-    """The helmet's mirror-like patches (roughness map ~0.03) sit where GGX's denominator nh^2 (a^2 - 1) + 1 cancels: an ulp
-    in the view or half vector moves such a highlight by percents -- in the oracle's own float arithmetic just as much --
-    and those few huge values carry the L2 norm.  Measured over the pixels whose hits agree: 5.7e-4 with the default
-    arithmetic policy (1-ulp hardware rcp / rsq / sqrt, what an HLSL compiler emits), 2.8e-4 with the oracle's C arithmetic
-    ("gi_exact_shade": what remains is the ulp between ocml's and glibc's sinf / cosf in the bounce direction, hence in V).
-    So the whole-image bar here is the north star's 1e-3; all but <= 0.1 % of the pixels agree to 1e-4 each, and without
-    those the image meets the 2e-5 bar of every other scene."""
-    sc = S.load_gltf(os.path.join(GOLDEN, "DamagedHelmet_256.glb"), tex_upscale=8)
+    """BASELINE.json configs[1] on the helmet's ORIGINAL texture content (tests/golden/DamagedHelmet_jpeg.glb: the three
+    2048^2 JPEG maps byte for byte).  Its mirror-like patches (roughness map ~0.03) sit where GGX's denominator
+    nh^2 (a^2 - 1) + 1 cancels: an ulp in the view or half vector moves such a highlight by percents -- in the oracle's own
+    float arithmetic just as much -- and those few huge values carry the L2 norm.  Two arithmetic policies of the hit
+    shading, each held to its own measured bar over the pixels whose hits agree (north_star's bar: 1e-3):
+      default ("gi_exact_shade" = 0): the 1-ulp hardware rcp / rsq / sqrt an HLSL compiler emits -- what the reference's own
+        DXC build runs, and 9 us per frame faster -- <= 6e-4;
+      exact   ("gi_exact_shade" = 1): the oracle's C arithmetic; what remains is the ulp between ocml's and glibc's
+        sinf / cosf in the bounce direction, hence in V -- <= 3e-4.
+    All but <= 0.1 % of the pixels agree to 1e-4 each, and without those the image meets the 2e-5 bar of every other scene."""
+    sc = S.load_gltf(os.path.join(GOLDEN, "DamagedHelmet_jpeg.glb"))
     assert sc.num_triangles == 15452 and len(sc.geometries) == 1 and [t.shape for t in sc.textures] == [(2048, 2048, 4)] * 3
     assert sc.geometries[0]["indices"].dtype == np.uint16
     cam = S.orbit_camera()  # reference defaults (InspectCamera.h:52-55): eye (0, 0, 3)
-    _pipeline_vs_oracle(sc, cam, 1280, 720, 3, frames=4, hit_tol=3e-4, exact_shade=exact_shade, rad_tol=1e-3)
+    _pipeline_vs_oracle(sc, cam, 1280, 720, 3, frames=4, hit_tol=3e-4, exact_shade=exact_shade, rad_tol=3e-4 if exact_shade else 6e-4)
 
 
 def test_helmet_gbuffer_producer_matches_oracle():

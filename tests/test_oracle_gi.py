@@ -156,7 +156,7 @@ def _gi_golden_cases():
 
 
 @pytest.mark.parametrize("name", ["gi_cornell_tex_40x32", "gi_cornell_tex_multibounce_32x24", "gi_cornell_box_real_32x32",
-                                  "gi_damaged_helmet_48x32"])
+                                  "gi_damaged_helmet_48x32", "gi_damaged_helmet_full_80x64"])
 def test_trace_ref_matches_the_numpy_restatement_golden(name):
     """oracle/trace_ref.cpp (own SAH BVH, float32 Moeller-Trumbore) against vectors produced by a second, independent
     reading of the shaders with brute-force float64 intersection: same hits, same sun visibility, same radiance."""
