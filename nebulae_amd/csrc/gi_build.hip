@@ -490,9 +490,96 @@ struct CollapseArgs {
     uint32_t* inner_scan;   // exclusive prefix sum of inner_count over the level
     uint32_t* level_state;  // [0] = entries of the next level
     uint32_t level_start, level_count;
+    const float4* plan;     // per binary node: {C(n,1), C(n,2), C(n,3), decision bits} of collapse_plan_kernel, or null (greedy)
 };
 
 __device__ __forceinline__ bool collapse_is_leaf(const BinaryNodes& N, int node) { return N.size[node] <= (uint32_t)kMaxLeafTris; }
+
+// Which descendants of a binary node become the (up to four) children of its wide node: chosen by cost, not by the
+// "open the largest box" rule -- the optimal conversion of a binary BVH into a wide one by dynamic programming over the
+// tree (Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017, section
+// 3.1, for width 4).  For a binary node n with children l and r:
+//   C(n, 1)      = cost of the subtree with n as the root of ONE wide node  = A(n) c_node + min_k [ C(l, k) + C(r, 4 - k) ]
+//                  (a run of <= kMaxLeafTris triangles is a leaf: A(n) c_leaf)
+//   C(n, i), i>1 = cost of the subtree as a forest of at most i entries of an ancestor's wide node
+//                = min( C(n, i - 1),  min_k [ C(l, k) + C(r, i - k) ] )
+// A = half the surface area of the node's box (the chance a ray visits it), c_node / c_leaf = the traversal's cost of an
+// inner visit / a leaf visit (a leaf of one or two triangles costs the same six loads).  Children come one SAH pass after
+// their parent, so the tree is swept bottom-up one pass at a time (node ids of a pass are contiguous).  The decisions ride
+// in .w: bits 0-1 = k of C(n,1); bit 2 = C(n,2) splits (1,1), else it is C(n,1); bits 3-4 = C(n,3): 0 = take C(n,2), else k.
+#ifndef NEB_COLLAPSE_CNODE
+#define NEB_COLLAPSE_CNODE 1.0f
+#endif
+#ifndef NEB_COLLAPSE_CLEAF
+#define NEB_COLLAPSE_CLEAF 1.2f
+#endif
+__global__ void collapse_plan_kernel(BinaryNodes N, uint32_t first, uint32_t count, float4* plan)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count)
+        return;
+    const uint32_t id = first + k;
+    const float4 lo = N.lo[id], hi = N.hi[id];
+    const float area = box_half_area(f3(lo.x, lo.y, lo.z), f3(hi.x, hi.y, hi.z));
+    if (N.size[id] <= (uint32_t)kMaxLeafTris) {
+        const float c = area * NEB_COLLAPSE_CLEAF;
+        plan[id] = make_float4(c, c, c, __uint_as_float(0u));
+        return;
+    }
+    const float4 pl = plan[__float_as_int(lo.w)], pr = plan[__float_as_int(hi.w)];
+    const float cl[4] = {0.f, pl.x, pl.y, pl.z}, cr[4] = {0.f, pr.x, pr.y, pr.z};
+    uint32_t k4 = 1u;
+    float d4 = cl[1] + cr[3];
+    if (cl[2] + cr[2] < d4)
+        d4 = cl[2] + cr[2], k4 = 2u;
+    if (cl[3] + cr[1] < d4)
+        d4 = cl[3] + cr[1], k4 = 3u;
+    const float c1 = area * NEB_COLLAPSE_CNODE + d4;
+    const float d2 = cl[1] + cr[1];
+    const float c2 = fminf(c1, d2);
+    uint32_t k3 = 0u;
+    float c3 = c2;
+    if (cl[1] + cr[2] < c3)
+        c3 = cl[1] + cr[2], k3 = 1u;
+    if (cl[2] + cr[1] < c3)
+        c3 = cl[2] + cr[1], k3 = 2u;
+    plan[id] = make_float4(c1, c2, c3, __uint_as_float(k4 | (d2 < c1 ? 4u : 0u) | (k3 << 3)));
+}
+
+// the entries (binary node ids) that cover `node` when it may take up to `budget` slots of a wide node, left to right
+__device__ __forceinline__ void collapse_expand(const CollapseArgs& a, int node, int budget, int* out, int& n_out)
+{
+    int st_node[8], st_budget[8];
+    int sp = 0;
+    st_node[sp] = node, st_budget[sp++] = budget;
+    while (sp) {
+        --sp;
+        const int x = st_node[sp];
+        int b = st_budget[sp];
+        if (b <= 1 || collapse_is_leaf(a.N, x)) {
+            out[n_out++] = x;
+            continue;
+        }
+        const uint32_t bits = __float_as_uint(a.plan[x].w);
+        int kl = 0; // slots of the left child; 0 = the node stays whole at this budget
+        if (b >= 3) {
+            const uint32_t k3 = (bits >> 3) & 3u;
+            if (k3)
+                kl = (int)k3;
+            else
+                b = 2; // C(n,3) == C(n,2)
+        }
+        if (b == 2 && kl == 0)
+            kl = (bits & 4u) ? 1 : 0;
+        if (kl == 0) {
+            out[n_out++] = x;
+            continue;
+        }
+        // right below left on the stack: the left subtree comes out first
+        st_node[sp] = __float_as_int(a.N.hi[x].w), st_budget[sp++] = b - kl;
+        st_node[sp] = __float_as_int(a.N.lo[x].w), st_budget[sp++] = kl;
+    }
+}
 
 __global__ void collapse_open_kernel(CollapseArgs a)
 {
@@ -503,7 +590,16 @@ __global__ void collapse_open_kernel(CollapseArgs a)
     const int bn = (int)a.q_node[e];
     int c[4] = {__float_as_int(a.N.lo[bn].w), __float_as_int(a.N.hi[bn].w), -1, -1};
     int nc = 2;
-    while (nc < 4) { // open the inner child with the largest surface area
+    if (a.plan) { // the cost-optimal choice (collapse_plan_kernel)
+        const int k4 = (int)(__float_as_uint(a.plan[bn].w) & 3u);
+        const int l = c[0], r = c[1];
+        nc = 0;
+        collapse_expand(a, l, k4, c, nc);
+        collapse_expand(a, r, 4 - k4, c, nc);
+        for (int q = nc; q < 4; ++q)
+            c[q] = -1;
+    }
+    while (!a.plan && nc < 4) { // (A/B arm, NEB_COLLAPSE_DP = 0) open the inner child with the largest surface area
         int best = -1;
         float best_area = -1.0f;
         for (int q = 0; q < nc; ++q) {
@@ -960,6 +1056,10 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     uint32_t* d_icount = (uint32_t*)dalloc((size_t)n * 4, false);
     uint32_t* d_iscan = (uint32_t*)dalloc((size_t)n * 4, false);
     float4* d_shade = (float4*)dalloc((size_t)n * 128, true);
+#ifndef NEB_COLLAPSE_DP
+#define NEB_COLLAPSE_DP 1 // 1: cost-optimal BVH4 collapse (collapse_plan_kernel); 0: the greedy largest-box rule (A/B arm)
+#endif
+    float4* d_plan = NEB_COLLAPSE_DP ? (float4*)dalloc(n2 * 16, false) : nullptr;
     size_t cub_bytes = 0, cub_b2 = 0, cub_b3 = 0;
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b2, d_flags, d_scan, (int)n, stream);
@@ -1008,6 +1108,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     BUILD_HIP(hipGetLastError());
     uint32_t passes = 0;
     const uint32_t root_node = n; // (only meaningful when n > kMaxLeafTris)
+    std::vector<uint32_t> pass_first{n, n + 1u}; // node ids [pass_first[p], pass_first[p + 1]) were created together: the root, then one SAH pass each
     if (n > (uint32_t)kMaxLeafTris) {
         const SahSegment root_seg{0u, n, root_node};
         float minus_one;
@@ -1042,11 +1143,13 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             hipLaunchKernelGGL(sah_emit_kernel, grid, dim3(256), 0, stream, N, segs, (const SahSplit*)d_splits, n_segs, (const unsigned long long*)d_flags,
                                (const unsigned long long*)d_scan, (const uint32_t*)idx_out, rs, ws, d_segs[(passes + 1u) & 1u]);
             BUILD_HIP(hipGetLastError());
-            uint32_t next = 0;
-            BUILD_HIP(hipMemcpyAsync(&next, ws, 4, hipMemcpyDeviceToHost, stream));
+            uint32_t next_state[2] = {0u, 0u}; // {segments of the next level, next free node id}
+            BUILD_HIP(hipMemcpyAsync(next_state, ws, 8, hipMemcpyDeviceToHost, stream));
             BUILD_HIP(hipStreamSynchronize(stream));
-            if (next > n)
+            const uint32_t next = next_state[0];
+            if (next > n || next_state[1] > 2u * n || next_state[1] < pass_first.back())
                 return bail(NEB_ERR_HIP, "neb_gi_build_bvh: segment bound exceeded (internal error)");
+            pass_first.push_back(next_state[1]);
             n_segs = next;
             ++passes;
         }
@@ -1071,6 +1174,16 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
         a.inner_count = d_icount;
         a.inner_scan = d_iscan;
         a.level_state = d_state + 4;
+        a.plan = d_plan;
+        if (d_plan) { // cost of every subtree as 1, 2 or 3 entries of a wide node: triangles first, then bottom-up, one SAH pass at a time
+            hipLaunchKernelGGL(collapse_plan_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, N, 0u, n, d_plan);
+            for (size_t lv = pass_first.size() - 1; lv-- > 0;) {
+                const uint32_t first = pass_first[lv], count = pass_first[lv + 1] - first;
+                if (count)
+                    hipLaunchKernelGGL(collapse_plan_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, N, first, count, d_plan);
+            }
+            BUILD_HIP(hipGetLastError());
+        }
         BUILD_HIP(hipMemcpyAsync(d_qnode, &root_node, 4, hipMemcpyHostToDevice, stream));
         BUILD_HIP(hipMemsetAsync(d_qoff, 0, 4, stream));
         BUILD_HIP(hipStreamSynchronize(stream));
