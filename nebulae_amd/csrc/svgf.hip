@@ -25,11 +25,17 @@
 #ifndef NEB_ATROUS_PRIO // 0: no s_setprio; 1: a workgroup's priority = the tiles it still has to do (default)
 #define NEB_ATROUS_PRIO 1
 #endif
-#ifndef NEB_ATROUS_R_NARROW // rows per lane of the LDS kernel at steps <= 4: 4; 3 = A/B arm (4 workgroups per CU: measured the same, 34.5 against 34.1 us)
+#ifndef NEB_ATROUS_R_NARROW // rows per lane of the LDS kernel at steps <= 4: 4; A/B arms: 3 (4 workgroups per CU: the same, 34.5 against 34.1 us), 2 (34.3 against 32.4)
 #define NEB_ATROUS_R_NARROW 4
 #endif
 #ifndef NEB_ATROUS_STORE // how the LDS kernel stores its output: 1 write-through (sc1, default), 0 plain, 2 non-temporal (A/B arms)
 #define NEB_ATROUS_STORE 1
+#endif
+#ifndef NEB_ATROUS_WX8 // 64-column blocks per tile at step 8 / at steps 16 and 32: 1; 2 = A/B arm (128-column tiles, eight waves)
+#define NEB_ATROUS_WX8 1
+#endif
+#ifndef NEB_ATROUS_WX16
+#define NEB_ATROUS_WX16 1
 #endif
 #ifndef NEB_ATROUS_STAMPS // diagnostic builds only (tools/atrous_stamps.py): per-wave phase times from s_memtime
 #define NEB_ATROUS_STAMPS 0
@@ -346,22 +352,27 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
 //   last level writes radiance[cur], which still holds the frame's input) or from the fused staging (kInFused).
 enum : int { kInClassic = 0, kInLum = 1, kInFused = 2 };
 
-template <int S, int R, int IN>
+// WX: 64-column blocks per tile.  With 2, a workgroup of eight waves shares the 4 S halo columns over 128 columns (1.5 x the
+// columns staged per output at S = 16 instead of 2) -- measured SLOWER, 39.2 against 36.2 us at S = 16 and 35.3 against 31.9 at
+// S = 8: two large workgroups per CU leave the SIMDs idle at their barriers more than the smaller halo saves.  Product: 1.
+template <int S, int R, int IN, int WX = 1>
 struct AtrousTile {
-    static constexpr int BW = 64, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4, TOTAL = ROWS * COLS;
-    static constexpr int NLOAD = (TOTAL + 255) / 256;
+    static constexpr int THREADS = 256 * WX;
+    static constexpr int BW = 64 * WX, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4, TOTAL = ROWS * COLS;
+    static constexpr int NLOAD = (TOTAL + THREADS - 1) / THREADS;
     // kInFused keeps {variance, alpha} of the tile's own pixels in a third, small plane
     static constexpr int LDS_BYTES = TOTAL * 2 * 16 + (IN == kInFused ? BH * BW * 8 : 0);
     // workgroups per CU: what the 160 KB of LDS hold, at most 5 (R <= 2) / 3 -- also the register budget the kernel is compiled for
     static constexpr int PER_CU = (R <= 2 ? 5 : (R == 3 ? 4 : 3)) < (160 * 1024) / LDS_BYTES ? (R <= 2 ? 5 : (R == 3 ? 4 : 3)) : (160 * 1024) / LDS_BYTES;
+    static constexpr int WAVES_PER_SIMD = PER_CU * WX < 8 ? PER_CU * WX : 8; // launch bound: k blocks of T threads per CU <=> k T / 256 waves per SIMD
 };
 
-template <int S, int R, int IN, bool OUT_ALPHA>
-__global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atrous_lds_kernel(AtrousArgs a)
+template <int S, int R, int IN, bool OUT_ALPHA, int WX = 1>
+__global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD)) void svgf_atrous_lds_kernel(AtrousArgs a)
 {
-    using T = AtrousTile<S, R, IN>;
-    constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD;
-    static_assert(IN != kInFused || S == 1, "the fused temporal staging is level 0");
+    using T = AtrousTile<S, R, IN, WX>;
+    constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD, THREADS = T::THREADS;
+    static_assert(IN != kInFused || (S == 1 && WX == 1), "the fused temporal staging is level 0");
     extern __shared__ float4 lds[];
     float4* __restrict__ A = lds;               // {r, g, b, lum}
     float4* __restrict__ B = lds + ROWS * COLS; // {nx, ny, nz, z}
@@ -378,6 +389,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
     const float4* __restrict__ geometry = a.geometry;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (wave-uniform: row bases and row addresses become scalar)
+    const int rg = wv & 3, cb = wv >> 2; // the wave's row group (R lattice rows) and 64-column block of the tile
 
     // Tile walk, XCD-aware: workgroups b, b+8, ... share an XCD (and its L2); each XCD takes a contiguous
     // run of tiles, and the workgroups of an XCD interleave inside that run.  Speed only.
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
             if (!toff_regular) {
 #pragma unroll
                 for (int k = 0; k < NLOAD; ++k) {
-                    const int i = threadIdx.x + 256 * k;
+                    const int i = threadIdx.x + THREADS * k;
                     const int lr = i / COLS;
                     toff[k] = (uint32_t)(lr * S * a.W + (i - lr * COLS)) * 16u;
                 }
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
             toff_regular = false;
 #pragma unroll
             for (int k = 0; k < NLOAD; ++k) {
-                const int i = threadIdx.x + 256 * k;
+                const int i = threadIdx.x + THREADS * k;
                 const int lr = i / COLS, lc = i - lr * COLS;
                 // clamp to the image (svgf_atrous.hlsl:65), then to the resident rows: a partial tile also stages rows
                 // that no valid output taps; on a row strip those may lie outside the allocation, so they are
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
     // kInClassic: the next tile's radiance, into registers
     auto issue_load = [&](int k, const Tile& o) {
         if constexpr (IN == kInClassic) {
-            if (threadIdx.x + 256 * k < TOTAL)
+            if (threadIdx.x + THREADS * k < TOTAL)
                 pc[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + o.first) + toff[k]);
         }
     };
@@ -455,10 +467,10 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
     auto issue_dma = [&](const float4* plane, float4* dst_lds, const Tile& o) {
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
-            if (threadIdx.x + 256 * k < TOTAL) {
+            if (threadIdx.x + THREADS * k < TOTAL) {
                 const char* g = reinterpret_cast<const char*>(plane + o.first) + toff[k];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(dst_lds + 256 * k + 64 * wv), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst_lds + THREADS * k + 64 * wv), 16, 0, 0);
             }
         }
     };
@@ -470,10 +482,10 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
     float nalpha[R];
     auto issue_centre_loads = [&](const Tile& o) {
         if constexpr (IN != kInFused) {
-            const int xo = o.x0 + lane;
+            const int xo = o.x0 + cb * 64 + lane;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int yo = o.r + S * (o.jbase + wv * R + k);
+                const int yo = o.r + S * (o.jbase + rg * R + k);
                 nvar[k] = 0u;
                 nalpha[k] = 0.f;
                 if (xo < a.Wd && yo < a.row1) {
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
                 lum[k] = luminance(pc[k].x, pc[k].y, pc[k].z);
 #pragma unroll
             for (int k = 0; k < NLOAD; ++k) {
-                const int i = threadIdx.x + 256 * k;
+                const int i = threadIdx.x + THREADS * k;
                 if (i < TOTAL)
                     A[i] = make_float4(pc[k].x, pc[k].y, pc[k].z, lum[k]);
             }
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
             size_t gi[NLOAD];
 #pragma unroll
             for (int k = 0; k < NLOAD; ++k) {
-                const int i = threadIdx.x + 256 * k;
+                const int i = threadIdx.x + THREADS * k;
                 own[k] = false;
                 if (i < TOTAL) {
                     const size_t e = nt.first + (toff[k] >> 4);
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
             }
 #pragma unroll
             for (int k = 0; k < NLOAD; ++k) {
-                const int i = threadIdx.x + 256 * k;
+                const int i = threadIdx.x + THREADS * k;
                 if (i < TOTAL) {
                     const float4 Cc = A[i], Ch = B[i];
                     float3 Nc;
@@ -618,24 +630,24 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
 
         NEB_STAMP(3);
         // ---- filter the current tile ----
-        const int xo = cx0 + lane;
+        const int xo = cx0 + cb * 64 + lane;
         float z0[R], n0x[R], n0y[R], n0z[R], lum0[R], cl[R], alpha0[R];
         float sr[R], sg[R], sb[R], sw[R];
         bool valid[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int lr = wv * R + k + 2;
-            const float4 cA = A[lr * COLS + lane + 2 * S];
-            const float4 cB = B[lr * COLS + lane + 2 * S];
+            const int lr = rg * R + k + 2;
+            const float4 cA = A[lr * COLS + cb * 64 + lane + 2 * S];
+            const float4 cB = B[lr * COLS + cb * 64 + lane + 2 * S];
             z0[k] = cB.w;
             n0x[k] = cB.x;
             n0y[k] = cB.y;
             n0z[k] = cB.z;
             lum0[k] = cA.w;
-            const int yo = cr + S * (cjbase + wv * R + k);
+            const int yo = cr + S * (cjbase + rg * R + k);
             valid[k] = (xo < a.Wd) && (yo < a.row1);
             if constexpr (IN == kInFused) {
-                const float2 va = V[(wv * R + k) * BW + lane]; // (a pixel that is not valid holds stale values: never stored)
+                const float2 va = V[(rg * R + k) * BW + lane]; // (a pixel that is not valid holds stale values: never stored)
                 alpha0[k] = va.y;
                 cl[k] = lum_scale(va.x, a.phiColor);
             } else {
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
         // trip five times per row.
         float4 gA[2][3], gB[2][3];
         auto load_group = [&](int g) {
-            const int ir = g >> 1, lrow_base = (wv * R + ir) * COLS + lane + 2 * S;
+            const int ir = g >> 1, lrow_base = (rg * R + ir) * COLS + cb * 64 + lane + 2 * S;
             if ((g & 1) == 0) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -704,7 +716,7 @@ __global__ __launch_bounds__(256, (AtrousTile<S, R, IN>::PER_CU)) void svgf_atro
         for (int k = 0; k < R; ++k) {
             if (!valid[k])
                 continue;
-            const int yo = cr + S * (cjbase + wv * R + k);
+            const int yo = cr + S * (cjbase + rg * R + k);
             const float inv = fast_rcp(fmaxf(sw[k], 1e-4f)); // :84
             const float r = sr[k] * inv, g = sg[k] * inv, b = sb[k] * inv;
             store_output(a.dst + ((size_t)(yo - a.row_begin) * a.W + xo), make_float4(r, g, b, OUT_ALPHA ? alpha0[k] : luminance(r, g, b)));
@@ -764,17 +776,17 @@ extern "C" int neb_debug_atrous_stamps(unsigned long long* host, uint32_t* grids
 // tile i, one barrier per tile -- 45-94 us per level against 41-49 us for the kernel above; the longer live
 // ranges cost more than the barrier and the exposed decode they remove.  Round 3: the geometry texels prefetched into
 // registers like the radiance instead of the DMA at the tile boundary: 45 us per level against 35.)
-template <int S, int R, int IN, bool OUT_ALPHA>
+template <int S, int R, int IN, bool OUT_ALPHA, int WX = 1>
 static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t s)
 {
-    using T = AtrousTile<S, R, IN>;
+    using T = AtrousTile<S, R, IN, WX>;
     constexpr size_t lds_bytes = (size_t)T::LDS_BYTES;
     // the dynamic-LDS limit is a per-device function attribute: remember which devices have it (one bit each; a
     // device ordinal beyond the mask just sets it on every launch)
     static std::atomic<uint64_t> attr_set{0};
     const uint64_t bit = (device >= 0 && device < 64) ? (1ull << device) : 0ull;
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&svgf_atrous_lds_kernel<S, R, IN, OUT_ALPHA>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&svgf_atrous_lds_kernel<S, R, IN, OUT_ALPHA, WX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return e;
@@ -794,7 +806,7 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
 #if NEB_ATROUS_STAMPS
     a.stamps = atrous_stamp_buffer(S, grid);
 #endif
-    hipLaunchKernelGGL((svgf_atrous_lds_kernel<S, R, IN, OUT_ALPHA>), dim3(grid), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((svgf_atrous_lds_kernel<S, R, IN, OUT_ALPHA, WX>), dim3(grid), dim3(T::THREADS), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -807,9 +819,9 @@ static hipError_t launch_lds_step(const AtrousArgs& a, uint32_t step, int device
     case 1: return launch_lds<1, NEB_ATROUS_R_NARROW, IN, OUT_ALPHA>(a, device, num_cus, s);
     case 2: return launch_lds<2, NEB_ATROUS_R_NARROW, IN, OUT_ALPHA>(a, device, num_cus, s);
     case 4: return launch_lds<4, NEB_ATROUS_R_NARROW, IN, OUT_ALPHA>(a, device, num_cus, s);
-    case 8: return launch_lds<8, 2, IN, OUT_ALPHA>(a, device, num_cus, s);
-    case 16: return launch_lds<16, 2, IN, OUT_ALPHA>(a, device, num_cus, s);
-    case 32: return launch_lds<32, 2, IN, OUT_ALPHA>(a, device, num_cus, s);
+    case 8: return launch_lds<8, 2, IN, OUT_ALPHA, NEB_ATROUS_WX8>(a, device, num_cus, s);
+    case 16: return launch_lds<16, 2, IN, OUT_ALPHA, NEB_ATROUS_WX16>(a, device, num_cus, s);
+    case 32: return launch_lds<32, 2, IN, OUT_ALPHA, NEB_ATROUS_WX16>(a, device, num_cus, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -868,6 +880,8 @@ hipError_t launch_atrous_lum(const SvgfLaunch& L, uint32_t step, bool last, cons
         return hipSuccess;
     a.alpha_src = dst; // the last level writes the plane that still holds the frame's input: its alpha is carried
     const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
+    // (the last level's alpha read from its destination -- 4 of every 16 bytes -- is hidden under the arithmetic: 35.9 us with it,
+    // 35.6 without)
     return last ? launch_lds_step<kInLum, true>(a, step, L.device, num_cus, s) : launch_lds_step<kInLum, false>(a, step, L.device, num_cus, s);
 }
 
