@@ -464,10 +464,12 @@ def main(argv=None, rt=None, emit=None):
         # same loader the tests use; the camera stays the reference's Sponza view
         sc = S.load_gltf(args.scene)
         scene_label = f"{os.path.basename(args.scene)}"
+        # the reference's Sponza view for a Sponza file (Nebulae's default scene), otherwise a camera that frames the scene's box
+        cam = S.sponza_camera() if "sponza" in scene_label.lower() else S.framing_camera(sc)
     else:
         sc = S.atrium_standin(target_triangles=args.triangles, tex_size=args.tex_size)
         scene_label = "sponza-standin"
-    cam = S.sponza_camera()
+        cam = S.sponza_camera()
     scheme = None if args.scheme == "auto" else args.scheme
 
     def workload_label(gw, gh, spp, levels, gi=True):

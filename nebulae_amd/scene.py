@@ -698,6 +698,14 @@ def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex
     return sc
 
 
+def framing_camera(sc):
+    """A view of a whole scene from outside its box (bench.py --scene with a file that is not Sponza): the reference's orbit
+    camera (InspectCamera.h:31-42) about the box centre, far enough for the vertical field of view to hold the box."""
+    lo, hi = sc.world_aabb()
+    centre, radius = 0.5 * (lo + hi), 0.5 * float(np.linalg.norm(hi - lo))
+    return orbit_camera(origin=tuple(float(v) for v in centre), yaw_deg=12.0, pitch_deg=70.0, distance=max(2.2 * radius, 0.2))
+
+
 def sponza_camera():
     """Reference default orbit camera (InspectCamera.h:52-55): origin (0,0,0), yaw 0, pitch 90 deg, distance 3 ->
     eye (0,0,3) looking down -z; moved up to eye height inside the atrium so the view is not degenerate."""

@@ -42,6 +42,18 @@ def test_single_gpu_line():
     assert 0 < d["frame_roofline"]["frac"] < d["svgf_roofline"]["frac"] < 1
 
 
+def test_scene_file_replaces_the_stand_in():
+    """bench.py --scene <file>: a real glTF file through the same loader (what a dropped-in Sponza.glb would take)."""
+    scene = os.path.join(ROOT, "tests", "golden", "DamagedHelmet_jpeg.glb")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--cpu-frames", "0", "--scene", scene,
+                        "--width", "1280", "--height", "720", "--levels", "3"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert "DamagedHelmet_jpeg.glb 1280x720 (15452 triangles, 1 submeshes, 1 materials, 3 textures of 2048^2)" in d["config"]["workload"]
+    assert d["config"]["bvh"]["triangles"] == 15452 and d["value"] > 0 and d["mrays_per_s"] > 0
+    assert "scene file DamagedHelmet_jpeg.glb" in d["data"]
+
+
 @pytest.mark.parametrize("scheme", ["once", "per_level"])
 def test_two_rank_rehearsal(scheme):
     env = dict(os.environ, NEB_BENCH_SHARE_DEVICE="1", NEB_BENCH_BACKEND="gloo", NEB_STRIPS_SCHEME=scheme)
