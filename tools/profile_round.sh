@@ -44,6 +44,8 @@ for f in glob.glob(f"profiles/{tag}_*.json"):
         d["build_id"] = bid
         json.dump(d, open(f, "w"), indent=1)
 PY
+# the bench line once more, now that this build's counter summaries exist: it quotes them (roofline.traffic / .valu)
+python bench.py $extra > "$out/bench2.json" 2>> "$out/bench.err" && cp "$out/bench2.json" "profiles/${tag}_bench.json"
 mkdir -p "$out/profiles" && cp profiles/${tag}_* "$out/profiles/"
 python - "$tag" <<'PY'
 import csv, sys
