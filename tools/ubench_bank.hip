@@ -47,6 +47,58 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s)
         asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, v26, v8\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v24, v10\n v_fma_f32 v24, v16, v16, v16\n v_fma_f32 v11, v16, v25, v11\n v_fma_f32 v12, v21, v30, v12\n v_fma_f32 v13, v22, v31, v13\n"
                                     "v_fma_f32 v14, v23, v28, v14\n v_fma_f32 v15, v20, v29, v15\n v_fma_f32 v8, v17, v26, v8\n v_fma_f32 v25, v17, v17, v17\n v_fma_f32 v9, v18, v27, v9\n v_fma_f32 v10, v19, v28, v10\n v_fma_f32 v11, v16, v29, v11\n") LOOP_END
                      : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 7) // inline constant as the third source (no constant-bus read?)
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, v26, 1.0\n v_fma_f32 v9, v18, v27, 1.0\n v_fma_f32 v10, v19, v24, 1.0\n v_fma_f32 v11, v16, v25, 1.0\n"
+                                    "v_fma_f32 v12, v21, v30, 1.0\n v_fma_f32 v13, v22, v31, 1.0\n v_fma_f32 v14, v23, v28, 1.0\n v_fma_f32 v15, v20, v29, 1.0\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 8) // 32-bit literal (VOP2 encoding)
+        asm volatile(INIT_REGS REP8("v_max_f32 v8, 0x3c23d70a, v17\n v_max_f32 v9, 0x3c23d70a, v18\n v_max_f32 v10, 0x3c23d70a, v19\n v_max_f32 v11, 0x3c23d70a, v16\n"
+                                    "v_max_f32 v12, 0x3c23d70a, v21\n v_max_f32 v13, 0x3c23d70a, v22\n v_max_f32 v14, 0x3c23d70a, v23\n v_max_f32 v15, 0x3c23d70a, v20\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 9) // the same instruction with a VGPR in place of the literal
+        asm volatile(INIT_REGS REP8("v_max_f32 v8, v26, v17\n v_max_f32 v9, v27, v18\n v_max_f32 v10, v24, v19\n v_max_f32 v11, v25, v16\n"
+                                    "v_max_f32 v12, v30, v21\n v_max_f32 v13, v31, v22\n v_max_f32 v14, v28, v23\n v_max_f32 v15, v29, v20\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 10) // v_cndmask with its lane mask in an SGPR pair (VOP3) against VCC (VOP2)
+        asm volatile("s_mov_b64 s[22:23], 0x5555\n s_mov_b64 vcc, 0x5555\n" INIT_REGS REP8("v_cndmask_b32_e64 v8, v17, v26, s[22:23]\n v_cndmask_b32_e64 v9, v18, v27, s[22:23]\n v_cndmask_b32_e64 v10, v19, v24, s[22:23]\n v_cndmask_b32_e64 v11, v16, v25, s[22:23]\n"
+                                    "v_cndmask_b32_e64 v12, v21, v30, s[22:23]\n v_cndmask_b32_e64 v13, v22, v31, s[22:23]\n v_cndmask_b32_e64 v14, v23, v28, s[22:23]\n v_cndmask_b32_e64 v15, v20, v29, s[22:23]\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS, "s22", "s23", "vcc");
+    if constexpr (MODE == 11)
+        asm volatile("s_mov_b64 vcc, 0x5555\n" INIT_REGS REP8("v_cndmask_b32_e32 v8, v17, v26, vcc\n v_cndmask_b32_e32 v9, v18, v27, vcc\n v_cndmask_b32_e32 v10, v19, v24, vcc\n v_cndmask_b32_e32 v11, v16, v25, vcc\n"
+                                    "v_cndmask_b32_e32 v12, v21, v30, vcc\n v_cndmask_b32_e32 v13, v22, v31, vcc\n v_cndmask_b32_e32 v14, v23, v28, vcc\n v_cndmask_b32_e32 v15, v20, v29, vcc\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS, "vcc");
+    if constexpr (MODE == 12) // v_cvt_f32_ubyteN (the quantised node's plane decode)
+        asm volatile(INIT_REGS REP8("v_cvt_f32_ubyte0 v8, v17\n v_cvt_f32_ubyte1 v9, v18\n v_cvt_f32_ubyte2 v10, v19\n v_cvt_f32_ubyte3 v11, v16\n"
+                                    "v_cvt_f32_ubyte0 v12, v21\n v_cvt_f32_ubyte1 v13, v22\n v_cvt_f32_ubyte2 v14, v23\n v_cvt_f32_ubyte3 v15, v20\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 13) // v_max3 / v_min3 (three sources)
+        asm volatile(INIT_REGS REP8("v_max3_f32 v8, v17, v26, v8\n v_min3_f32 v9, v18, v27, v9\n v_max3_f32 v10, v19, v24, v10\n v_min3_f32 v11, v16, v25, v11\n"
+                                    "v_max3_f32 v12, v21, v30, v12\n v_min3_f32 v13, v22, v31, v13\n v_max3_f32 v14, v23, v28, v14\n v_min3_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 14)
+        asm volatile(INIT_REGS REP8("v_add_f32 v8, v17, v8\n v_add_f32 v9, v18, v9\n v_add_f32 v10, v19, v10\n v_add_f32 v11, v16, v11\n"
+                                    "v_add_f32 v12, v21, v12\n v_add_f32 v13, v22, v13\n v_add_f32 v14, v23, v14\n v_add_f32 v15, v20, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 15)
+        asm volatile(INIT_REGS REP8("v_sub_f32 v8, v17, v26\n v_sub_f32 v9, v18, v27\n v_sub_f32 v10, v19, v24\n v_sub_f32 v11, v16, v25\n"
+                                    "v_sub_f32 v12, v21, v30\n v_sub_f32 v13, v22, v31\n v_sub_f32 v14, v23, v28\n v_sub_f32 v15, v20, v29\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 16)
+        asm volatile(INIT_REGS REP8("v_mul_f32 v8, v17, v26\n v_mul_f32 v9, v18, v27\n v_mul_f32 v10, v19, v24\n v_mul_f32 v11, v16, v25\n"
+                                    "v_mul_f32 v12, v21, v30\n v_mul_f32 v13, v22, v31\n v_mul_f32 v14, v23, v28\n v_mul_f32 v15, v20, v29\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 17) // fma with source modifiers (-|a|) and the clamp output modifier
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, -|v17|, v26, v8 clamp\n v_fma_f32 v9, -|v18|, v27, v9 clamp\n v_fma_f32 v10, -|v19|, v24, v10 clamp\n v_fma_f32 v11, -|v16|, v25, v11 clamp\n"
+                                    "v_fma_f32 v12, -|v21|, v30, v12 clamp\n v_fma_f32 v13, -|v22|, v31, v13 clamp\n v_fma_f32 v14, -|v23|, v28, v14 clamp\n v_fma_f32 v15, -|v20|, v29, v15 clamp\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 18) // a - b written as fma(b, -1.0, a)
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v26, -1.0, v17\n v_fma_f32 v9, v27, -1.0, v18\n v_fma_f32 v10, v24, -1.0, v19\n v_fma_f32 v11, v25, -1.0, v16\n"
+                                    "v_fma_f32 v12, v30, -1.0, v21\n v_fma_f32 v13, v31, -1.0, v22\n v_fma_f32 v14, v28, -1.0, v23\n v_fma_f32 v15, v29, -1.0, v20\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 19) // v_pk_fma_f32 (two fmas per lane and instruction)
+        asm volatile(INIT_REGS REP8("v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_pk_fma_f32 v[12:13], v[20:21], v[30:31], v[12:13]\n v_pk_fma_f32 v[14:15], v[22:23], v[28:29], v[14:15]\n"
+                                    "v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_pk_fma_f32 v[12:13], v[20:21], v[30:31], v[12:13]\n v_pk_fma_f32 v[14:15], v[22:23], v[28:29], v[14:15]\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
     if constexpr (MODE == 6)
         asm volatile(INIT_REGS REP8("v_fmac_f32 v8, v17, v26\n v_fmac_f32 v9, v18, v27\n v_fmac_f32 v10, v19, v24\n v_fmac_f32 v11, v16, v25\n"
                                     "v_fmac_f32 v12, v21, v30\n v_fmac_f32 v13, v22, v31\n v_fmac_f32 v14, v23, v28\n v_fmac_f32 v15, v20, v29\n") LOOP_END
@@ -75,12 +127,25 @@ static void run(const char* name, int blocks_per_cu, int per_iter)
 
 int main()
 {
-    for (int w : {1, 2, 3, 4, 6}) {
+    for (int w : {3, 8}) {
         run<0>("fma v, v, s, const (1 VGPR source)", w, 64);
         run<3>("fma v, v, s, v (2 VGPR sources, 2 banks)", w, 64);
         run<1>("fma v, v, v, v (3 VGPR sources, 3 banks)", w, 64);
         run<2>("fma v, v, v, v (3 VGPR sources, 1 bank)", w, 64);
         run<6>("fmac v, v, v (VOP2; 3 VGPR sources, 3 banks)", w, 64);
+        run<7>("fma v, v, v, 1.0 (inline constant source)", w, 64);
+        run<8>("v_max_f32 v, literal, v (32-bit literal, VOP2)", w, 64);
+        run<9>("v_max_f32 v, v, v (VOP2)", w, 64);
+        run<10>("v_cndmask_b32 v, v, v, s[n:n+1] (mask in SGPRs, VOP3)", w, 64);
+        run<11>("v_cndmask_b32 v, v, v, vcc (VOP2)", w, 64);
+        run<12>("v_cvt_f32_ubyteN v, v", w, 64);
+        run<13>("v_max3_f32 / v_min3_f32 v, v, v, v", w, 64);
+        run<14>("v_add_f32 v, v, v (VOP2)", w, 64);
+        run<15>("v_sub_f32 v, v, v (VOP2)", w, 64);
+        run<16>("v_mul_f32 v, v, v (VOP2)", w, 64);
+        run<17>("v_fma_f32 v, -|v|, v, v clamp (modifiers)", w, 64);
+        run<18>("v_fma_f32 v, v, -1.0, v (a - b as an fma)", w, 64);
+        run<19>("v_pk_fma_f32 (per instruction = two fmas per lane)", w, 64);
         run<4>("tap mix: 12 three-source fma + v_log + v_exp", w, 112);
         run<5>("tap mix with the transcendentals as fma", w, 112);
     }
