@@ -612,6 +612,10 @@ def main(argv=None, rt=None, emit=None):
                                   "frac": fused_bytes / t_svgf_chain / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s",
                                   "fused_launch": {"bytes_per_px": TEMPORAL_BYTES_PX, "us": per_level[0] * 1e6,
                                                    "frac": TEMPORAL_BYTES_PX * own_px / per_level[0] / 1e9 / HBM_PEAK_GBPS,
+                                                   # the same launch under SURVEY 8d's unfused model: it does the work of the temporal
+                                                   # pass (82 B/px) and of level 0 (46 B/px)
+                                                   "bytes_per_px_8d": TEMPORAL_BYTES_PX + ATROUS_BYTES_PX,
+                                                   "frac_8d": (TEMPORAL_BYTES_PX + ATROUS_BYTES_PX) * own_px / per_level[0] / 1e9 / HBM_PEAK_GBPS,
                                                    "traffic": traffic[2] if traffic else None},
                                   "note": "temporal + level 0 as one launch: 60 B read + 6 B moments / variance + 16 B level-0 output = 82 B/px; "
                                           "the accumulated radiance is never written or re-read"} if (fused and L > 0) else None),
