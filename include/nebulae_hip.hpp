@@ -70,7 +70,18 @@ namespace Neb
 
         void ResetHistory(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_reset_history(m_ctx, commandList), "neb_svgf_reset_history"); }
         void SubmitTemporalAccumulation(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_temporal(m_ctx, commandList), "neb_svgf_temporal"); }
+        // (called right after SubmitTemporalAccumulation on the same command list -- DeferredRenderer::SubmitCommandsSVGFDenoising's
+        // order -- the two run as one fused chain: see neb_svgf_atrous in nebulae_hip.h)
         void SubmitATrousComputeWavelet(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_atrous(m_ctx, commandList), "neb_svgf_atrous"); }
+        // Implementation knobs without a reference counterpart ("svgf_fuse", "svgf_profile", "atrous_variant", the "gi_*" options)
+        void SetOption(const char* key, int value) { ThrowIfFailed(m_ctx, neb_set_option(m_ctx, key, value), "neb_set_option"); }
+        // Durations (us) of the kernels of the last SubmitATrousComputeWavelet chain, after SetOption("svgf_profile", 1); returns how many
+        uint32_t LevelTimes(float* outMicroseconds, uint32_t capacity)
+        {
+            uint32_t n = 0;
+            ThrowIfFailed(m_ctx, neb_svgf_level_times(m_ctx, outMicroseconds, capacity, &n), "neb_svgf_level_times");
+            return n;
+        }
 
         // GetTemporalConstants()/GetATrousConstants(): one POD with the six tunables (SVGFDenoiser.h:76-92).
         neb_svgf_params GetConstants() const
