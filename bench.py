@@ -79,7 +79,7 @@ def library_build_id():
     h = hashlib.sha1()
     for d in (os.path.join(ROOT, "nebulae_amd", "csrc"), os.path.join(ROOT, "include")):
         for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".h", ".hpp")):
+            if f.endswith((".hip", ".h")):  # (what libnebulae_hip.so is compiled from: not the header-only C++ mirror)
                 h.update(f.encode())
                 h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
