@@ -42,6 +42,17 @@ def test_single_gpu_line():
     assert 0 < d["frame_roofline"]["frac"] < d["svgf_roofline"]["frac"] < 1
 
 
+def test_single_gpu_line_with_the_separate_kernels():
+    """NEB_BENCH_NO_FUSE=1: option svgf_fuse = 0 -- the temporal pass as its own kernel, level times still from the library's events."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--cpu-frames", "0", "--tex-size", "256"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, NEB_BENCH_NO_FUSE="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    ku = d["kernel_us"]
+    assert ku["temporal"] > 0 and ku["fused_temporal_level0"] is None and len(ku["atrous_levels"]) == 5 and all(t > 0 for t in ku["atrous_levels"])
+    assert d["svgf_fused_model"] is None and 0 < d["temporal_roofline"]["frac"] < 1 and 0 < d["roofline"]["frac"] < 1
+
+
 def test_scene_file_replaces_the_stand_in():
     """bench.py --scene <file>: a real glTF file through the same loader (what a dropped-in Sponza.glb would take)."""
     scene = os.path.join(ROOT, "tests", "golden", "DamagedHelmet_jpeg.glb")
