@@ -14,14 +14,17 @@ from strip_harness import LockstepStrips
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scheme", ["once", "per_level"])
-def test_two_strips_equal_full_image_gi_plus_svgf(scheme):
-    W, H, L, N = 256, 192, 5, 2
+@pytest.mark.parametrize("scheme,W,H,N", [("once", 256, 192, 2), ("per_level", 256, 192, 2),
+                                          # the bench's N = 8 shape: ONE 1920x1080 frame in eight 135-row strips (halo 62 rows)
+                                          ("once", 1920, 1080, 8), ("per_level", 1920, 1080, 8)])
+def test_strips_equal_full_image_gi_plus_svgf(scheme, W, H, N):
+    """(the full image runs the fused SVGF chain, the strips the separate kernels: the comparison is also fused == separate)"""
+    L = 5
     sc = S.atrium_standin(target_triangles=20000, n_submeshes=40, tex_size=32)
     cam = S.sponza_camera()
     full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
     ls = LockstepStrips(W, H, N, L, scheme)
-    for f in range(1, 6):
+    for f in range(1, 6 if N == 2 else 5):
         info = RenderInfo(scene=sc, camera=cam, frame_index=f)
         for r in [full] + ls.rs:
             r.begin_frame(info)
