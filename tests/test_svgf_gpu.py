@@ -141,6 +141,28 @@ def test_held_back_temporal_pass_is_submitted_by_any_other_call():
     d.destroy()
 
 
+def test_level_times_need_the_profile_option_and_report_one_duration_per_kernel():
+    W, H, L = 256, 128, 4
+    d = make(W, H, L)
+    g, rad = frame_inputs(W, H, 1, None)
+    feed(d, None, 1, g, rad)
+    d.submit_temporal_accumulation()
+    d.submit_atrous_compute_wavelet()
+    with pytest.raises(NebError):
+        d.level_times()  # option svgf_profile is off
+    for fuse in (1, 0):
+        d.set_option("svgf_fuse", fuse)
+        d.set_option("svgf_profile", 1)
+        feed(d, None, 2, g, rad)
+        d.submit_temporal_accumulation()
+        d.submit_atrous_compute_wavelet()
+        t = d.level_times()
+        assert len(t) == L and all(0.0 < x < 1e5 for x in t)
+        d.set_option("svgf_profile", 0)
+        d.end_frame()
+    d.destroy()
+
+
 @pytest.mark.parametrize("step_level", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("variant", [1, 0])
 def test_single_atrous_level_matches_oracle(step_level, variant):
