@@ -81,7 +81,7 @@ def test_fused_chain_matches_golden(path):
     d.destroy()
 
 
-@pytest.mark.parametrize("W,H,L", [(64, 48, 1), (136, 104, 2), (200, 136, 5), (328, 176, 6), (1920, 1080, 5)])
+@pytest.mark.parametrize("W,H,L", [(8, 8, 3), (16, 24, 4), (64, 48, 1), (136, 104, 2), (200, 136, 5), (328, 176, 6), (1920, 1080, 5)])
 def test_fused_chain_equals_separate_kernels_bit_for_bit(W, H, L):
     """The fused chain and the stand-alone kernels (option svgf_fuse = 0: what a row strip runs) give the same bits in
     everything a caller may read afterwards: radiance[cur] (alpha carried from the frame's input), moments[cur], variance
