@@ -63,7 +63,7 @@ def parse(argv=None):
     ap.add_argument("--exchange", choices=("torch", "rccl"), default=None,
                     help="N > 1: halo transport -- torch.distributed P2P on the planes, or the library's own neb_strips_exchange (RCCL); "
                          "default: NEB_STRIPS_EXCHANGE or torch")
-    ap.add_argument("--scheme", choices=("once", "per_level", "auto"), default="auto",
+    ap.add_argument("--scheme", choices=("once", "per_level", "overlap", "auto"), default="auto",
                     help="N > 1: halo exchange scheme (auto: the cheaper one by strips.choose_scheme's cost table)")
     ap.add_argument("--config5", action="store_true", help="also run BASELINE.json configs[4] (default: only when N = 8)")
     ap.add_argument("--config5-frames", type=int, default=32, help="frames of the config-5 sequence (half moving, half still)")
@@ -393,7 +393,7 @@ class Workload:
         if self.world == 1:
             return "single GPU"
         return (f"row-strips x{self.world} of {p.H // p.N} rows + halo exchange over RCCL: scheme '{p.scheme}' ({p.scheme_reason}; "
-                f"{'one exchange per frame' if p.scheme == 'once' else 'one exchange per a-trous level'}, {p.exchanged_bytes_per_frame() / 1e6:.1f} MB sent "
+                f"{ {'once': 'one exchange per frame', 'per_level': 'one exchange per a-trous level', 'overlap': 'two exchanges per frame, GI recomputed on the overlap rows'}[p.scheme]}, {p.exchanged_bytes_per_frame() / 1e6:.1f} MB sent "
                 f"per rank and frame), transport '{self.r.exchange}' ({'neb_strips_exchange: grouped ncclSend / ncclRecv' if self.r.exchange == 'rccl' else 'torch.distributed batch_isend_irecv on the planes'})")
 
     def destroy(self):

@@ -22,7 +22,14 @@ Two exchange schemes (``StripPartition(scheme=...)``, both bit-identical to one 
 ``"per_level"`` -- L exchanges per frame: before level l the 2 * 2^l boundary rows of that level's source plane
   are swapped; every level runs on owned rows only; halo = 2 * 2^(L-1).
 
-Both move 62 radiance rows per direction and frame at L = 5; rows are contiguous row blocks sent straight out of
+``"overlap"`` -- SURVEY.md 8e's scheme from north_star: every rank ALSO traces, accumulates and filters levels 0 .. L-2 on
+  B = sum_{l<=L-2} 2*2^l rows (30 for L = 5) beyond its strip -- the GI dispatch is a pure function of the pixel and the
+  frame, so the copies agree bit for bit -- then swaps the 2*2^(L-1) (32) boundary rows of level L-2's output, runs the widest
+  level on its own rows, and finally swaps B rows of the FINAL image so that both copies of next frame's radiance history agree
+  (quirk 5: the filtered output is the history).  Two exchanges of 32 + 30 rows; the redundancy is paid in the GI stage, three
+  quarters of the frame, which is why the cost table never picks it -- built so that the three can be measured.
+
+All move 62 radiance rows per direction and frame at L = 5; rows are contiguous row blocks sent straight out of
 the plane (``torch.distributed`` P2P, backend "nccl" = RCCL over xGMI; one direct link per neighbour).
 
 The compute backend is injected (``denoiser_factory``): the product uses the HIP ``SVGFDenoiser``;
@@ -46,6 +53,7 @@ def frame_factors(n):
 # conservative guesses for the xGMI side until an N > 1 run replaces them -- override with NEB_STRIPS_EXCHANGE_LATENCY_US /
 # NEB_STRIPS_LINK_GBPS):
 ATROUS_US_PER_MPX_LEVEL = 16.0   # one a-trous level over a megapixel (33 us per 2.07 Mpx level at 1080p, profiles/r03*)
+GI_TEMPORAL_US_PER_MPX = 300.0   # the GI dispatch + the temporal pass over a megapixel (590 + 30 us per 2.07 Mpx)
 EXCHANGE_LATENCY_US = 12.0       # one grouped send + receive with a neighbour, launch to completion, message size aside
 LINK_GBPS = 60.0                 # sustained one-direction rate of one xGMI link for row blocks of a few hundred KB
 
@@ -65,7 +73,11 @@ def scheme_costs(width, height, world, levels):
     level0 = rows * width * 1e-6 * ATROUS_US_PER_MPX_LEVEL
     once = redundant_rows * width * 1e-6 * ATROUS_US_PER_MPX_LEVEL + max(0.0, once_x - level0)
     per_level = sum(lat + 2 * (1 << l) * width * 16 / (gbps * 1e3) for l in range(levels))
-    return {"once": once, "per_level": per_level}
+    band = sum(2 * (1 << l) for l in range(levels - 1))
+    ext = [sum(2 * (1 << m) for m in range(l + 1, levels - 1)) for l in range(levels - 1)]
+    overlap = (2 * band * width * 1e-6 * (GI_TEMPORAL_US_PER_MPX + 0.0) + sum(2 * e for e in ext) * width * 1e-6 * ATROUS_US_PER_MPX_LEVEL
+               + 2 * lat + (2 * (1 << (levels - 1)) + band) * width * 16 / (gbps * 1e3))
+    return {"once": once, "per_level": per_level, "overlap": overlap}
 
 
 def choose_scheme(width, height, world, levels):
@@ -76,8 +88,9 @@ def choose_scheme(width, height, world, levels):
     halo_once = 2 * ((1 << levels) - 1)
     if height // world < halo_once:
         return "per_level", f"strips of {height // world} rows are shorter than the {halo_once}-row halo of 'once'"
-    pick = "once" if c["once"] <= c["per_level"] else "per_level"
-    return pick, f"cost table: once +{c['once']:.0f} us, per_level +{c['per_level']:.0f} us per frame at {height // world}-row strips"
+    pick = min(("once", "per_level", "overlap"), key=lambda k: c[k])
+    return pick, (f"cost table: once +{c['once']:.0f} us, per_level +{c['per_level']:.0f} us, overlap +{c['overlap']:.0f} us per frame at "
+                  f"{height // world}-row strips")
 
 
 class StripPartition:
@@ -90,11 +103,13 @@ class StripPartition:
             self.scheme, self.scheme_reason = choose_scheme(width, height, world, levels)
         else:
             self.scheme, self.scheme_reason = scheme, "requested"
-        if self.scheme not in ("once", "per_level"):
+        if self.scheme not in ("once", "per_level", "overlap"):
             raise ValueError(f"unknown exchange scheme {self.scheme!r}")
         self.W, self.H, self.N, self.L = width, height, world, levels
+        # "overlap": rows beyond the strip on which GI, the temporal pass and levels 0 .. L-2 are recomputed
+        self.band = sum(2 * (1 << l) for l in range(levels - 1)) if (self.scheme == "overlap" and world > 1) else 0
         if world > 1 and levels > 0:
-            self.halo = 2 * ((1 << levels) - 1) if self.scheme == "once" else 2 * (1 << (levels - 1))
+            self.halo = 2 * ((1 << levels) - 1) if self.scheme == "once" else 2 * (1 << (levels - 1))  # (overlap: max(band, widest reach) = the reach)
         else:
             self.halo = 0
         if world > 1 and height // world < self.halo:
@@ -109,13 +124,20 @@ class StripPartition:
         return max(0, a - self.halo), min(self.H, b + self.halo)
 
     def rows_temporal(self, r):
-        a, b = self.owned(r)
+        a, b = self.gi_rows(r)
         return b - a
+
+    def gi_rows(self, r):
+        """image rows [row0, row1) on which rank r runs the GI dispatch and the temporal pass: its strip (+- the band of "overlap")"""
+        a, b = self.owned(r)
+        return max(0, a - self.band), min(self.H, b + self.band)
 
     def level_extension(self, level):
         """rows beyond the owned strip that `level` must also filter: what the later levels still reach into"""
-        if self.N == 1 or self.scheme != "once":
+        if self.N == 1 or self.scheme == "per_level":
             return 0
+        if self.scheme == "overlap":  # levels 0 .. L-2 are local: what levels l+1 .. L-2 still reach into; the widest level: nothing
+            return sum(2 * (1 << m) for m in range(level + 1, self.L - 1))
         return sum(2 * (1 << m) for m in range(level + 1, self.L))
 
     def atrous_rows(self, r, level):
@@ -138,14 +160,23 @@ class StripPartition:
         return self._swap(r, self.halo) if (self.scheme == "once" and self.halo) else []
 
     def level_exchange(self, r, level):
-        """scheme "per_level": the same for the source plane of `level`"""
-        return self._swap(r, 2 * (1 << level)) if (self.scheme == "per_level" and self.N > 1) else []
+        """scheme "per_level": the same for the source plane of `level`; scheme "overlap": for the widest level only"""
+        if self.N > 1 and (self.scheme == "per_level" or (self.scheme == "overlap" and level == self.L - 1)):
+            return self._swap(r, 2 * (1 << level))
+        return []
+
+    def history_exchange(self, r):
+        """scheme "overlap": after the last level, the rows of the FINAL image that lie in the neighbours' bands (their copies of
+        next frame's radiance history)"""
+        return self._swap(r, self.band) if (self.scheme == "overlap" and self.band) else []
 
     def exchanged_bytes_per_frame(self):
         """bytes a middle rank sends per frame (both neighbours)"""
         if self.N == 1:
             return 0
         rows = sum(2 * (1 << l) for l in range(self.L))
+        if self.scheme == "overlap":
+            rows = 2 * (1 << (self.L - 1)) + self.band
         return 2 * rows * self.W * (16 + 2 if self.scheme == "once" else 16)
 
 
@@ -227,7 +258,7 @@ class StripRenderer(DeferredRenderer):
         return self._views[key][row0 - base:row1 - base]
 
     def submit_commands_gi_pathtrace(self, rows=None, stream=None):
-        super().submit_commands_gi_pathtrace(rows=self.part.owned(self.rank) if rows is None else rows, stream=stream)
+        super().submit_commands_gi_pathtrace(rows=self.part.gi_rows(self.rank) if rows is None else rows, stream=stream)
 
     def _staging_mode(self, sample):
         """How halo rows travel, decided ONCE and COLLECTIVELY (every rank must post the same operations):
@@ -363,7 +394,7 @@ class StripRenderer(DeferredRenderer):
             return True
         if events is not None:
             events["t0"].record()
-        self.svgf.submit_temporal_accumulation(st, rows=own)
+        self.svgf.submit_temporal_accumulation(st, rows=self.part.gi_rows(self.rank))
         if events is not None:
             events["t1"].record()
         per_level = events.get("levels") if events is not None else None
@@ -371,7 +402,7 @@ class StripRenderer(DeferredRenderer):
         once = self.part.N > 1 and self.part.scheme == "once"
         for level in range(L):
             rows = self.part.atrous_rows(self.rank, level)
-            if self.part.N > 1 and self.part.scheme == "per_level":
+            if self.part.level_exchange(self.rank, level):  # "per_level": every level; "overlap": the widest one
                 self.exchange_halo(level)
             if per_level is not None:
                 per_level[level][0].record()
@@ -391,6 +422,9 @@ class StripRenderer(DeferredRenderer):
                 self.svgf.submit_atrous_level(level, rows, st)
             if per_level is not None:
                 per_level[level][1].record()
+        if self.part.history_exchange(self.rank):  # "overlap": both copies of next frame's history must hold the FINAL rows
+            (dp, ds) = self.svgf.atrous_level_planes(L - 1)[1] if L > 1 else (PLANE_RADIANCE, self.svgf.get_current_resource_index())
+            self._swap_rows([(dp, ds)], self.part.history_exchange(self.rank))
         if events is not None and "a1" in events:
             events["a1"].record()  # (with "t1": brackets all levels with two events only)
         if L == 1:  # single level filters into the scratch plane: copy the owned rows back (api.hip: neb_svgf_atrous)

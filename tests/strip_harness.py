@@ -37,7 +37,7 @@ class LockstepStrips:
             if r.reset_history:
                 r.reset_history = False
                 r.svgf.reset_history()
-            r.svgf.submit_temporal_accumulation(rows=part.owned(r.rank))
+            r.svgf.submit_temporal_accumulation(rows=part.gi_rows(r.rank))
         torch.cuda.synchronize()
         if self.scheme == "once":
             for k, r in enumerate(rs):
@@ -45,13 +45,16 @@ class LockstepStrips:
                 self._pull(k, [(PLANE_RADIANCE, cur), (PLANE_VARIANCE, 0)], part.frame_exchange(k))
         for level in range(L):
             torch.cuda.synchronize()
-            if self.scheme == "per_level":
-                for k, r in enumerate(rs):
-                    (sp, ss), _ = r.svgf.atrous_level_planes(level)
-                    self._pull(k, [(sp, ss)], part.level_exchange(k, level))
+            for k, r in enumerate(rs):  # "per_level": every level; "overlap": the widest one
+                (sp, ss), _ = r.svgf.atrous_level_planes(level)
+                self._pull(k, [(sp, ss)], part.level_exchange(k, level))
             torch.cuda.synchronize()
             for r in rs:
                 r.svgf.submit_atrous_level(level, part.atrous_rows(r.rank, level))
+        torch.cuda.synchronize()
+        for k, r in enumerate(rs):  # "overlap": the final rows inside the neighbours' bands (next frame's history)
+            (dp, ds) = r.svgf.atrous_level_planes(L - 1)[1] if L > 1 else (PLANE_RADIANCE, r.svgf.get_current_resource_index())
+            self._pull(k, [(dp, ds)], part.history_exchange(k))
         if L == 1:
             for r in rs:
                 cur = r.svgf.get_current_resource_index()

@@ -106,7 +106,7 @@ class DryRuntime:
                 self.svgf.plane_tensor(PLANE_RADIANCE, cur).copy_(torch.from_numpy(synth.synth_radiance(self._g["base"][r0:r1], 1)))
 
             def submit_commands_gi_pathtrace(self, rows=None, stream=None):
-                own = self.part.owned(self.rank)
+                own = self.part.gi_rows(self.rank) if rows is None else rows
                 r0, _ = self._rows()
                 cur = self.svgf.get_current_resource_index()
                 t = self.svgf.plane_tensor(PLANE_RADIANCE, cur)
@@ -135,7 +135,7 @@ def _rank_main(rank, world, port, argv, out_path):
         assert not lines
 
 
-@pytest.mark.parametrize("world,scheme", [(8, "auto"), (2, "per_level")])
+@pytest.mark.parametrize("world,scheme", [(8, "auto"), (2, "per_level"), (4, "overlap")])
 def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     # 8 strips need >= 62 rows each for the one-exchange scheme at 5 levels: 64 x 512 frames; the config-5 leg runs at its own
     # (shrunk) size with its moving-then-still camera; --gather adds the final gather after every frame
@@ -153,7 +153,7 @@ def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     assert cfg["global_width"] == 64 and cfg["global_height"] == 512 and cfg["rows_per_strip"] == 512 // world
     want_scheme = "once" if scheme == "auto" else scheme
     assert f"scheme '{want_scheme}'" in cfg["parallelism"] and f"row-strips x{world}" in cfg["parallelism"]
-    a, b = (2, 4) if world == 8 else (1, 2)
+    a, b = {8: (2, 4), 4: (2, 2), 2: (1, 2)}[world]
     ws = d["weak_scaling"]
     assert ws["global_width"] == 64 * a and ws["global_height"] == 512 * b and ws["frames_per_s_1080p_equivalents"] > 0
     c5 = d["config5"]

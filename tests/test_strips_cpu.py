@@ -36,6 +36,13 @@ def test_partition_geometry():
     assert q.frame_exchange(1) == [] and q.atrous_rows(1, 0) == q.owned(1)
     assert q.exchanged_bytes_per_frame() == 2 * 62 * 3840 * 16  # 62 rows per direction
     assert strips.frame_factors(1) == (1, 1) and strips.frame_factors(4) == (2, 2) and strips.frame_factors(8) == (2, 4)
+    # SURVEY.md 8e's overlapped scheme: GI / temporal / levels 0..3 on +-30 rows, 32 rows before the widest level, 30 rows of history after it
+    v = strips.StripPartition(3840, 2160, 4, 5, scheme="overlap")
+    assert v.band == 30 and v.halo == 32 and v.gi_rows(0) == (0, 570) and v.gi_rows(2) == (1050, 1650) and v.resident(1) == (508, 1112)
+    assert [v.level_extension(l) for l in range(5)] == [28, 24, 16, 0, 0] and v.atrous_rows(1, 0) == (512, 1108) and v.atrous_rows(1, 4) == (540, 1080)
+    assert v.level_exchange(1, 3) == [] and v.level_exchange(1, 4) == [(0, (540, 572), (508, 540)), (2, (1048, 1080), (1080, 1112))]
+    assert v.history_exchange(1) == [(0, (540, 570), (510, 540)), (2, (1050, 1080), (1080, 1110))] and v.frame_exchange(1) == []
+    assert v.exchanged_bytes_per_frame() == 2 * 62 * 3840 * 16 and q.history_exchange(1) == [] and p.gi_rows(1) == p.owned(1)
     one = strips.StripPartition(1920, 1080, 1, 5)
     assert one.halo == 0 and one.resident(0) == (0, 1080) and one.level_exchange(0, 3) == [] and one.frame_exchange(0) == []
     assert one.atrous_rows(0, 2) == (0, 1080)
@@ -60,8 +67,8 @@ def _run_frames(r, part, rank, frames, moving_frame=None):
         cur = r.svgf.get_current_resource_index()
         r.svgf.plane_tensor(PLANE_DEPTH, cur).copy_(torch.from_numpy(g["depth"][res0:res1].view(np.int32)))
         r.svgf.plane_tensor(PLANE_NORMAL, cur).copy_(torch.from_numpy(g["normal"][res0:res1]))
-        own0, own1 = part.owned(rank)
-        r.svgf.plane_tensor(PLANE_RADIANCE, cur)[own0 - res0:own1 - res0].copy_(torch.from_numpy(rad[own0:own1]))
+        g0, g1 = part.gi_rows(rank)  # the rows this rank "renders": its strip (+- the band of the overlap scheme)
+        r.svgf.plane_tensor(PLANE_RADIANCE, cur)[g0 - res0:g1 - res0].copy_(torch.from_numpy(rad[g0:g1]))
         ran.append(r.submit_commands_svgf_denoising())
         r.end_frame()
     cur = r.svgf.get_current_resource_index()
@@ -90,7 +97,8 @@ def _worker(rank, world, port, W, H, L, nframes, moving_frame, out_dir, scheme):
 
 @pytest.mark.parametrize("world,W,H,L,moving,scheme", [(2, 64, 144, 5, None, "once"), (3, 72, 120, 4, None, "once"), (2, 64, 80, 3, 2, "once"),
                                                         (2, 40, 64, 1, None, "once"), (2, 64, 144, 5, None, "per_level"),
-                                                        (3, 72, 120, 4, 3, "per_level")])
+                                                        (3, 72, 120, 4, 3, "per_level"), (2, 64, 144, 5, None, "overlap"),
+                                                        (3, 72, 120, 4, 3, "overlap"), (2, 40, 64, 1, None, "overlap")])
 def test_strips_equal_single_process_bit_for_bit(tmp_path, world, W, H, L, moving, scheme):
     from oracle_backend import OracleDenoiser
     nframes = 4

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("scheme,W,H,N", [("once", 256, 192, 2), ("per_level", 256, 192, 2),
                                           # the bench's N = 8 shape: ONE 1920x1080 frame in eight 135-row strips (halo 62 rows)
-                                          ("once", 1920, 1080, 8), ("per_level", 1920, 1080, 8)])
+                                          ("once", 1920, 1080, 8), ("per_level", 1920, 1080, 8),
+                                          ("overlap", 256, 192, 2), ("overlap", 1920, 1080, 8)])
 def test_strips_equal_full_image_gi_plus_svgf(scheme, W, H, N):
     """(the full image runs the fused SVGF chain, the strips the separate kernels: the comparison is also fused == separate)"""
     L = 5
