@@ -110,7 +110,8 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "atrous_variant": 1 = LDS row-lattice kernel (default; 4 rows per lane for steps <= 4, 2 for steps 8..32; wider steps take the
  *                     direct kernel), 0 = direct-load kernel;
  *   "gi_debug_hits":  1 = neb_gi_trace also records a neb_gi_hit per pixel (needs a scene);
- *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (default on),
+ *   "gi_sort_rays":   mask, bit 0 = radix-sort the shadow rays by origin Morton code before tracing them (until the option is set:
+ *                     on for dispatches of 1.5 M pixels and more, off for smaller ones, where the sort costs more than it saves),
  *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
  *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it;
  *   "gi_exact_shade":   1 = hit shading in the C arithmetic of the CPU oracle (IEEE division, sqrt, powf, sinf / cosf) instead of

@@ -133,6 +133,7 @@ struct GiState {
     bool defer_resolve = false;
     bool exact_shade = false; // "gi_exact_shade": gi_shade_kernel<false>, the oracle's C arithmetic
     bool sort_shadow = true;  // "gi_sort_rays" bit 0
+    bool sort_shadow_auto = true; // until "gi_sort_rays" is set: sort the shadow rays of dispatches of 1.5 M pixels and more only
     bool sort_bounce = false; // "gi_sort_rays" bit 1
     uint32_t* d_sort = nullptr;      // 4 x npx uint32: keys, vals, keys_out, vals_out
     void* d_sort_temp = nullptr;

@@ -248,11 +248,13 @@ __host__ __device__ constexpr float atrous_log2k(int dx, int dy)
     return lx + ly;
 }
 
-// max(0, dot(n0, n)) of svgf_atrous.hlsl:74, saturated: the [0, 1] clamp is the free output modifier of the dot
-// product's last fma (a bare max(x, 0) is a separate v_max per tap).  Two unit normals can give 1 + 2 ulp, where the
-// reference's pow(d, 128) would be 1 + 3e-5 and this is 1 -- a deliberate divergence, the same in both
-// kernels so that every path and every level is one function.
-__device__ __forceinline__ float normal_dot_sat(float d) { return fminf(fmaxf(d, 0.0f), 1.0f); }
+// max(0, dot(n0, n)) of svgf_atrous.hlsl:74 at no instruction: the centre normal arrives HALVED (exact), so the dot product is
+// d / 2 and the free [0, 1] clamp of its last fma is max(0, d) / 2 for every d <= 2 -- normals decoded from RGBA16F are unit
+// only to ~1e-3, d does exceed 1, and pow(d, 128) is then up to 1.14, which a clamp of d itself to [0, 1] would lose (rounds 1-2
+// had that divergence; a bare max(x, 0) is a separate v_max per tap).  log2(d / 2) = log2(d) - 1: the tap's constant carries the
+// + phiNormal that undoes it (`tap_constant`).
+__device__ __forceinline__ float half_dot_max0(float dh) { return fminf(fmaxf(dh, 0.0f), 1.0f); }
+__device__ __forceinline__ float tap_constant(float phiN, int dx, int dy) { return phiN + atrous_log2k(dx, dy); }
 
 __device__ __forceinline__ float lum_scale(float var_f, float phiColor)
 {
@@ -261,12 +263,13 @@ __device__ __forceinline__ float lum_scale(float var_f, float phiColor)
 }
 
 // One tap (svgf_atrous.hlsl:67-81): w = Kx*Ky * exp(-|dz|/(phiDepth*step)) * pow(max(0,d), phiNormal) * exp(-|dl|/denL) as ONE
-// exp2: exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d == 0 -> -inf -> weight 0)
-__device__ __forceinline__ float tap_weight(float n0x, float n0y, float n0z, float z0, float lum0, float cl, float4 tA, float4 tB, float phiN, float cz,
-                                            float lk)
+// exp2: exponent = log2(Kx*Ky) + phiNormal*log2(d) - |dz|*cz - |dl|*cl   (d <= 0 -> -inf -> weight 0)
+// h0 = the centre normal halved, lkp = tap_constant(phiN, dx, dy) = log2(Kx*Ky) + phiN.
+__device__ __forceinline__ float tap_weight(float h0x, float h0y, float h0z, float z0, float lum0, float cl, float4 tA, float4 tB, float phiN, float cz,
+                                            float lkp)
 {
-    const float d = normal_dot_sat(fmaf(n0z, tB.z, fmaf(n0y, tB.y, n0x * tB.x)));
-    float e = fmaf(phiN, NEB_TAP_LOG2(d), lk);
+    const float dh = half_dot_max0(fmaf(h0z, tB.z, fmaf(h0y, tB.y, h0x * tB.x)));
+    float e = fmaf(phiN, NEB_TAP_LOG2(dh), lkp);
     e = fmaf(-fabsf(z0 - tB.w), cz, e);
     e = fmaf(-fabsf(lum0 - tA.w), cl, e);
     return NEB_TAP_EXP2(e);
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
             const int qx = min(max(x + dx * a.step, 0), a.W - 1);
             const float4 c = a.src[rowoff + qx];
             const float4 g = a.geometry[rowoff + qx];
-            const float w = tap_weight(g0.x, g0.y, g0.z, g0.w, lum0, cl, make_float4(c.x, c.y, c.z, luminance(c.x, c.y, c.z)), g, a.phiNormal, a.cz,
-                                       atrous_log2k(dx, dy));
+            const float w = tap_weight(0.5f * g0.x, 0.5f * g0.y, 0.5f * g0.z, g0.w, lum0, cl, make_float4(c.x, c.y, c.z, luminance(c.x, c.y, c.z)), g,
+                                       a.phiNormal, a.cz, tap_constant(a.phiNormal, dx, dy));
             sr = fmaf(w, c.x, sr);
             sg = fmaf(w, c.y, sg);
             sb = fmaf(w, c.z, sb);
@@ -518,6 +521,16 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
     // in this kernel the difference does not show: 192.5 against 192.0 us per frame)
     float cz = a.cz, phiN = a.phiNormal;
     asm volatile("" : "+v"(cz), "+v"(phiN));
+    // log2(Kx Ky) + phiN of the six tap classes (|dx|, |dy| in {0, 1, 2}), held in registers: computed per tap it would be an add each
+    float lkp[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            lkp[i][j] = tap_constant(phiN, i, j);
+            asm volatile("" : "+v"(lkp[i][j]));
+            lkp[j][i] = lkp[i][j];
+        }
 
     NEB_STAMP(0);
     while (have) {
@@ -642,9 +655,9 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
             const float4 cA = A[lr * COLS + cb * 64 + lane + 2 * S];
             const float4 cB = B[lr * COLS + cb * 64 + lane + 2 * S];
             z0[k] = cB.w;
-            n0x[k] = cB.x;
-            n0y[k] = cB.y;
-            n0z[k] = cB.z;
+            n0x[k] = 0.5f * cB.x; // halved: see half_dot_max0
+            n0y[k] = 0.5f * cB.y;
+            n0z[k] = 0.5f * cB.z;
             lum0[k] = cA.w;
             const int yo = cr + S * (cjbase + rg * R + k);
             valid[k] = (xo < a.Wd) && (yo < a.row1);
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                     const int dy = ir - k - 2;
                     if (dy < -2 || dy > 2)
                         continue;
-                    const float w = tap_weight(n0x[k], n0y[k], n0z[k], z0[k], lum0[k], cl[k], tA, tB, phiN, cz, atrous_log2k(dx, dy));
+                    const float w = tap_weight(n0x[k], n0y[k], n0z[k], z0[k], lum0[k], cl[k], tA, tB, phiN, cz, lkp[dx < 0 ? -dx : dx][dy < 0 ? -dy : dy]);
                     sr[k] = fmaf(w, tA.x, sr[k]);
                     sg[k] = fmaf(w, tA.y, sg[k]);
                     sb[k] = fmaf(w, tA.z, sb[k]);

@@ -110,6 +110,33 @@ def test_fused_chain_equals_separate_kernels_bit_for_bit(W, H, L):
     b.destroy()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0])
+def test_normal_weight_is_max0_not_saturate(variant, fuse):
+    """svgf_atrous.hlsl:74 is pow(max(0, dot(n0, n)), phiNormal): normals out of an RGBA16F target are unit only to ~1e-3 and
+    the dot product does exceed 1.  With normals 3 % too long pow(1.06, 128) is ~1.7e3 between parallel normals and ~0.3 across
+    a 20-degree crease -- a [0, 1] clamp of the dot product (rounds 1-2 had one) moves the filtered frame by far more than the
+    tolerance.  Both kernels (LDS tiles / direct), fused and level-wise."""
+    W, H, L = 192, 96, 3
+    d, o = make(W, H, L), OracleSVGF(W, H, L)
+    d.set_option("atrous_variant", variant)
+    d.set_option("svgf_fuse", fuse)
+    for f in (1, 2):
+        g, rad = frame_inputs(W, H, f, None)
+        g = dict(g)
+        n = g["normal"].astype(np.float32)
+        n[..., :3] *= 1.03
+        g["normal"] = n.astype(np.float16)
+        feed(d, o, f, g, rad)
+        d.submit_temporal_accumulation()
+        d.submit_atrous_compute_wavelet()
+        o.temporal_pass()
+        o.atrous_pass()
+        assert rel_l2(d.download(PLANE_RADIANCE), o.radiance[o.cur]) < TOL_E2E
+        d.end_frame()
+    d.destroy()
+
+
 def test_held_back_temporal_pass_is_submitted_by_any_other_call():
     """neb_svgf_temporal on a whole-frame context is held back for the fused chain; every other entry point that looks at the
     planes submits it first (the stand-alone kernel), so a caller never sees the difference."""
