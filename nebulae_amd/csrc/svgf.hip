@@ -433,9 +433,13 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         if (interior) {
             o.first = (size_t)(y_first - a.row_begin) * a.W + x_first;
             if (!toff_regular) {
+                // (the lane index made opaque: computed from threadIdx.x these loop-invariant offsets are hoisted out of the tile
+                // loop and held in NLOAD more registers for the whole kernel -- which the fused kernel does not have)
+                int tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
 #pragma unroll
                 for (int k = 0; k < NLOAD; ++k) {
-                    const int i = threadIdx.x + THREADS * k;
+                    const int i = tid + THREADS * k;
                     const int lr = i / COLS;
                     toff[k] = (uint32_t)(lr * S * a.W + (i - lr * COLS)) * 16u;
                 }
@@ -520,17 +524,24 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
     // than a third VGPR source does, tools/ubench_bank.hip: 1.83 against 1.25 ns per wave-instruction at three waves per SIMD;
     // in this kernel the difference does not show: 192.5 against 192.0 us per frame)
     float cz = a.cz, phiN = a.phiNormal;
-    asm volatile("" : "+v"(cz), "+v"(phiN));
-    // log2(Kx Ky) + phiN of the six tap classes (|dx|, |dy| in {0, 1, 2}), held in registers: computed per tap it would be an add each
+    // log2(Kx Ky) + phiN of the six tap classes (|dx|, |dy| in {0, 1, 2}), set up once: computed per tap it would be an add each.
+    // The levels hold all eight constants in vector registers.  The fused kernel has none to spare (168 = the budget of three
+    // waves per SIMD; with them it spilled five, and a kernel that needs scratch memory right after the GI kernels, which use
+    // theirs at another size, waits for the queue's scratch set-up: 57.7 us per launch against 50.9): there they are scalar operands.
     float lkp[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = i; j < 3; ++j) {
             lkp[i][j] = tap_constant(phiN, i, j);
-            asm volatile("" : "+v"(lkp[i][j]));
+            if constexpr (IN == kInFused)
+                lkp[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lkp[i][j])));
+            else
+                asm volatile("" : "+v"(lkp[i][j]));
             lkp[j][i] = lkp[i][j];
         }
+    if constexpr (IN != kInFused)
+        asm volatile("" : "+v"(cz), "+v"(phiN));
 
     NEB_STAMP(0);
     while (have) {
