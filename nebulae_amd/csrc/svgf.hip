@@ -19,6 +19,12 @@
 #include "neb_internal.h"
 
 // Tuning / diagnostic switches (tools/build_variant.sh): the product is built with none of them set.
+#ifndef NEB_ATROUS_PER_CU_R2 // most workgroups per CU of the R = 2 tiles (= waves per SIMD = the register budget: 4 -> 128 registers)
+#define NEB_ATROUS_PER_CU_R2 4
+#endif
+#ifndef NEB_ATROUS_XGROUP // pixels per column group of the x lattice (see AtrousTile); >= 64 = consecutive columns at every step
+#define NEB_ATROUS_XGROUP 8
+#endif
 #ifndef NEB_ATROUS_NOTRANS // timing only (wrong results): v_log / v_exp replaced by full-rate instructions
 #define NEB_ATROUS_NOTRANS 0
 #endif
@@ -328,10 +334,11 @@ __global__ __launch_bounds__(256) void svgf_atrous_direct_kernel(AtrousArgs a)
 }
 
 // LDS kernel: row-lattice tiles, persistent workgroups.
-//   Workgroup = 256 lanes = 4 waves.  Output tile = BW (64) consecutive columns x BH (= 4R)
+//   Workgroup = 256 lanes = 4 waves.  Output tile = BW (64) columns x BH (= 4R)
 //   rows of the lattice {r + S*j}.  Taps of a lattice row are lattice rows j-2..j+2, so the
-//   tile needs only BH+4 image rows (each a contiguous, coalesced segment of BW+4S texels)
-//   for any step S: read amplification (1 + 4/BH)(1 + 4S/BW) instead of (1 + 4S/T)^2.
+//   tile needs only BH+4 image rows for any step S; its columns are consecutive up to S = 8 (BW + 4 S staged) and a lattice of
+//   8-pixel groups beyond (BW + 32 staged at any step, AtrousTile below): read amplification (1 + 4/BH)(1 + 32/BW) instead
+//   of (1 + 4S/T)^2.
 //   Two float4 LDS planes, lane-contiguous (ds_read_b128, conflict-free): A = {r, g, b, lum} and B = {nx, ny, nz, z}
 //   (= the texels of the frame's decoded geometry plane).  Wave w filters lattice rows [w*R, w*R+R): a lane walks its
 //   column's R+4 staged rows once and feeds each staged texel to every output row it is a tap of.
@@ -358,15 +365,31 @@ enum : int { kInClassic = 0, kInLum = 1, kInFused = 2 };
 // WX: 64-column blocks per tile.  With 2, a workgroup of eight waves shares the 4 S halo columns over 128 columns (1.5 x the
 // columns staged per output at S = 16 instead of 2) -- measured SLOWER, 39.2 against 36.2 us at S = 16 and 35.3 against 31.9 at
 // S = 8: two large workgroups per CU leave the SIMDs idle at their barriers more than the smaller halo saves.  Product: 1.
+//
+// The columns of a tile.  Up to S = 8 a tile's 64 output columns are consecutive and it stages 64 + 4 S of them.  Beyond, that halo
+// doubles and triples the tile (128 staged columns per 64 outputs at S = 16), so the columns form a lattice too, in GROUPS of
+// XS = 8 pixels (128 bytes of a plane = one L2 line: every load and store instruction still touches whole lines): local column c is
+// pixel x0 + xcol(c) = x0 + (c / XS - 2) S + c % XS.  A tap at +-S, +-2 S is then one or two groups = XS or 2 XS local columns away
+// for every lane, the halo is 4 XS = 32 columns at any step (S = 16: 96 staged columns instead of 128, four workgroups per CU instead
+// of three), and S / XS tiles whose x0 differ by XS interleave over the same span of (64 / XS) S pixels.  For S <= XS this is the
+// plain layout.  Measured inside the frame (same box): S = 16 33.2 us against 34.9; with groups of 4 pixels (64 bytes, 80 staged
+// columns) 35.6 -- an LDS-DMA instruction then touches sixteen half lines instead of eight whole ones.
 template <int S, int R, int IN, int WX = 1>
 struct AtrousTile {
     static constexpr int THREADS = 256 * WX;
-    static constexpr int BW = 64 * WX, BH = 4 * R, COLS = BW + 4 * S, ROWS = BH + 4, TOTAL = ROWS * COLS;
+    static constexpr int XS = S < NEB_ATROUS_XGROUP ? S : NEB_ATROUS_XGROUP; // pixels per column group = the tap stride in local columns
+    static constexpr int XM = S / XS;                                        // interleaved tiles per span
+    static constexpr int BW = 64 * WX, SPAN = (BW / XS) * S;                 // output columns of a tile, and the pixels they span
+    static constexpr int BH = 4 * R, COLS = BW + 4 * XS, ROWS = BH + 4, TOTAL = ROWS * COLS;
+    static_assert(S % XS == 0 && 64 % XS == 0, "column groups tile both the step and the wave");
+    // pixel column (relative to the tile's x0) of local column c
+    __host__ __device__ static constexpr int xcol(int c) { return (c / XS - 2) * S + c % XS; }
     static constexpr int NLOAD = (TOTAL + THREADS - 1) / THREADS;
     // kInFused keeps {variance, alpha} of the tile's own pixels in a third, small plane
     static constexpr int LDS_BYTES = TOTAL * 2 * 16 + (IN == kInFused ? BH * BW * 8 : 0);
     // workgroups per CU: what the 160 KB of LDS hold, at most 5 (R <= 2) / 3 -- also the register budget the kernel is compiled for
-    static constexpr int PER_CU = (R <= 2 ? 5 : (R == 3 ? 4 : 3)) < (160 * 1024) / LDS_BYTES ? (R <= 2 ? 5 : (R == 3 ? 4 : 3)) : (160 * 1024) / LDS_BYTES;
+    static constexpr int PER_CU_CAP = R <= 2 ? NEB_ATROUS_PER_CU_R2 : (R == 3 ? 4 : 3);
+    static constexpr int PER_CU = PER_CU_CAP < (160 * 1024) / LDS_BYTES ? PER_CU_CAP : (160 * 1024) / LDS_BYTES;
     static constexpr int WAVES_PER_SIMD = PER_CU * WX < 8 ? PER_CU * WX : 8; // launch bound: k blocks of T threads per CU <=> k T / 256 waves per SIMD
 };
 
@@ -375,6 +398,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
 {
     using T = AtrousTile<S, R, IN, WX>;
     constexpr int BW = T::BW, BH = T::BH, COLS = T::COLS, ROWS = T::ROWS, TOTAL = T::TOTAL, NLOAD = T::NLOAD, THREADS = T::THREADS;
+    constexpr int XS = T::XS, XM = T::XM, SPAN = T::SPAN;
     static_assert(IN != kInFused || (S == 1 && WX == 1), "the fused temporal staging is level 0");
     extern __shared__ float4 lds[];
     float4* __restrict__ A = lds;               // {r, g, b, lum}
@@ -423,13 +447,13 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         const int jt = rest / S;    // tile index along the lattice
         const int jmin = (a.row0 - o.r + S - 1) / S > 0 ? (a.row0 - o.r + S - 1) / S : 0; // first lattice index inside [row0,row1)
         o.jbase = jmin + jt * BH;
-        o.x0 = tx_tile * BW;
+        o.x0 = (tx_tile / XM) * SPAN + (tx_tile % XM) * XS;
         return o.r + S * o.jbase < a.row1; // false: whole tile below the row range
     };
     // fills toff[] / o.first for a tile about to be loaded
     auto tile_offsets = [&](Tile& o) {
-        const int y_first = o.r + S * (o.jbase - 2), y_last = o.r + S * (o.jbase + ROWS - 3), x_first = o.x0 - 2 * S;
-        const bool interior = y_first >= max(0, a.row_begin) && y_last < min(a.H, a.row_end) && x_first >= 0 && x_first + COLS <= a.W;
+        const int y_first = o.r + S * (o.jbase - 2), y_last = o.r + S * (o.jbase + ROWS - 3), x_first = o.x0 + T::xcol(0);
+        const bool interior = y_first >= max(0, a.row_begin) && y_last < min(a.H, a.row_end) && x_first >= 0 && o.x0 + T::xcol(COLS - 1) < a.W;
         if (interior) {
             o.first = (size_t)(y_first - a.row_begin) * a.W + x_first;
             if (!toff_regular) {
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                 for (int k = 0; k < NLOAD; ++k) {
                     const int i = tid + THREADS * k;
                     const int lr = i / COLS;
-                    toff[k] = (uint32_t)(lr * S * a.W + (i - lr * COLS)) * 16u;
+                    toff[k] = (uint32_t)(lr * S * a.W + (T::xcol(i - lr * COLS) - T::xcol(0))) * 16u;
                 }
                 toff_regular = true;
             }
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                 // redirected to a resident row (their values are never used)
                 int y = min(max(o.r + S * (o.jbase + lr - 2), 0), a.H - 1);
                 y = min(max(y, a.row_begin), a.row_end - 1);
-                const int x = min(max(o.x0 - 2 * S + lc, 0), a.W - 1);
+                const int x = min(max(o.x0 + T::xcol(lc), 0), a.W - 1);
                 toff[k] = (uint32_t)((y - a.row_begin) * a.W + x) * 16u; // (a plane is < 4 GB: checked at launch)
             }
         }
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
     float nalpha[R];
     auto issue_centre_loads = [&](const Tile& o) {
         if constexpr (IN != kInFused) {
-            const int xo = o.x0 + cb * 64 + lane;
+            const int xo = o.x0 + T::xcol(cb * 64 + lane + 2 * XS);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int yo = o.r + S * (o.jbase + rg * R + k);
@@ -525,22 +549,23 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
     // in this kernel the difference does not show: 192.5 against 192.0 us per frame)
     float cz = a.cz, phiN = a.phiNormal;
     // log2(Kx Ky) + phiN of the six tap classes (|dx|, |dy| in {0, 1, 2}), set up once: computed per tap it would be an add each.
-    // The levels hold all eight constants in vector registers.  The fused kernel has none to spare (168 = the budget of three
-    // waves per SIMD; with them it spilled five, and a kernel that needs scratch memory right after the GI kernels, which use
-    // theirs at another size, waits for the queue's scratch set-up: 57.7 us per launch against 50.9): there they are scalar operands.
+    // The levels of the fused chain hold all eight constants in vector registers.  The fused kernel and the kernels that prefetch
+    // the next tile's radiance into registers have none to spare (168 = the budget of three waves per SIMD; with them the fused kernel
+    // spilled five, and a kernel that needs scratch memory right after the GI kernels, which use theirs at another size, waits for
+    // the queue's scratch set-up: 57.7 us per launch against 50.9): there they are scalar operands.
     float lkp[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = i; j < 3; ++j) {
             lkp[i][j] = tap_constant(phiN, i, j);
-            if constexpr (IN == kInFused)
+            if constexpr (IN != kInLum)
                 lkp[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lkp[i][j])));
             else
                 asm volatile("" : "+v"(lkp[i][j]));
             lkp[j][i] = lkp[i][j];
         }
-    if constexpr (IN != kInFused)
+    if constexpr (IN == kInLum)
         asm volatile("" : "+v"(cz), "+v"(phiN));
 
     NEB_STAMP(0);
@@ -598,9 +623,9 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                     nc[k] = a.normal_cur[e].y; // .zw = shading normal
                     nh[k] = a.normal_hist[e].y;
                     const int lr = i / COLS, lc = i - lr * COLS;
-                    const int x = cx0 + lc - 2 * S, y = cr + S * (cjbase + lr - 2);
+                    const int x = cx0 + T::xcol(lc), y = cr + S * (cjbase + lr - 2);
                     // one of the tile's own output pixels (never a clamped position: those lie outside the image)
-                    own[k] = lr >= 2 && lr < BH + 2 && lc >= 2 * S && lc < BW + 2 * S && x < a.Wd && y >= a.row0 && y < a.row1;
+                    own[k] = lr >= 2 && lr < BH + 2 && lc >= 2 * XS && lc < BW + 2 * XS && x < a.Wd && y >= a.row0 && y < a.row1;
                     mh[k] = own[k] ? a.mom_hist[e] : 0u;
                 }
             }
@@ -622,7 +647,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                         a.variance_out[gi[k]] = (uint16_t)mv.y;
                         a.geometry_out[gi[k]] = geo;
                         const int lr = i / COLS, lc = i - lr * COLS;
-                        V[(lr - 2) * BW + (lc - 2 * S)] = make_float2(half_bits_to_float(mv.y), Cc.w); // (the variance as the levels read it back)
+                        V[(lr - 2) * BW + (lc - 2 * XS)] = make_float2(half_bits_to_float(mv.y), Cc.w); // (the variance as the levels read it back)
                     }
                 }
             }
@@ -656,15 +681,15 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
 
         NEB_STAMP(3);
         // ---- filter the current tile ----
-        const int xo = cx0 + cb * 64 + lane;
+        const int xo = cx0 + T::xcol(cb * 64 + lane + 2 * XS);
         float z0[R], n0x[R], n0y[R], n0z[R], lum0[R], cl[R], alpha0[R];
         float sr[R], sg[R], sb[R], sw[R];
         bool valid[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int lr = rg * R + k + 2;
-            const float4 cA = A[lr * COLS + cb * 64 + lane + 2 * S];
-            const float4 cB = B[lr * COLS + cb * 64 + lane + 2 * S];
+            const float4 cA = A[lr * COLS + cb * 64 + lane + 2 * XS];
+            const float4 cB = B[lr * COLS + cb * 64 + lane + 2 * XS];
             z0[k] = cB.w;
             n0x[k] = 0.5f * cB.x; // halved: see half_dot_max0
             n0y[k] = 0.5f * cB.y;
@@ -688,18 +713,18 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         // trip five times per row.
         float4 gA[2][3], gB[2][3];
         auto load_group = [&](int g) {
-            const int ir = g >> 1, lrow_base = (rg * R + ir) * COLS + cb * 64 + lane + 2 * S;
+            const int ir = g >> 1, lrow_base = (rg * R + ir) * COLS + cb * 64 + lane + 2 * XS;
             if ((g & 1) == 0) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    gA[0][j] = A[lrow_base + (j - 2) * S];
-                    gB[0][j] = B[lrow_base + (j - 2) * S];
+                    gA[0][j] = A[lrow_base + (j - 2) * XS];
+                    gB[0][j] = B[lrow_base + (j - 2) * XS];
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    gA[1][j] = A[lrow_base + (j + 1) * S];
-                    gB[1][j] = B[lrow_base + (j + 1) * S];
+                    gA[1][j] = A[lrow_base + (j + 1) * XS];
+                    gB[1][j] = B[lrow_base + (j + 1) * XS];
                 }
             }
         };
@@ -818,7 +843,7 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
             return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    a.tiles_x = (a.Wd + T::BW - 1) / T::BW;
+    a.tiles_x = ((a.Wd + T::SPAN - 1) / T::SPAN) * T::XM;
     const int max_lattice_rows = (a.row1 - a.row0 + S - 1) / S; // per residue class, upper bound
     a.tiles_j = (max_lattice_rows + T::BH - 1) / T::BH;
     a.nblocks = (uint32_t)a.tiles_x * (uint32_t)S * (uint32_t)a.tiles_j;
