@@ -387,7 +387,7 @@ struct AtrousTile {
     static constexpr int NLOAD = (TOTAL + THREADS - 1) / THREADS;
     // kInFused keeps {variance, alpha} of the tile's own pixels in a third, small plane
     static constexpr int LDS_BYTES = TOTAL * 2 * 16 + (IN == kInFused ? BH * BW * 8 : 0);
-    // workgroups per CU: what the 160 KB of LDS hold, at most 5 (R <= 2) / 3 -- also the register budget the kernel is compiled for
+    // workgroups per CU: what the 160 KB of LDS hold, at most 4 (R <= 2: 128 registers per lane) / 3 (168) -- also the register budget the kernel is compiled for
     static constexpr int PER_CU_CAP = R <= 2 ? NEB_ATROUS_PER_CU_R2 : (R == 3 ? 4 : 3);
     static constexpr int PER_CU = PER_CU_CAP < (160 * 1024) / LDS_BYTES ? PER_CU_CAP : (160 * 1024) / LDS_BYTES;
     static constexpr int WAVES_PER_SIMD = PER_CU * WX < 8 ? PER_CU * WX : 8; // launch bound: k blocks of T threads per CU <=> k T / 256 waves per SIMD
@@ -861,8 +861,8 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
     return hipGetLastError();
 }
 
-// R = 4 rows per lane for steps <= 4 (43.5 KB LDS tile, 3 workgroups per CU), R = 2 for steps 8..32 (the tile is 64 + 4 S
-// columns wide), as measured
+// R = 4 rows per lane for steps <= 4 (43.5 - 51 KB LDS tile, 3 workgroups per CU), R = 2 for steps 8..32 (96 staged columns:
+// 64 + 4 S at S = 8, 64 + 4 groups of 8 beyond; 37 KB, 4 workgroups per CU), as measured
 template <int IN, bool OUT_ALPHA>
 static hipError_t launch_lds_step(const AtrousArgs& a, uint32_t step, int device, int num_cus, hipStream_t s)
 {
