@@ -215,6 +215,32 @@ def test_single_atrous_level_matches_oracle(step_level, variant):
     d.destroy()
 
 
+@pytest.mark.parametrize("step_level", [3, 4, 5])
+def test_wide_steps_on_an_image_with_interior_tiles(step_level):
+    """Steps 16 and 32 lay a tile's columns out as a lattice of 8-pixel groups (svgf.hip, AtrousTile); a tile that needs no
+    clamping takes precomputed offsets.  Such tiles only exist on images wider and taller than ~20 steps: 1100 x 650 has them at
+    every step, with a ragged last span (1100 = 4 spans of 256 + 76; width not a multiple of 8 either: the dispatch floors it)."""
+    W, H, L = 1100, 650, 6
+    d = make(W, H, L)
+    g, rad = frame_inputs(W, H, 2, None)
+    feed(d, None, 2, g, rad)
+    var = (np.float32(0.02) + np.float32(0.5) * synth.uniform01(9, 2, np.arange(W * H, dtype=np.uint32), 5)).reshape(H, W).astype(np.float16)
+    d.upload(PLANE_VARIANCE, 0, var)
+    (sp, ss), (dp, ds) = d.atrous_level_planes(step_level)
+    d.upload(sp, ss, rad)
+    d.upload(dp, ds, np.zeros_like(rad))
+    d.submit_atrous_level(step_level, (0, H))
+    got = d.download(dp, ds)
+    from oracle import svgf_np
+    want = svgf_np.atrous(rad, var, g["depth"], g["normal"], 1 << step_level)
+    Wd, Hd = (W // 8) * 8, (H // 8) * 8
+    assert rel_l2(got[:Hd, :Wd, :3], want[:Hd, :Wd, :3]) < TOL_PASS
+    assert float(np.abs(got[:Hd, :Wd, :3] - want[:Hd, :Wd, :3]).max()) < 1e-4 * float(np.abs(want).max())  # no misplaced pixel hides in a norm
+    assert np.array_equal(got[:Hd, :Wd, 3], rad[:Hd, :Wd, 3])
+    assert not got[:, Wd:].any() and not got[Hd:].any()  # the floored remainder is never written
+    d.destroy()
+
+
 @pytest.mark.parametrize("W,H,L", [(40, 24, 1), (72, 40, 2), (70, 53, 3), (136, 104, 6), (256, 256, 4)])
 def test_sequences_match_oracle_including_ragged_sizes(W, H, L):
     d, o = make(W, H, L), OracleSVGF(W, H, L)
