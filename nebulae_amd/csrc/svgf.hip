@@ -31,9 +31,9 @@
 #ifndef NEB_ATROUS_PRIO // 0: no s_setprio; 1: a workgroup's priority = the tiles it still has to do (default)
 #define NEB_ATROUS_PRIO 1
 #endif
-#ifndef NEB_ATROUS_R_NARROW // rows per lane of the LDS kernel at steps <= 4: 4; A/B arms: 3 (4 workgroups per CU: the same, 34.5 against 34.1 us), 2 (34.3 against 32.4)
-#define NEB_ATROUS_R_NARROW 4
-#endif
+#ifndef NEB_ATROUS_R_NARROW // rows per lane of the LDS kernel at steps <= 4.  2 (8-row tiles, 28 KB, four workgroups per CU at 128 registers): S = 2 / 4
+#define NEB_ATROUS_R_NARROW 2 // of the fused chain 29.4 / 29.0 us against 30.9 / 30.2 with 4, 30.5 / 30.3 with 3; the separate kernels 30.5 against 33.0; a
+#endif                        // 136-row strip 9.4 against 12.8.  (With five workgroups per CU and 96 registers -- the round-2 setting -- 2 lost: 34.3 against 32.4.)
 #ifndef NEB_ATROUS_STORE // how the LDS kernel stores its output: 1 write-through (sc1, default), 0 plain, 2 non-temporal (A/B arms)
 #define NEB_ATROUS_STORE 1
 #endif
@@ -861,8 +861,8 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
     return hipGetLastError();
 }
 
-// R = 4 rows per lane for steps <= 4 (43.5 - 51 KB LDS tile, 3 workgroups per CU), R = 2 for steps 8..32 (96 staged columns:
-// 64 + 4 S at S = 8, 64 + 4 groups of 8 beyond; 37 KB, 4 workgroups per CU), as measured
+// R = 2 rows per lane at every step (12 staged rows of 68 - 96 columns: 26 - 37 KB, 4 workgroups per CU, 128 registers per lane),
+// as measured; the fused temporal + level-0 kernel alone keeps R = 4 (its staging needs the registers of three waves per SIMD)
 template <int IN, bool OUT_ALPHA>
 static hipError_t launch_lds_step(const AtrousArgs& a, uint32_t step, int device, int num_cus, hipStream_t s)
 {
