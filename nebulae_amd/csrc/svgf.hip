@@ -441,10 +441,24 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         size_t first; // element index the offsets in toff[] count from
     };
     auto tile_origin = [&](uint32_t t, Tile& o) -> bool {
-        const int tx_tile = (int)(t % (uint32_t)a.tiles_x);
-        const int rest = (int)(t / (uint32_t)a.tiles_x);
-        o.r = rest % S;             // residue class of the lattice rows
-        const int jt = rest / S;    // tile index along the lattice
+        // Tile order inside an XCD's run.  The levels: along the lattice fastest, then columns, then residues -- the tiles that share
+        // staged rows (j and j + 1 of one column and residue: 4 of a tile's 12 rows) and columns (neighbouring column tiles) are in
+        // flight on the same XCD at the same time and its L2 serves the second reader (S = 16: 30.6 us against 32.7; 8: 28.0 / 28.8;
+        // 4: 27.9 / 28.7).  Level 0 with the temporal pass, bound by memory, keeps columns fastest: narrow vertical runs cost it
+        // 53.2 us against 50.8 (short row segments of many rows: the DRAM pages).  Blocks of 2 / 4 / 8 tiles along the lattice with
+        // the columns in between lose at the wide steps (the padded tile count unbalances the XCDs).
+        int tx_tile, jt;
+        if constexpr (IN == kInFused) {
+            tx_tile = (int)(t % (uint32_t)a.tiles_x);
+            const int rest = (int)(t / (uint32_t)a.tiles_x);
+            o.r = rest % S; // residue class of the lattice rows
+            jt = rest / S;  // tile index along the lattice
+        } else {
+            jt = (int)(t % (uint32_t)a.tiles_j);
+            const int rest = (int)(t / (uint32_t)a.tiles_j);
+            tx_tile = rest % a.tiles_x;
+            o.r = rest / a.tiles_x;
+        }
         const int jmin = (a.row0 - o.r + S - 1) / S > 0 ? (a.row0 - o.r + S - 1) / S : 0; // first lattice index inside [row0,row1)
         o.jbase = jmin + jt * BH;
         o.x0 = (tx_tile / XM) * SPAN + (tx_tile % XM) * XS;
