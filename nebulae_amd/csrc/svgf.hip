@@ -590,12 +590,16 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         // to do lets the workgroups finish together.
         {
             const uint32_t remaining = (t_end - t + wgs_per_xcd - 1u) / wgs_per_xcd; // (this tile included)
-            if (remaining >= 3u)
+            // (four levels: with 8-row tiles a workgroup has four tiles or more -- 28.7 / 27.4 / 28.0 / 30.6 us for S = 2 .. 16 against
+            // 29.0 / 28.0 / 28.3 / 30.9 with "three and more" as one level; no priorities at all: 32.0 / 30.7 / 31.5 / 34.5)
+            if (remaining >= 4u)
                 __builtin_amdgcn_s_setprio(3);
-            else if (remaining == 2u)
+            else if (remaining == 3u)
                 __builtin_amdgcn_s_setprio(2);
-            else
+            else if (remaining == 2u)
                 __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
         }
 #endif
         const int cr = nt.r, cjbase = nt.jbase, cx0 = nt.x0;
