@@ -514,10 +514,18 @@ def main(argv=None, rt=None, emit=None):
         e = {k: rt.event() for k in ("gi0", "gi1", "t0", "t1", "a1")}
         w.step(e)
         ev2.append(e)
+    # the levels behind the first as ONE interval of the library's events (svgf_profile = 2: no event between them)
+    lt2 = []
+    if world == 1:
+        r.svgf.set_option("svgf_profile", 2)
+        for _ in range(8):
+            w.step()
+            lt2.append(r.svgf.level_times())
+        r.svgf.set_option("svgf_profile", 0)
     rt.synchronize()
-    rays_ev = (r.ray_count(reset=True) if do_gi else 0) // 2  # (two batches of 8 frames)
+    rays_ev = (r.ray_count(reset=True) if do_gi else 0) // (3 if world == 1 else 2)  # (batches of 8 frames)
     t_gi = float(np.mean([e["gi0"].elapsed_time(e["gi1"]) for e in ev])) * 1e-3
-    fused = False
+    fused = bracketed = False
     if world == 1:
         per_level = [float(np.mean([x[i] for x in lt])) * 1e-6 for i in range(L)]
         t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev2])) * 1e-3
@@ -528,6 +536,9 @@ def main(argv=None, rt=None, emit=None):
         # the roofline's kernel = a pure a-trous level (levels 1.. of the fused chain; every level otherwise)
         pure = per_level[1:] if (fused and L > 1) else per_level
         t_atrous = float(np.mean(pure)) if pure else 0.0
+        bracketed = fused and L > 1 and all(len(x) == 2 for x in lt2)
+        if bracketed:  # average launch duration over the L - 1 pure levels, timed as one interval
+            t_atrous = float(np.mean([x[1] for x in lt2])) * 1e-6 / (L - 1)
     else:
         t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev])) * 1e-3
         per_level = [float(np.mean([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev])) * 1e-3 for i in range(L)]
@@ -593,7 +604,10 @@ def main(argv=None, rt=None, emit=None):
                           "fused_temporal_level0": per_level[0] * 1e6 if (fused and L > 0) else None,
                           "atrous_levels": [t * 1e6 for t in per_level], "svgf_chain": t_svgf_chain * 1e6},
             "roofline": {"bound": "hbm",
-                         "kernel": ("svgf_atrous_lds_kernel, a pure level (mean over levels 1.. of the fused chain: the library's own HIP events on the launch stream)"
+                         "kernel": (("svgf_atrous_lds_kernel, a pure level (levels 1.. of the fused chain timed as ONE interval of the library's own HIP events on the "
+                                     "launch stream, divided by their number; kernel_us.atrous_levels has an event pair per level, ~2 us of packets each)"
+                                     if bracketed else
+                                     "svgf_atrous_lds_kernel, a pure level (mean over levels 1.. of the fused chain: the library's own HIP events on the launch stream)")
                                     if fused else "svgf_atrous_lds_kernel (mean over the levels of a frame)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,

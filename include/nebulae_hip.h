@@ -118,7 +118,7 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);
- *   "svgf_fuse":        1 (default) / 0, see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1, see neb_svgf_level_times. */
+ *   "svgf_fuse":        1 (default) / 0, see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1 / 2, see neb_svgf_level_times. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
 /* ---- resource sharing: the ~25 getters of SVGFDenoiser.h:24-70 collapse into one call.
@@ -153,7 +153,8 @@ int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream);
 int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream);
 /* With option "svgf_profile" = 1, neb_svgf_atrous brackets each of its kernels with events on `stream`; this call waits for the
  * last chain submitted and returns the kernels' durations in microseconds (entry 0 = level 0, fused with the temporal pass when
- * the chain ran fused), *n_out = how many. */
+ * the chain ran fused), *n_out = how many.  With "svgf_profile" = 2 only three events are recorded and two durations returned:
+ * the first kernel, and all the others together (an event between two launches costs about 2 us of its own). */
 int neb_svgf_level_times(neb_ctx* ctx, float* out_us, uint32_t capacity, uint32_t* n_out);
 /* Row-range forms for multi-GPU row strips (no reference counterpart):
  * image rows [row0,row1) must be resident, and for the a-trous level so must every

@@ -278,8 +278,8 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
         return NEB_OK;
     }
     if (!strcmp(key, "svgf_profile")) {
-        if (value < 0 || value > 1)
-            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: svgf_profile must be 0 or 1");
+        if (value < 0 || value > 2)
+            return fail(ctx, NEB_ERR_INVALID_ARG, "neb_set_option: svgf_profile must be 0, 1 (an event in front of every kernel) or 2 (first kernel / the rest)");
         ctx->profile = value;
         ctx->prof_recorded = 0;
         return NEB_OK;
@@ -453,10 +453,18 @@ static hipError_t geometry_ensure(neb_ctx* ctx, uint32_t row0, uint32_t row1, hi
 }
 
 // option svgf_profile: event k is recorded in front of the k-th kernel of neb_svgf_atrous's chain (k = levels: behind the last)
+// (svgf_profile = 2: only in front of the first kernel, in front of the second and behind the last -- every event is a packet of its
+// own between two launches, ~2 us; the levels after the first are then timed as one interval with none inside)
 static void profile_mark(neb_ctx* ctx, uint32_t k, hipStream_t stream)
 {
     if (!ctx->profile)
         return;
+    if (ctx->profile == 2) {
+        if (k > 1 && k != ctx->levels)
+            return;
+        if (k > 1)
+            k = 2;
+    }
     while (ctx->prof_events.size() <= k) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess)

@@ -172,7 +172,8 @@ class SVGFDenoiser:
 
     def level_times(self):
         """Durations (us) of the kernels of the last submit_atrous_compute_wavelet chain (option svgf_profile = 1): entry 0 is
-        level 0 -- fused with the temporal pass when the two calls ran as one chain."""
+        level 0 -- fused with the temporal pass when the two calls ran as one chain.  Option svgf_profile = 2: [the first kernel,
+        all the others as one interval]."""
         out = (C.c_float * 32)()
         n = C.c_uint32()
         self._check(self._lib.neb_svgf_level_times(self._ctx, out, 32, C.byref(n)), "neb_svgf_level_times")

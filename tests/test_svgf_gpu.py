@@ -187,6 +187,17 @@ def test_level_times_need_the_profile_option_and_report_one_duration_per_kernel(
         assert len(t) == L and all(0.0 < x < 1e5 for x in t)
         d.set_option("svgf_profile", 0)
         d.end_frame()
+        # svgf_profile = 2: the first kernel, and the others as one interval
+        d.set_option("svgf_profile", 2)
+        feed(d, None, 3, g, rad)
+        d.submit_temporal_accumulation()
+        d.submit_atrous_compute_wavelet()
+        t2 = d.level_times()
+        assert len(t2) == 2 and all(0.0 < x < 1e5 for x in t2)
+        d.set_option("svgf_profile", 0)
+        d.end_frame()
+    with pytest.raises(NebError):
+        d.set_option("svgf_profile", 3)
     d.destroy()
 
 
