@@ -34,6 +34,9 @@
 #ifndef NEB_ATROUS_R_NARROW // rows per lane of the LDS kernel at steps <= 4.  2 (8-row tiles, 28 KB, four workgroups per CU at 128 registers): S = 2 / 4
 #define NEB_ATROUS_R_NARROW 2 // of the fused chain 29.4 / 29.0 us against 30.9 / 30.2 with 4, 30.5 / 30.3 with 3; the separate kernels 30.5 against 33.0; a
 #endif                        // 136-row strip 9.4 against 12.8.  (With five workgroups per CU and 96 registers -- the round-2 setting -- 2 lost: 34.3 against 32.4.)
+#ifndef NEB_ATROUS_R_FUSED // rows per lane of the fused temporal + level-0 kernel: 2 (its staging then holds four texels per lane instead of
+#define NEB_ATROUS_R_FUSED 2 // six and the kernel fits 128 registers: four workgroups per CU, 47.6 us against 50.7 with 4)
+#endif
 #ifndef NEB_ATROUS_STORE // how the LDS kernel stores its output: 1 write-through (sc1, default), 0 plain, 2 non-temporal (A/B arms)
 #define NEB_ATROUS_STORE 1
 #endif
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         // staged rows (j and j + 1 of one column and residue: 4 of a tile's 12 rows) and columns (neighbouring column tiles) are in
         // flight on the same XCD at the same time and its L2 serves the second reader (S = 16: 30.6 us against 32.7; 8: 28.0 / 28.8;
         // 4: 27.9 / 28.7).  Level 0 with the temporal pass, bound by memory, keeps columns fastest: narrow vertical runs cost it
-        // 53.2 us against 50.8 (short row segments of many rows: the DRAM pages).  Blocks of 2 / 4 / 8 tiles along the lattice with
+        // 53.2 us against 50.8 with 16-row tiles, 50.1 against 47.6 with 8-row ones (short row segments of many rows: the DRAM pages).  Blocks of 2 / 4 / 8 tiles along the lattice with
         // the columns in between lose at the wide steps (the padded tile count unbalances the XCDs).
         int tx_tile, jt;
         if constexpr (IN == kInFused) {
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
     float cz = a.cz, phiN = a.phiNormal;
     // log2(Kx Ky) + phiN of the six tap classes (|dx|, |dy| in {0, 1, 2}), set up once: computed per tap it would be an add each.
     // The levels of the fused chain hold all eight constants in vector registers.  The fused kernel and the kernels that prefetch
-    // the next tile's radiance into registers have none to spare (168 = the budget of three waves per SIMD; with them the fused kernel
+    // the next tile's radiance into registers run at their register budget (with the constants in registers the 16-row fused kernel
     // spilled five, and a kernel that needs scratch memory right after the GI kernels, which use theirs at another size, waits for
     // the queue's scratch set-up: 57.7 us per launch against 50.9): there they are scalar operands.
     float lkp[3][3];
@@ -880,7 +883,7 @@ static hipError_t launch_lds(AtrousArgs a, int device, int num_cus, hipStream_t 
 }
 
 // R = 2 rows per lane at every step (12 staged rows of 68 - 96 columns: 26 - 37 KB, 4 workgroups per CU, 128 registers per lane),
-// as measured; the fused temporal + level-0 kernel alone keeps R = 4 (its staging needs the registers of three waves per SIMD)
+// as measured -- the fused temporal + level-0 kernel included (NEB_ATROUS_R_FUSED)
 template <int IN, bool OUT_ALPHA>
 static hipError_t launch_lds_step(const AtrousArgs& a, uint32_t step, int device, int num_cus, hipStream_t s)
 {
@@ -974,7 +977,7 @@ hipError_t launch_atrous_fused_temporal(const SvgfLaunch& L, bool only_level, co
     a.t_alpha = L.p.alpha;
     a.t_varianceEps = L.p.varianceEps;
     const int num_cus = L.num_cus > 0 ? L.num_cus : 256;
-    return only_level ? launch_lds<1, 4, kInFused, true>(a, L.device, num_cus, s) : launch_lds<1, 4, kInFused, false>(a, L.device, num_cus, s);
+    return only_level ? launch_lds<1, NEB_ATROUS_R_FUSED, kInFused, true>(a, L.device, num_cus, s) : launch_lds<1, NEB_ATROUS_R_FUSED, kInFused, false>(a, L.device, num_cus, s);
 }
 
 } // namespace neb
