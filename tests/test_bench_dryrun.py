@@ -126,6 +126,7 @@ def _rank_main(rank, world, port, argv, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path.insert(0, ROOT)
     import bench
+    bench.Workload.SETTLE_FRAMES = 4  # (the dry run has no clocks to settle: keep the CPU suite short)
     lines = []
     bench.main(argv, rt=DryRuntime(), emit=lines.append)
     if rank == 0:
