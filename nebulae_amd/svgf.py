@@ -34,6 +34,7 @@ class SVGFDenoiser:
         self.width = self.height = 0
         self.row_begin = self.row_end = 0
         self.levels = self.NUM_ATROUS_PASSES
+        self.device = 0
 
     # ---- lifecycle (SVGFDenoiser.cpp:14-37) ----
     def is_initialized(self):
@@ -49,6 +50,7 @@ class SVGFDenoiser:
         rc = self._lib.neb_create(C.byref(info), C.byref(ctx))
         _lib.check(self._lib, None, rc, "neb_create")
         self._ctx = ctx
+        self.device = int(device)
         self.width, self.height = width, height
         self.row_begin, self.row_end = row_begin, (row_end or height)
         return True
@@ -149,7 +151,7 @@ class SVGFDenoiser:
         h = _Holder()
         h.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2,
                                       "strides": None}
-        t = torch.as_tensor(h, device=f"cuda:{torch.cuda.current_device()}")
+        t = torch.as_tensor(h, device=f"cuda:{self.device}")  # (the context's own device, whatever torch's current one is)
         t._neb_owner = self  # keep the context alive as long as the view
         return t
 
