@@ -539,3 +539,42 @@ def test_axis_parallel_sun_rays(direction):
     if (dwant[..., 0] > 0).any():  # (a level sun leaves the closed box dark)
         assert rel_l2(direct[lit_same][:, :3], dwant[lit_same][:, :3]) <= 2e-5
     r.destroy()
+
+
+def test_degenerate_normals_do_not_walk_the_whole_tree():
+    """A G-buffer whose covered pixels carry normals that are not numbers (a slot nobody wrote, a broken producer) makes bounce
+    rays with a NaN direction: every plane distance is NaN, the box test -- which drops NaNs -- passes every node, and the ray visits
+    the whole tree without ever hitting a triangle: 0.1 s per wave on a 262 k-triangle scene (seen in a tool that forgot to fill the
+    second G-buffer slot).  Such a ray does not start (it hits nothing): the dispatch takes its usual time, no node is visited."""
+    import time
+    import torch
+    sc = S.atrium_standin(target_triangles=120000, n_submeshes=60, tex_size=64)
+    cam = S.sponza_camera()
+    W, H = 512, 288
+    r = DeferredRenderer()
+    r.init(W, H)
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=3))
+    r.submit_commands_gbuffer()
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    r.set_debug_hits(True)
+    r.submit_commands_gi_pathtrace()  # (first launch of the process: not timed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r.submit_commands_gi_pathtrace()
+    torch.cuda.synchronize()
+    usual = time.perf_counter() - t0
+    r.ray_count()
+    before = r.traversal_stats()
+    assert before["bounce_nodes"] > 0
+    n = r.svgf.download(PLANE_NORMAL)
+    r.svgf.upload(PLANE_NORMAL, SLOT_CURRENT, np.full_like(n, np.nan))
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    t0 = time.perf_counter()
+    r.submit_commands_gi_pathtrace()
+    torch.cuda.synchronize()
+    degenerate = time.perf_counter() - t0
+    r.ray_count()
+    after = r.traversal_stats()
+    assert after["bounce_nodes"] == before["bounce_nodes"], (before, after)  # no bounce ray walked the tree
+    assert degenerate < 5.0 * usual + 2e-3, (degenerate, usual)
+    r.destroy()
