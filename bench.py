@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TEMPORAL_BYTES_PX = 82  # 60 B read + 22 B written
 ATROUS_BYTES_PX = 46    # per level: 30 B read + 16 B written
 GI_STREAM_BYTES_PX = 56  # 24 B G-buffer read + 32 B radiance read-modify-write
-PROFILE_ROUND = "r03"   # only PMC summaries of this round's kernels are quoted (profiles/r03*_*.json), and only of this very build
+PROFILE_ROUND = "r04"   # only PMC summaries of this round's kernels are quoted (profiles/r04*_*.json), and only of this very build
 
 
 def parse(argv=None):
@@ -70,6 +70,86 @@ def parse(argv=None):
     ap.add_argument("--config5-size", type=int, nargs=2, default=(3840, 2160), metavar=("W", "H"),
                     help="frame of the config-5 leg (BASELINE.json configs[4]: 3840 2160; the CPU dry run shrinks it)")
     return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, child=None, emit=None, timeout=None):
+    """`python3 bench.py --gpus N` typed without a launcher: this process -- which has touched no GPU and never will -- starts N
+    ranks of `child` (default: this very file) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one per GPU,
+    relays rank 0's stdout (the ONE JSON line) and every rank's stderr, and returns 0 only if every rank exited 0.  The first
+    rank that fails ends the job: the others are terminated (their own process groups, exact PIDs), nothing is retried and no
+    process that initialised a GPU is ever replaced by exec."""
+    import signal
+    import subprocess
+    child = child or [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(child + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True, start_new_session=True))
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        t_end = time.time() + 10
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    rc, t0 = 0, time.time()
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0:
+                    print(f"bench.py: rank {r} of {n} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    rc = code if code > 0 else 1
+                    live.clear()
+                    break
+            if timeout is not None and time.time() - t0 > timeout:
+                print(f"bench.py: ranks still running after {timeout} s; stopping them", file=sys.stderr, flush=True)
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
+    reader.join(timeout=5)
+    out = [l.rstrip("\n") for l in lines if l.strip()]
+    if rc == 0:
+        for l in out:
+            (emit or (lambda line: print(line, flush=True)))(l)
+        if not any(l.startswith("{") for l in out):
+            print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+            rc = 1
+    else:
+        for l in out:
+            print(l, file=sys.stderr, flush=True)
+    return rc
 
 
 def library_build_id():
@@ -144,9 +224,24 @@ def measured_valu(width, height, levels):
 
 
 def host_cores():
-    """(threads the CPU leg uses, cores this process may run on): a 1-GPU box shares its host and gpurun's share is 16 cores."""
+    """-> (threads the CPU leg uses, cores this process may run on, why): every core in the affinity mask, unless a cgroup CPU
+    quota says this job may use fewer core-seconds per second (more runnable threads than that are only throttled), or
+    NEB_BENCH_CPU_THREADS overrides."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(n, 16)), n
+    use, why = n, "every core of the affinity mask"
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            quota = int(txt[0]) if txt[0] != "max" else -1
+            period = int(txt[1]) if len(txt) > 1 else int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0 and quota / period < use:
+                use, why = max(1, int(quota // period)), f"cgroup CPU quota {quota}/{period} us = {quota / period:.1f} cores"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if os.environ.get("NEB_BENCH_CPU_THREADS"):
+        use, why = max(1, int(os.environ["NEB_BENCH_CPU_THREADS"])), "NEB_BENCH_CPU_THREADS"
+    return use, n, why
 
 
 def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
@@ -158,7 +253,7 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
 
     import numpy as np
     from oracle_lib import OracleSVGF, OracleTracer, SvgfParams, lib
-    cores, cores_available = host_cores()
+    cores, cores_available, cores_why = host_cores()
     med = lambda v: float(np.median(v))  # noqa: E731
     # ---- all cores: `frames` GI frames + `frames` SVGF frames, median of each ----
     t_gi, rays = [], 0
@@ -211,7 +306,7 @@ def cpu_baseline(W, H, L, frames, gb, consts, scene, noisy, do_gi):
     o.close()
     dt_one = (t1_gi + t1_svgf) * scale
     return {"value": 1.0 / dt_all, "unit": "frames/s", "cores": cores, "cores_available": cores_available,
-            "cores_note": f"{cores} of the {cores_available} cores this process may run on (host has {os.cpu_count()})", "kind": "port",
+            "cores_note": f"{cores} of the {cores_available} cores this process may run on (host has {os.cpu_count()}): {cores_why}", "kind": "port",
             "gi_mrays_per_s": (rays / med(t_gi) / 1e6) if do_gi else None,
             "sample": (f"median of {frames} full {W}x{H} GI frames ({rays} rays, {med(t_gi) * 1e3:.0f} ms) of oracle/trace_ref.cpp + " if do_gi else "")
                       + f"median of {len(t_svgf)} full {W}x{H} SVGF frames (temporal + {L} a-trous levels, {med(t_svgf) * 1e3:.0f} ms) of "
@@ -266,7 +361,7 @@ class GpuRuntime:
 class Workload:
     """One strip renderer of a GW x GH frame cut into `world` row strips, its static G-buffer and direct-light term."""
 
-    def __init__(self, rt, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True, scheme=None):
+    def __init__(self, rt, args, GW, GH, L, spp, sc, cam, rank, world, local_rank, group, do_gi=True, scheme=None, link=None):
         import torch
         from nebulae_amd import strips, synth
         self.rt = rt
@@ -274,7 +369,7 @@ class Workload:
         from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE
         self.torch, self.RenderInfo = torch, RenderInfo
         self.args, self.GW, self.GH, self.L, self.sc, self.cam, self.rank, self.world, self.do_gi = args, GW, GH, L, sc, cam, rank, world, do_gi
-        self.part = strips.StripPartition(GW, GH, world, L, scheme=scheme)
+        self.part = strips.StripPartition(GW, GH, world, L, scheme=scheme, link=link)
         self.r = r = rt.make_renderer(self.part, rank, local_rank, group, args.exchange)
         # one strip = the whole frame: temporal + a-trous run as the library's fused chain when every pixel is covered by both
         self.fused_chain = (world == 1 and GW % 8 == 0 and GH % 8 == 0 and 1 <= L <= 6 and args.atrous_variant == 1
@@ -371,16 +466,15 @@ class Workload:
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         return float(mx[0].item()), float(sm[0].item())
 
-    # Frames run before the W warm-up frames of the contract: a freshly created context reaches its steady frame time only after
-    # ~50 frames (clocks, TLBs over the 0.8 GB of scene tables) -- 20 timed steps behind 5 warm-ups read 1290 frames/s, behind 64
-    # warm-ups 1352 on the same box.  A renderer runs in that steady state; the line reports both counts.
+    # A freshly created context reaches its steady frame time only after ~50 frames (clocks, TLBs over the 0.8 GB of scene tables):
+    # 20 timed steps behind 5 warm-ups read ~1290 frames/s, behind 64 warm-ups ~1352 on the same box.  `value` is what the contract
+    # defines -- exactly W warm-up frames, then K timed steps; the settled rate is measured in a SECOND timed region of K steps once
+    # SETTLE_FRAMES frames have run, and reported beside it (`value_settled`).
     SETTLE_FRAMES = 48
 
     def timed(self, steps, warmup, step_fn=None):
-        """settle, warm-up, barrier, EXACTLY `steps` steps, barrier -> (seconds: max over ranks, rays: sum over ranks)"""
+        """`warmup` untimed steps, barrier, EXACTLY `steps` steps, barrier -> (seconds: max over ranks, rays: sum over ranks)"""
         step_fn = step_fn or (lambda k: self.step())
-        for k in range(max(self.SETTLE_FRAMES - warmup, 0)):
-            step_fn(k - warmup - self.SETTLE_FRAMES)
         for k in range(warmup):
             step_fn(k - warmup)
         self.barrier()
@@ -407,7 +501,7 @@ class Workload:
         self.r.destroy()
 
 
-def run_config5(rt, args, sc, rank, world, local_rank, group, scheme=None):
+def run_config5(rt, args, sc, rank, world, local_rank, group, scheme=None, link=None):
     """BASELINE.json configs[4]: 3840x2160 in `world` strips, 4 spp, 5 levels; the camera orbits
     (yaw += 0.5 deg per frame) for the first half of the sequence and stands still for the second.  Two runs: the
     reference's policy (SVGF skipped while moving, history reset on the first still frame) and always-on (beyond the
@@ -422,7 +516,7 @@ def run_config5(rt, args, sc, rank, world, local_rank, group, scheme=None):
     out = {"workload": f"{c5w}x{c5h}, 4 spp one-bounce GI + SVGF temporal + 5 a-trous levels, {world} row strips of {c5h // world} rows, "
                        f"{half} frames with the camera orbiting (yaw += 0.5 deg per frame; G-buffer and direct term re-rendered) then {n - half} still frames"}
     for mode in ("reference_policy", "always_on"):
-        w = Workload(rt, args, c5w, c5h, 5, 4, sc, cam_at(-1), rank, world, local_rank, group, scheme=scheme)
+        w = Workload(rt, args, c5w, c5h, 5, 4, sc, cam_at(-1), rank, world, local_rank, group, scheme=scheme, link=link)
         w.r.denoise_while_moving = mode == "always_on"
         w.step()  # one still frame first, so that the sequence starts from a settled state
         w.step()
@@ -441,6 +535,9 @@ def run_config5(rt, args, sc, rank, world, local_rank, group, scheme=None):
 def main(argv=None, rt=None, emit=None):
     """argv / rt / emit: None for the real run (sys.argv, the HIP runtime, print); the CPU dry run passes its own."""
     args = parse(argv)
+    if rt is None and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python3 bench.py --gpus N` with no launcher around it: be the launcher (before anything touches a GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -450,7 +547,7 @@ def main(argv=None, rt=None, emit=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if not rt.available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if os.environ.get("NEB_BENCH_SHARE_DEVICE"):  # rehearsal of the N > 1 path on a 1-GPU box: every rank on cuda:0
@@ -462,6 +559,11 @@ def main(argv=None, rt=None, emit=None):
 
     from nebulae_amd import scene as S
     from nebulae_amd import strips
+    # N > 1: what one halo exchange with a neighbour costs on THIS node -- 20 exchanges of 4 KB and of 2 MB, the product's own
+    # batch_isend_irecv pattern, outside every timed region -- feeds the scheme chooser in place of guessed xGMI constants
+    link = None
+    if world > 1:
+        link = strips.measure_link(rank, world, group, lambda n: rt.to_device(torch.zeros(n, dtype=torch.uint8)), rt.synchronize)
     from nebulae_amd.svgf import PLANE_ALBEDO, PLANE_DEPTH, PLANE_NORMAL, PLANE_ROUGH_METAL, PLANE_WORLDPOS
 
     L = args.levels
@@ -487,13 +589,19 @@ def main(argv=None, rt=None, emit=None):
 
     # ---- the primary workload: ONE width x height frame (BASELINE.json configs[2]) on `world` GPUs = `world` row strips ----
     GW, GH = args.width, args.height
-    w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme)
+    w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme, link=link)
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
     bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth()} if do_gi else None
 
-    dt, rays_total = w.timed(args.steps, max(args.warmup, 2))  # >= 2 warm-ups: frame 2 is "camera moved", frame 3 resets history
+    # (frame 1 -- "camera moved": SVGF skipped -- ran in the set-up; frame 2 resets the history.  At least one warm-up frame runs so
+    # that every timed frame is a steady-state denoised frame; `warmup_run` on the line says what ran)
+    warmup_run = max(args.warmup, 1)
+    dt, rays_total = w.timed(args.steps, warmup_run)
     assert all(w.ran_svgf), "SVGF was skipped inside the timed region"
+    # the settled rate: the same K steps, timed the same way, once the context has run SETTLE_FRAMES frames in all
+    settle_run = max(Workload.SETTLE_FRAMES - warmup_run - args.steps, 0)
+    dt_settled, _ = w.timed(args.steps, settle_run)
 
     # ---- optional: the same loop with SURVEY.md 8e's final gather of the strips to rank 0 after every frame ----
     fps_with_gather = None
@@ -569,15 +677,15 @@ def main(argv=None, rt=None, emit=None):
     weak = None
     if world > 1 and not args.no_weak and do_gi:
         a, b = strips.frame_factors(world)
-        ww = Workload(rt, args, args.width * a, args.height * b, L, args.spp, sc, cam, rank, world, local_rank, group, scheme=scheme)
-        dtw, rays_w = ww.timed(args.steps, max(args.warmup, 2))
+        ww = Workload(rt, args, args.width * a, args.height * b, L, args.spp, sc, cam, rank, world, local_rank, group, scheme=scheme, link=link)
+        dtw, rays_w = ww.timed(args.steps, max(args.warmup, 1))
         weak = {"frames_per_s_1080p_equivalents": args.steps / dtw * world, "global_frames_per_s": args.steps / dtw, "ms_per_frame": dtw / args.steps * 1e3,
                 "mrays_per_s": rays_w / dtw / 1e6, "global_width": args.width * a, "global_height": args.height * b,
                 "rows_per_strip": args.height * b // world, "parallelism": ww.parallelism_label()}
         ww.destroy()
     config5 = None
     if do_gi and (args.config5 or world == 8):
-        config5 = run_config5(rt, args, sc, rank, world, local_rank, group, scheme)
+        config5 = run_config5(rt, args, sc, rank, world, local_rank, group, scheme, link)
 
     if rank == 0:
         fps = args.steps / dt                                 # whole-job frames per second of the ONE frame
@@ -594,12 +702,15 @@ def main(argv=None, rt=None, emit=None):
         out = {
             "metric": ("denoised frames/s (1920x1080: GI 1 spp + SVGF temporal + a-trous)" if do_gi else
                        "denoised frames/s (1920x1080: SVGF temporal + a-trous only)"),
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_frames": max(Workload.SETTLE_FRAMES - max(args.warmup, 2), 0),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": warmup_run,
+            # a second timed region of the same K steps after `settled_after_frames` frames of this context (value: after W only)
+            "value_settled": args.steps / dt_settled, "ms_per_step_settled": dt_settled / args.steps * 1e3,
+            "settled_after_frames": warmup_run + args.steps + settle_run,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not args.scene else f"scene file {os.path.basename(args.scene)}; synthetic camera",
             "config": {"workload": workload_label(GW, GH, args.spp, L, do_gi),
                        "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
-                       "parallelism": parallelism, "halo_rows": halo_rows, "rows_per_strip": GH // world,
+                       "parallelism": parallelism, "link": (link.label() if link is not None else None), "halo_rows": halo_rows, "rows_per_strip": GH // world,
                        "frames_in_flight": 2 if (do_gi and args.overlap) else 1,
                        "scene_device_bytes": scene_bytes, "bvh": bvh, "library_build_id": library_build_id()},
             "frames_per_s_with_final_gather": fps_with_gather,

@@ -118,7 +118,7 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);
- *   "svgf_fuse":        1 (default) / 0, see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1 / 2, see neb_svgf_level_times. */
+ *   "svgf_fuse":        0 (default) / 1 (opt-in), see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1 / 2, see neb_svgf_level_times. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
 
 /* ---- resource sharing: the ~25 getters of SVGFDenoiser.h:24-70 collapse into one call.
@@ -141,16 +141,29 @@ int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream);
 /* SVGFDenoiser::SubmitATrousComputeWavelet (SVGFDenoiser.cpp:133-203): all levels, all rows.
  * Only valid when the context holds the full image (row_begin == 0, row_end == height).
  *
- * The two calls above, made in this order on the same stream with nothing between them -- what
- * DeferredRenderer::SubmitCommandsSVGFDenoising does (src/DeferredRenderer.cpp:593-614) -- run as ONE chain on a whole-frame
- * context whose width and height are multiples of 8: neb_svgf_temporal only notes the request, and neb_svgf_atrous runs the
- * temporal pass inside the staging phase of level 0 (the accumulated radiance is never written to memory: quirk 5 makes the
- * FILTERED image the next frame's history), carries the luminance between the levels and writes radiance[cur], moments[cur] and
- * variance exactly as the separate passes do -- the same bits.  Any other call in between (a plane pointer, an upload or
- * download, a row-range form, neb_end_frame ...) first submits the noted pass as its own kernel, so callers never observe the
- * difference, except in radiance[hist] and the scratch plane, which hold intermediate levels afterwards (as radiance[hist] does
- * in the reference), here with the luminance in .w.  Option "svgf_fuse" = 0 always runs the separate kernels. */
+ * By default both calls are stream-ordered at the call, as the reference records into its command list at the call
+ * (SVGFDenoiser.cpp:116,185): after neb_svgf_temporal returns, the pass is enqueued on `stream`.
+ *
+ * Option "svgf_fuse" = 1 (OPT-IN; the binding of INTEGRATION.md sets it in SVGFDenoiser::Init): the two calls, made in this order
+ * on the same stream with no other neb_* call between them -- what DeferredRenderer::SubmitCommandsSVGFDenoising does
+ * (src/DeferredRenderer.cpp:610-611) -- run as ONE chain on a whole-frame context whose width and height are multiples of 8:
+ * neb_svgf_temporal only NOTES the request (nothing is enqueued yet), and neb_svgf_atrous runs the temporal pass inside the
+ * staging phase of level 0 (the accumulated radiance is never written to memory: quirk 5 makes the FILTERED image the next
+ * frame's history), carries the luminance between the levels and writes radiance[cur], moments[cur] and variance exactly as the
+ * separate passes do -- the same bits.  Any other neb_* call in between (a plane pointer, an upload or download, a row-range
+ * form, neb_end_frame, neb_stream_synchronize ...) first submits the noted pass as its own kernel.
+ * WHO CAN SEE THE DIFFERENCE, and so must not opt in (or must call neb_end_frame / neb_stream_synchronize first): a host that kept
+ * plane pointers from an earlier neb_get_plane and, between the two calls, orders work on them WITHOUT going through the library
+ * -- a raw hipStreamSynchronize / hipEventRecord on `stream`, or a kernel of its own reading moments, variance or the accumulated
+ * radiance: until neb_svgf_atrous (or any other neb_* call) it finds them un-accumulated, and a launch error of the noted pass is
+ * reported by that later call.  After the chain, radiance[hist] and the scratch plane hold intermediate levels (as radiance[hist]
+ * does in the reference), here with the luminance in .w.  neb_svgf_denoise below is the same chain as one explicit call. */
 int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream);
+/* DeferredRenderer::SubmitCommandsSVGFDenoising's pair of calls (src/DeferredRenderer.cpp:610-611: SubmitTemporalAccumulation, then
+ * SubmitATrousComputeWavelet) as ONE entry point, whatever "svgf_fuse" says: the fused chain on a whole-frame context whose width
+ * and height are multiples of 8, the two separate passes otherwise; the same bits as neb_svgf_temporal + neb_svgf_atrous, everything
+ * enqueued on `stream` when the call returns.  Only valid when the context holds the full image. */
+int neb_svgf_denoise(neb_ctx* ctx, neb_stream stream);
 /* With option "svgf_profile" = 1, neb_svgf_atrous brackets each of its kernels with events on `stream`; this call waits for the
  * last chain submitted and returns the kernels' durations in microseconds (entry 0 = level 0, fused with the temporal pass when
  * the chain ran fused), *n_out = how many.  With "svgf_profile" = 2 only three events are recorded and two durations returned:

@@ -44,6 +44,10 @@ namespace Neb
                 throw NebException(NEB_ERR_STATE, "SVGFDenoiser::Init: already initialised");
             neb_create_info info{device, width, height, rowBegin, rowEnd, numAtrousPasses};
             ThrowIfFailed(nullptr, neb_create(&info, &m_ctx), "neb_create");
+            // This class orders all its work on the planes through neb_* calls, so it opts into the held-back temporal pass:
+            // SubmitTemporalAccumulation + SubmitATrousComputeWavelet back to back run as one fused chain (nebulae_hip.h).
+            // A host that also touches cached plane pointers with raw HIP calls between the two: SetOption("svgf_fuse", 0).
+            ThrowIfFailed(m_ctx, neb_set_option(m_ctx, "svgf_fuse", 1), "neb_set_option");
             return true;
         }
         // The reference returns false on success (src/SVGFDenoiser.cpp:36) and its caller throws on it; fixed here.
@@ -73,6 +77,8 @@ namespace Neb
         // (called right after SubmitTemporalAccumulation on the same command list -- DeferredRenderer::SubmitCommandsSVGFDenoising's
         // order -- the two run as one fused chain: see neb_svgf_atrous in nebulae_hip.h)
         void SubmitATrousComputeWavelet(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_atrous(m_ctx, commandList), "neb_svgf_atrous"); }
+        // Both passes as one explicit call (DeferredRenderer::SubmitCommandsSVGFDenoising, src/DeferredRenderer.cpp:610-611)
+        void SubmitDenoising(neb_stream commandList) { ThrowIfFailed(m_ctx, neb_svgf_denoise(m_ctx, commandList), "neb_svgf_denoise"); }
         // Implementation knobs without a reference counterpart ("svgf_fuse", "svgf_profile", "atrous_variant", the "gi_*" options)
         void SetOption(const char* key, int value) { ThrowIfFailed(m_ctx, neb_set_option(m_ctx, key, value), "neb_set_option"); }
         // Durations (us) of the kernels of the last SubmitATrousComputeWavelet chain, after SetOption("svgf_profile", 1); returns how many

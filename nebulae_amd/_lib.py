@@ -61,6 +61,7 @@ _SIGS = {
     "neb_svgf_level_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "neb_svgf_temporal": (C.c_int, [C.c_void_p, C.c_void_p]),
     "neb_svgf_atrous": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neb_svgf_denoise": (C.c_int, [C.c_void_p, C.c_void_p]),
     "neb_svgf_temporal_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "neb_svgf_atrous_level_rows": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "neb_svgf_atrous_level_planes": (C.c_int, [C.c_void_p, C.c_uint32] + [C.POINTER(C.c_int)] * 4),

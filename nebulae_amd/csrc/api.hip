@@ -527,7 +527,7 @@ int neb_svgf_temporal_rows(neb_ctx* ctx, uint32_t row0, uint32_t row1, neb_strea
 // luminance)?  A whole frame whose every pixel both passes cover (Dispatch(W/8, H/8) floors), every level on the LDS kernel.
 static bool fused_chain_possible(const neb_ctx* ctx)
 {
-    if (!ctx->fuse || ctx->row_begin != 0 || ctx->row_end != ctx->H || (ctx->W % 8u) || (ctx->H % 8u) || ctx->levels == 0)
+    if (ctx->row_begin != 0 || ctx->row_end != ctx->H || (ctx->W % 8u) || (ctx->H % 8u) || ctx->levels == 0)
         return false;
     const SvgfLaunch L = make_launch(ctx, 0, ctx->H);
     for (uint32_t i = 0; i < ctx->levels; ++i)
@@ -542,7 +542,10 @@ int neb_svgf_temporal(neb_ctx* ctx, neb_stream stream)
         return NEB_ERR_INVALID_ARG;
     if (int rc = svgf_flush_pending(ctx))
         return rc;
-    if (fused_chain_possible(ctx)) { // held back: neb_svgf_atrous runs it inside level 0; anything else submits it first
+    // Stream-ordered by default, as the reference records at the call (SVGFDenoiser.cpp:116).  Only a host that opted in
+    // ("svgf_fuse" = 1: it promises to order work on the planes through neb_* calls) gets the pass held back for the fused chain:
+    // neb_svgf_atrous then runs it inside level 0; anything else submits it first.
+    if (ctx->fuse && fused_chain_possible(ctx)) {
         ctx->pending_temporal = true;
         ctx->pending_stream = (hipStream_t)stream;
         return NEB_OK;
@@ -654,6 +657,23 @@ int neb_svgf_atrous(neb_ctx* ctx, neb_stream stream)
                                     hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     return NEB_OK;
+}
+
+// DeferredRenderer::SubmitCommandsSVGFDenoising's two calls (src/DeferredRenderer.cpp:610-611) as ONE entry point: the fused
+// chain where the context allows it, the separate kernels otherwise -- the same bits either way, nothing held back.
+int neb_svgf_denoise(neb_ctx* ctx, neb_stream stream)
+{
+    if (!ctx)
+        return NEB_ERR_INVALID_ARG;
+    if (ctx->row_begin != 0 || ctx->row_end != ctx->H)
+        return fail(ctx, NEB_ERR_STATE, "neb_svgf_denoise: context holds a row strip; use the row-range forms");
+    if (int rc = svgf_flush_pending(ctx))
+        return rc;
+    if (fused_chain_possible(ctx))
+        return svgf_fused_chain(ctx, (hipStream_t)stream);
+    if (int rc = neb_svgf_temporal_rows(ctx, ctx->row_begin, ctx->row_end, stream))
+        return rc;
+    return neb_svgf_atrous(ctx, stream);
 }
 
 int neb_svgf_level_times(neb_ctx* ctx, float* out_us, uint32_t capacity, uint32_t* n_out)

@@ -114,7 +114,7 @@ struct neb_ctx {
     uint32_t geom_lo = 0, geom_hi = 0; // image rows [geom_lo, geom_hi) of the geometry plane hold this frame's decoded normal / depth
     neb_svgf_params params{};
     int atrous_variant = 1; // 0 = direct-load kernel, 1 = LDS row-lattice kernel
-    int fuse = 1;           // option svgf_fuse: run temporal + a-trous of a whole frame as the fused chain (0: always the separate kernels)
+    int fuse = 0;           // option svgf_fuse (opt-in): hold neb_svgf_temporal of a whole frame back so that neb_svgf_atrous can run both as the fused chain
     bool pending_temporal = false; // a neb_svgf_temporal held back for the fused chain
     hipStream_t pending_stream = nullptr;
     int profile = 0;                   // option svgf_profile: neb_svgf_atrous brackets its kernels with events (neb_svgf_level_times)

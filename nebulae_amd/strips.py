@@ -49,23 +49,79 @@ def frame_factors(n):
     return a, n // a
 
 
-# Cost table behind the choice of the exchange scheme (microseconds; measured on one MI355X where a kernel is involved,
-# conservative guesses for the xGMI side until an N > 1 run replaces them -- override with NEB_STRIPS_EXCHANGE_LATENCY_US /
-# NEB_STRIPS_LINK_GBPS):
-ATROUS_US_PER_MPX_LEVEL = 16.0   # one a-trous level over a megapixel (33 us per 2.07 Mpx level at 1080p, profiles/r03*)
-GI_TEMPORAL_US_PER_MPX = 300.0   # the GI dispatch + the temporal pass over a megapixel (590 + 30 us per 2.07 Mpx)
-EXCHANGE_LATENCY_US = 12.0       # one grouped send + receive with a neighbour, launch to completion, message size aside
-LINK_GBPS = 60.0                 # sustained one-direction rate of one xGMI link for row blocks of a few hundred KB
+# Cost table behind the choice of the exchange scheme (microseconds).  The kernel side is measured on one MI355X; the xGMI side
+# (EXCHANGE_LATENCY_US, LINK_GBPS) are GUESSES until a run with N > 1 ranks measures them: `measure_link` does that in a few
+# milliseconds at start-up (bench.py calls it), and only a measured link lets "auto" leave the default scheme.
+# Override with NEB_STRIPS_EXCHANGE_LATENCY_US / NEB_STRIPS_LINK_GBPS.
+ATROUS_US_PER_MPX_LEVEL = 14.0   # one a-trous level over a megapixel (28 us per 2.07 Mpx level at 1080p, profiles/r03m*)
+GI_TEMPORAL_US_PER_MPX = 290.0   # the GI dispatch + the temporal pass over a megapixel (571 + 30 us per 2.07 Mpx)
+EXCHANGE_LATENCY_US = 12.0       # GUESS: one grouped send + receive with a neighbour, launch to completion, message size aside
+LINK_GBPS = 60.0                 # GUESS: sustained one-direction rate of one xGMI link for row blocks of a few hundred KB
 
 
-def scheme_costs(width, height, world, levels):
-    """-> {"once": us, "per_level": us}: what each exchange scheme ADDS to a frame of a middle strip.
+class Link:
+    """What one halo exchange with a neighbour costs: latency (us, launch to completion of a grouped send + receive of a few KB)
+    and the one-direction rate (GB/s) for row blocks of a few MB.  `measured` says whether the numbers come from measure_link."""
+
+    def __init__(self, latency_us=None, gbps=None, measured=False, note=""):
+        import os
+        self.latency_us = float(os.environ.get("NEB_STRIPS_EXCHANGE_LATENCY_US", EXCHANGE_LATENCY_US if latency_us is None else latency_us))
+        self.gbps = float(os.environ.get("NEB_STRIPS_LINK_GBPS", LINK_GBPS if gbps is None else gbps))
+        self.measured, self.note = bool(measured), note
+
+    def label(self):
+        return (f"link {'measured' if self.measured else 'UNMEASURED (guessed constants)'}: {self.latency_us:.1f} us per exchange, "
+                f"{self.gbps:.1f} GB/s per direction" + (f" ({self.note})" if self.note else ""))
+
+
+def measure_link(rank, world, group, make_buffer, synchronize, nbytes=2 << 20, iters=20, small_bytes=4096):
+    """Times the product's own exchange pattern -- one batch_isend_irecv of a send + a receive with a neighbour, both directions
+    at once -- between the pairs (0,1), (2,3), ...: `iters` exchanges of `small_bytes` (the latency) and of `nbytes` (2 MB: the
+    size of a 1080p frame's 62 halo rows), outside any timed region.  The result is the MAX over ranks (one all-reduce), so every
+    rank feeds the SAME constants to choose_scheme and picks the same scheme.  make_buffer(n) -> a uint8 tensor of n bytes where
+    the planes live (device memory under RCCL); synchronize() drains the device."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    if world < 2:
+        return Link()
+    peer = rank ^ 1
+    active = peer < world
+    out = []
+    for n in (small_bytes, nbytes):
+        tx, rx = make_buffer(n), make_buffer(n)
+
+        def once():
+            if active:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, tx, peer, group=group), dist.P2POp(dist.irecv, rx, peer, group=group)]):
+                    w.wait()
+            synchronize()
+        for _ in range(3):
+            once()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            once()
+        out.append((time.perf_counter() - t0) / iters * 1e6)
+    v = torch.tensor(out, dtype=torch.float64)
+    v = v.to(tx.device) if (tx.is_cuda and dist.get_backend(group) != "gloo") else v
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    t_small, t_big = float(v[0]), float(v[1])
+    # bytes / us / 1e3 = GB/s; when the two sizes take about as long (a latency-dominated or noisy transport) the difference says
+    # nothing: fall back to the conservative whole-message rate
+    gbps = ((nbytes - small_bytes) / (t_big - t_small) if t_big > 1.25 * t_small else nbytes / max(t_big, 1e-3)) / 1e3
+    return Link(t_small, gbps, measured=True,
+                note=f"{iters} exchanges of {small_bytes} B: {t_small:.1f} us each; of {nbytes} B: {t_big:.1f} us each; max over ranks; host-synchronised")
+
+
+def scheme_costs(width, height, world, levels, link=None):
+    """-> {"once": us, "per_level": us, "overlap": us}: what each exchange scheme ADDS to a frame of a middle strip.
     once: sum_l 2 e_l redundant row-levels of a-trous + ONE exchange of h = sum 2*2^l rows x 18 B/px (the exchange runs beside
     the interior of level 0: only what exceeds that level's own time is charged); per_level: L exchanges of 2*2^l rows x 16 B/px,
     each a sync point in front of its level (nothing to overlap with)."""
-    import os
-    lat = float(os.environ.get("NEB_STRIPS_EXCHANGE_LATENCY_US", EXCHANGE_LATENCY_US))
-    gbps = float(os.environ.get("NEB_STRIPS_LINK_GBPS", LINK_GBPS))
+    link = link or Link()
+    lat, gbps = link.latency_us, link.gbps
     rows = height // world
     halo = sum(2 * (1 << l) for l in range(levels))
     redundant_rows = sum(2 * sum(2 * (1 << m) for m in range(l + 1, levels)) for l in range(levels))
@@ -80,27 +136,32 @@ def scheme_costs(width, height, world, levels):
     return {"once": once, "per_level": per_level, "overlap": overlap}
 
 
-def choose_scheme(width, height, world, levels):
-    """-> (scheme, reason): the cheaper scheme by scheme_costs; "once" needs strips at least as tall as its halo."""
+def choose_scheme(width, height, world, levels, link=None):
+    """-> (scheme, reason).  "once" needs strips at least as tall as its halo.  Without a MEASURED link the answer is the default,
+    "once" (one sync point per frame; the cost table is printed but does not decide: its xGMI constants are guesses); with one
+    (measure_link) the cheaper scheme by scheme_costs."""
     if world == 1 or levels == 0:
         return "once", "single strip"
-    c = scheme_costs(width, height, world, levels)
+    link = link or Link()
+    c = scheme_costs(width, height, world, levels, link)
     halo_once = 2 * ((1 << levels) - 1)
     if height // world < halo_once:
         return "per_level", f"strips of {height // world} rows are shorter than the {halo_once}-row halo of 'once'"
-    pick = min(("once", "per_level", "overlap"), key=lambda k: c[k])
-    return pick, (f"cost table: once +{c['once']:.0f} us, per_level +{c['per_level']:.0f} us, overlap +{c['overlap']:.0f} us per frame at "
-                  f"{height // world}-row strips")
+    table = (f"cost table: once +{c['once']:.0f} us, per_level +{c['per_level']:.0f} us, overlap +{c['overlap']:.0f} us per frame at "
+             f"{height // world}-row strips; {link.label()}")
+    if not link.measured:
+        return "once", "default (the link constants are unmeasured, so the table does not decide); " + table
+    return min(("once", "per_level", "overlap"), key=lambda k: c[k]), table
 
 
 class StripPartition:
-    def __init__(self, width, height, world, levels, scheme=None):
+    def __init__(self, width, height, world, levels, scheme=None, link=None):
         import os
         if height % world:
             raise ValueError(f"image height {height} is not divisible by {world} strips")
         scheme = scheme or os.environ.get("NEB_STRIPS_SCHEME") or "auto"
         if scheme == "auto":
-            self.scheme, self.scheme_reason = choose_scheme(width, height, world, levels)
+            self.scheme, self.scheme_reason = choose_scheme(width, height, world, levels, link)
         else:
             self.scheme, self.scheme_reason = scheme, "requested"
         if self.scheme not in ("once", "per_level", "overlap"):

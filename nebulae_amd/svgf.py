@@ -50,6 +50,9 @@ class SVGFDenoiser:
         rc = self._lib.neb_create(C.byref(info), C.byref(ctx))
         _lib.check(self._lib, None, rc, "neb_create")
         self._ctx = ctx
+        # like the binding of INTEGRATION.md: this class orders its work on the planes through neb_* calls only, so it opts into
+        # the held-back temporal pass (the two submit calls back to back = one fused chain).  The raw C ABI's default is 0.
+        self.set_option("svgf_fuse", 1)
         self.device = int(device)
         self.width, self.height = width, height
         self.row_begin, self.row_end = row_begin, (row_end or height)
@@ -171,6 +174,10 @@ class SVGFDenoiser:
 
     def submit_atrous_compute_wavelet(self, stream=0):
         self._check(self._lib.neb_svgf_atrous(self._ctx, C.c_void_p(stream)), "neb_svgf_atrous")
+
+    def submit_denoising(self, stream=0):
+        """neb_svgf_denoise: both passes as one explicit call (the fused chain where the context allows it)."""
+        self._check(self._lib.neb_svgf_denoise(self._ctx, C.c_void_p(stream)), "neb_svgf_denoise")
 
     def level_times(self):
         """Durations (us) of the kernels of the last submit_atrous_compute_wavelet chain (option svgf_profile = 1): entry 0 is

@@ -162,3 +162,59 @@ def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     assert c5["reference_policy"]["mrays_per_s"] > 0
     assert d["frames_per_s_with_final_gather"] > 0
     assert d["mrays_per_s"] > 0 and len(d["kernel_us"]["atrous_levels"]) == 5
+    # the contract's warm-up count is what ran in front of `value`; the settled rate rides beside it
+    assert d["warmup"] == 2 and d["warmup_run"] == 2 and d["value_settled"] > 0 and d["settled_after_frames"] >= 4
+    # the scheme chooser was fed a link measured at start-up (20 exchanges of 4 KB and of 2 MB with a neighbour), not guesses
+    assert cfg["link"].startswith("link measured: ") and "20 exchanges of 4096 B" in cfg["link"] and "of 2097152 B" in cfg["link"]
+    if scheme == "auto":
+        assert "cost table: once +" in cfg["parallelism"] and "link measured" in cfg["parallelism"]
+
+
+_ARGV = ["--steps", "2", "--warmup", "1", "--width", "64", "--height", "256", "--cpu-frames", "0", "--triangles", "2000", "--tex-size", "16",
+         "--no-weak", "--levels", "3"]
+
+
+def test_launcher_starts_the_ranks_and_relays_rank0s_line():
+    """`python3 bench.py --gpus N` with no launcher around it: bench.launch_ranks is what main() calls then (WORLD_SIZE unset).
+    Here with the CPU stand-in as the child program: two ranks under gloo, ONE JSON line relayed, exit code 0."""
+    sys.path.insert(0, ROOT)
+    import bench
+    lines = []
+    child = [sys.executable, os.path.join(ROOT, "tests", "bench_dry_child.py")]
+    rc = bench.launch_ranks(2, ["--gpus", "2"] + _ARGV, child=child, emit=lines.append, timeout=600)
+    assert rc == 0
+    js = [l for l in lines if l.startswith("{")]
+    assert len(js) == 1
+    d = json.loads(js[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "row-strips x2" in d["config"]["parallelism"]
+
+
+def test_launcher_stops_every_rank_when_one_fails():
+    sys.path.insert(0, ROOT)
+    import time
+
+    import bench
+    lines = []
+    child = [sys.executable, os.path.join(ROOT, "tests", "bench_dry_child.py")]
+    os.environ["NEB_DRY_CHILD_FAIL_RANK"] = "1"
+    try:
+        t0 = time.time()
+        rc = bench.launch_ranks(2, ["--gpus", "2"] + _ARGV, child=child, emit=lines.append, timeout=600)
+    finally:
+        del os.environ["NEB_DRY_CHILD_FAIL_RANK"]
+    assert rc == 3 and not lines and time.time() - t0 < 120  # rank 0 was waiting in the rendezvous: terminated, not waited for
+
+
+def test_bare_bench_gpus_2_is_its_own_launcher_and_fails_loudly_without_a_gpu():
+    """The driver's form, `python3 bench.py --gpus 2 ...`, typed in a container without a GPU: the parent must start two ranks
+    (no "launch with torch.distributed.run" refusal), each rank must refuse to run without a device (no CPU fallback), and the
+    parent must exit non-zero."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-frames", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_bench_gpu.py")
+    assert p.returncode != 0
+    assert "needs a GPU" in p.stderr and "exited with code" in p.stderr and "torch.distributed.run" not in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

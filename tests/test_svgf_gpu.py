@@ -168,6 +168,105 @@ def test_held_back_temporal_pass_is_submitted_by_any_other_call():
     d.destroy()
 
 
+def _raw_views(lib, ctx, W, H):
+    """torch views on plane pointers obtained ONCE from neb_get_plane -- the advertised resource-sharing path ("valid until
+    resize / destroy") -- as a host that caches them would hold."""
+    import ctypes as C
+
+    import torch
+    from nebulae_amd.svgf import PLANE_LAYOUT
+    out = {}
+    for name, plane, slot in (("rad0", PLANE_RADIANCE, 0), ("rad1", PLANE_RADIANCE, 1), ("mom0", PLANE_MOMENTS, 0), ("mom1", PLANE_MOMENTS, 1),
+                              ("var", PLANE_VARIANCE, 0), ("dep0", PLANE_DEPTH, 0), ("dep1", PLANE_DEPTH, 1), ("nor0", PLANE_NORMAL, 0),
+                              ("nor1", PLANE_NORMAL, 1)):
+        d, pitch, rows = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        assert lib.neb_get_plane(ctx, plane, slot, C.byref(d), C.byref(pitch), C.byref(rows)) == 0
+        dt, ch = PLANE_LAYOUT[plane]
+
+        class _H:
+            pass
+        h = _H()
+        h.__cuda_array_interface__ = {"shape": (H, W, ch) if ch > 1 else (H, W), "typestr": {np.float32: "<f4", np.float16: "<f2", np.uint32: "<i4"}[dt],
+                                      "data": (d.value, False), "version": 2, "strides": None}
+        out[name] = torch.as_tensor(h, device="cuda:0")
+    return out
+
+
+@pytest.mark.parametrize("fuse", [None, 1])
+def test_raw_abi_host_with_cached_plane_pointers_and_its_own_stream_sync(fuse):
+    """The host the header names: it keeps the pointers neb_get_plane returned, writes the frame's inputs through them, calls
+    neb_svgf_temporal and then orders its own work with RAW stream operations (torch.cuda.synchronize here), never a neb_* call.
+    Default ("svgf_fuse" = 0, what a raw C-ABI user gets): the pass is enqueued AT the call, as the reference records at the call
+    (SVGFDenoiser.cpp:116) -- moments, variance and the accumulated radiance are there after the sync.
+    Opt-in ("svgf_fuse" = 1): the pass is only noted -- the planes are still un-accumulated after the raw sync, exactly as
+    include/nebulae_hip.h says -- and any neb_* call (here neb_end_frame) submits it."""
+    import ctypes as C
+
+    import torch
+    from nebulae_amd import _lib
+    W, H, L = 128, 96, 3
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    info = _lib.CreateInfo(0, W, H, 0, 0, L)
+    assert lib.neb_create(C.byref(info), C.byref(ctx)) == 0
+    if fuse is not None:
+        assert lib.neb_set_option(ctx, b"svgf_fuse", fuse) == 0
+    v = _raw_views(lib, ctx, W, H)          # cached once, before any frame
+    o = OracleSVGF(W, H, L)
+    for f in (1, 2, 3):
+        g, rad = frame_inputs(W, H, f, None)
+        assert lib.neb_begin_frame(ctx, f) == 0
+        c = f & 1
+        o.begin_frame(f)
+        o.depth[c][...], o.normal[c][...], o.radiance[c][...] = g["depth"], g["normal"], rad
+        v[f"dep{c}"].copy_(torch.from_numpy(g["depth"].view(np.int32)))
+        v[f"nor{c}"].copy_(torch.from_numpy(g["normal"]))
+        v[f"rad{c}"].copy_(torch.from_numpy(rad))
+        before = v[f"mom{c}"].clone()
+        torch.cuda.synchronize()
+        assert lib.neb_svgf_temporal(ctx, None) == 0
+        torch.cuda.synchronize()            # raw HIP ordering: no neb_* call
+        o.temporal_pass()
+        if fuse == 1 and f == 3:
+            assert torch.equal(v[f"mom{c}"], before)  # held back: nothing was enqueued (the documented hazard of opting in)
+            assert lib.neb_end_frame(ctx) == 0        # ... until any neb_* call
+            torch.cuda.synchronize()
+        if fuse is None or f == 3:
+            assert rel_l2(v[f"rad{c}"].cpu().numpy(), o.radiance[c]) < TOL_PASS
+            tol = 4e-7 * float(rad[..., :3].max()) ** 2 + 1e-6
+            assert half_ulp_mismatch(v[f"mom{c}"].cpu().numpy(), o.moments[c], abs_tol=tol) < 1e-3
+            assert half_ulp_mismatch(v["var"].cpu().numpy().reshape(H, W), o.variance, abs_tol=tol) < 1e-3
+        if f < 3:
+            assert lib.neb_svgf_atrous(ctx, None) == 0
+            o.atrous_pass()
+            torch.cuda.synchronize()
+            assert rel_l2(v[f"rad{c}"].cpu().numpy(), o.radiance[c]) < TOL_E2E
+        assert lib.neb_end_frame(ctx) == 0
+    lib.neb_destroy(ctx)
+
+
+def test_denoise_entry_point_equals_the_two_calls_bit_for_bit():
+    """neb_svgf_denoise (SubmitCommandsSVGFDenoising's pair as one call; fused chain whatever "svgf_fuse" says) == neb_svgf_temporal +
+    neb_svgf_atrous as separate kernels, on a fusable and on a ragged frame."""
+    for W, H, L in ((136, 104, 4), (100, 52, 3)):
+        a, b = make(W, H, L), make(W, H, L)
+        a.set_option("svgf_fuse", 0)
+        b.set_option("svgf_fuse", 0)
+        for f in (1, 2, 3):
+            g, rad = frame_inputs(W, H, f, 3)
+            feed(a, None, f, g, rad)
+            feed(b, None, f, g, rad)
+            a.submit_denoising()
+            b.submit_temporal_accumulation()
+            b.submit_atrous_compute_wavelet()
+            for pl in (PLANE_RADIANCE, PLANE_MOMENTS, PLANE_VARIANCE):
+                assert np.array_equal(a.download(pl), b.download(pl)), (W, H, f, pl)
+            a.end_frame()
+            b.end_frame()
+        a.destroy()
+        b.destroy()
+
+
 def test_level_times_need_the_profile_option_and_report_one_duration_per_kernel():
     W, H, L = 256, 128, 4
     d = make(W, H, L)
