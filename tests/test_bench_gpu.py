@@ -26,6 +26,7 @@ def test_single_gpu_line():
               "dtype", "data", "config", "roofline", "cpu_baseline", "svgf_roofline", "svgf_fused_model", "frame_roofline", "kernel_us"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["warmup"] == 2 and d["warmup_run"] == 2 and d["value_settled"] > 0 and d["settled_after_frames"] >= 48
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
     # one GPU: temporal + level 0 ran as one launch, the pure levels are timed by the library's own events
     ku = d["kernel_us"]
@@ -68,9 +69,13 @@ def test_scene_file_replaces_the_stand_in():
 @pytest.mark.parametrize("scheme", ["once", "per_level"])
 def test_two_rank_rehearsal(scheme):
     env = dict(os.environ, NEB_BENCH_SHARE_DEVICE="1", NEB_BENCH_BACKEND="gloo", NEB_STRIPS_SCHEME=scheme)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29650 + (os.getpid() % 200)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+    # "once": the driver's own form, `python bench.py --gpus 2 ...` with no launcher around it (bench.py starts its ranks itself);
+    # "per_level": under torch.distributed.run, as the contract also allows
+    launcher = [] if scheme == "once" else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                            "--master-port", str(29650 + (os.getpid() % 200))]
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--cpu-frames", "0", "--gather", "--tex-size", "256"] + (["--config5", "--config5-frames", "4"] if scheme == "once" else [])
+    env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
@@ -79,6 +84,7 @@ def test_two_rank_rehearsal(scheme):
     assert ("one exchange per frame" if scheme == "once" else "one exchange per a-trous level") in d["config"]["parallelism"]
     assert f"scheme '{scheme}'" in d["config"]["parallelism"] and "transport 'torch'" in d["config"]["parallelism"]
     assert d["frames_per_s_with_final_gather"] > 0
+    assert d["config"]["link"].startswith("link measured: ") and d["value_settled"] > 0 and d["warmup_run"] == 2
     assert d["weak_scaling"]["global_height"] == 2160 and d["weak_scaling"]["rows_per_strip"] == 1080 and d["weak_scaling"]["frames_per_s_1080p_equivalents"] > 0
     if scheme == "once":
         c5 = d["config5"]
