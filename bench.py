@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--svgf-only", action="store_true", help="skip the GI dispatch (synthetic noisy radiance instead)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the loop with the final gather of all strips to rank 0 after every frame")
     ap.add_argument("--sort-rays", type=int, default=-1, help="GI ray sorting mask: bit 0 shadow rays, bit 1 bounce rays (-1 = library default)")
+    ap.add_argument("--sun-table", type=int, default=int(os.environ.get("NEB_BENCH_SUN_TABLE", "-1")),
+                    help="GI sun-visibility table: 1 on, 0 off (every shadow ray traced; same results), -1 = library default (on)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the GI stages of frame f+1 on a side stream while frame f is denoised (measured: +1 %%, off by default)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (the frame that grows with N)")
@@ -390,6 +392,8 @@ class Workload:
         self.rad_view = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
         if args.sort_rays >= 0:
             r.svgf.set_option("gi_sort_rays", args.sort_rays)
+        if args.sun_table >= 0:
+            r.svgf.set_option("gi_sun_table", args.sun_table)
         r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
         rt.synchronize()
         self.direct = self.rad_view[r.svgf.get_current_resource_index()].clone()

@@ -117,6 +117,10 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *   "gi_exact_shade":   1 = hit shading in the C arithmetic of the CPU oracle (IEEE division, sqrt, powf, sinf / cosf) instead of
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;
+ *   "gi_sun_table":     1 (default) / 0: answer the sun-visibility query of a hit from the per-triangle table where it is proven
+ *                       (neb_gi_sun_table_stats) instead of tracing the shadow ray, and trace the rest from compacted ray lists;
+ *                       2 = the table answers but the remaining rays keep the sorted / tiled pass (A/B arm); results are bit-identical
+ *                       in all three;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);
  *   "svgf_fuse":        0 (default) / 1 (opt-in), see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1 / 2, see neb_svgf_level_times. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
@@ -306,6 +310,13 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
 /* Diagnostics: counters as of the last neb_gi_ray_count call: {rays, bounce node visits, bounce triangle tests,
  * shadow node visits, shadow triangle tests}; the shadow entries are only collected while "gi_debug_hits" is 1. */
 int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5]);
+/* The sun-visibility table (no reference counterpart: the reference's shadow rays go to the driver's TraceRay,
+ * assets/shaders/pathtracer.hlsl:567-569).  Every shadow ray of the path points at the sun disk; for each (triangle, side) the
+ * library decides once per sun position -- exactly, from the scene's geometry -- whether ANY such ray leaving it can meet ANY
+ * triangle; where none can, the hit's sun-visibility query is answered without a traversal, with the traversal's own answer.
+ * out = {triangle sides proven lit on the +normal side, on the -normal side (last build), shadow rays answered by the table as of
+ * the last neb_gi_ray_count call (they are part of its count: a ray = a visibility query), table builds so far}. */
+int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream);
 /* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);
 /* Diagnostics / tests: runs the library's ray-reordering sort (raysort.hip: stable LSD radix sort on key bits

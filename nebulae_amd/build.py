@@ -6,7 +6,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnebulae_hip.so")
-SOURCES = ["api.hip", "svgf.hip", "gi.hip", "gi_build.hip", "raysort.hip", "strips.hip"]
+SOURCES = ["api.hip", "svgf.hip", "gi.hip", "gi_build.hip", "gi_sun_table.hip", "raysort.hip", "strips.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-fno-slp-vectorize"]  # keeps LLVM from forming v_pk_*_f32 pairs: they issue at half rate on gfx950 (tools/ubench_valu2.hip)
 

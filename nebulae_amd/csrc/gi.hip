@@ -67,7 +67,9 @@ struct GiArgs {
     neb_gi_hit* hits;            // may be null
     unsigned long long* ray_counter; // diagnostics: [1..4] traversal steps (only touched when stats != 0)
     uint32_t* bounce_counts;     // per-workgroup bounce-ray counts
-    uint32_t* shadow_counts;     // per-workgroup shadow-ray counts
+    uint32_t* shadow_counts;     // per-workgroup shadow-ray counts (every sun-visibility query, traced or answered by the table)
+    uint32_t* table_counts;      // per-workgroup count of the shadow rays the sun table answered
+    uint32_t sun_table;          // 1: the shading records carry the sun-visibility table of THIS frame's sun (gi_sun_table.hip)
     uint32_t W, row_begin, row0, row1, tiles_x;
     uint32_t sample;             // index of the sample this launch handles
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
@@ -79,6 +81,12 @@ struct GiArgs {
     uint32_t* bsort_keys;        // same for the bounce rays ("gi_sort_rays" bit 1): key = direction octant | origin Morton code
     uint32_t* bsort_vals;
     uint32_t raygen_only;        // 1: gi_raygen_trace_kernel only writes the ray record and its key (a sorted trace follows)
+    // Shadow rays that still need a walk once the sun table has answered the rest (~14 % on the bench frame), compacted by the
+    // shade pass: kListSegments lists, workgroup b appends to list b % kListSegments with ONE atomic per wave (spread over the
+    // segments: a single hot word takes only ~90 atomics/us), each list sized for every pixel of its workgroups, so none can overflow.
+    uint32_t* list;              // [kListSegments][list_cap] pixel indices, or null: the uncompacted paths
+    uint32_t* list_counts;       // [2][kListSegments]: the set this launch fills (list_set) and the one gi_shadow_trace_kernel clears for the next
+    uint32_t list_cap, list_set;
     float smin[3], sinv[3];      // scene box for the Morton keys
     uint32_t first_px, n_px;     // dispatched pixel range [first_px, first_px + n_px) of the resident planes
 };
@@ -100,6 +108,7 @@ __device__ __forceinline__ uint32_t gi_block()
     return seg * seg_len + (xcd < r ? xcd * (q + 1u) + k : r * (q + 1u) + (xcd - r) * q + k);
 }
 constexpr uint32_t kShadeRuns = 16u, kRaygenRuns = 16u;
+constexpr uint32_t kListSegments = 128u;
 
 template <uint32_t RUNS = 0u>
 __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
@@ -227,7 +236,8 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_bounce_trace_kernel(Gi
 // What gi_shade_kernel leaves for a pixel's shadow pass (GiRecords::srec) and how many shadow rays it made.
 struct ShadeOut {
     float4 rec_o = {0.f, 0.f, 0.f, 0.f}, shadow_d = {0.f, 0.f, 0.f, 0.f} /* valid = 0: no shadow ray */, rec_c = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f};
-    uint32_t rays = 0;
+    uint32_t rays = 0;  // sun-visibility queries of this pixel (0 / 1)
+    uint32_t table = 0; // ... answered by the sun table instead of a traversal
 };
 
 // Shading of path vertex a.bounce of pixel i, whose bounce ray ended in `h` {t (< 0 miss), u, v, triangle}: miss -> sky; hit ->
@@ -285,10 +295,36 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
             const bool transition = dot3(surf.GN, inc) <= 0.0f;
             const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
             const float3 O = evaluate_direct_brdf<FAST>(surf, V, L) * sun_rad * throughput; // :573-574
-            o.rec_o = make_float4(so.x, so.y, so.z, 0.001f);
-            o.shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
-            o.rec_c = make_float4(O.x, O.y, O.z, 0.f);
             o.rays = 1;
+            const uint32_t side = transition ? 1u : 0u;
+            bool hinted_hit = false;
+            if (a.sun_table && !((ts.lit >> side) & 1u) && ts.hint_side == side && ts.hint0 != kNoHint) {
+                // Occluder hints: the (up to) two triangles whose shadow covers most of this triangle (chosen once per sun position).
+                // They are tried with the traverser's own test on the very ray the shadow pass would walk -- same operands, same
+                // arithmetic -- so a hit is a hit of the any-hit traversal too: "occluded", exactly, without the walk.
+                const uint32_t h0 = ts.hint0, h1 = ts.hint1 != kNoHint ? ts.hint1 : ts.hint0;
+                const float4 a0 = a.S.tris[3 * h0], b0 = a.S.tris[3 * h0 + 1], c0 = a.S.tris[3 * h0 + 2];
+                const float4 a1 = a.S.tris[3 * h1], b1 = a.S.tris[3 * h1 + 1], c1 = a.S.tris[3 * h1 + 2];
+                float tt, uu, vv;
+                hinted_hit = intersect_tri_regs(a0, b0, c0, so, inc, 0.001f, kTraceMax, tt, uu, vv) ||
+                             intersect_tri_regs(a1, b1, c1, so, inc, 0.001f, kTraceMax, tt, uu, vv);
+            }
+            if (hinted_hit) {
+                o.table = 1; // occluded: nothing is added, no ray
+            } else if (a.sun_table && ((ts.lit >> side) & 1u)) {
+                // every shadow ray that leaves this triangle on this side is unoccluded (proven once per sun position,
+                // gi_sun_table.hip): what gi_shadow_trace_kernel would do after its walk -- radiance += BRDF * sunRadiance * throughput
+                // (:571-575) -- is done here, same operands, same order; no ray, no sort key, no record to gather
+                o.sum.x += O.x;
+                o.sum.y += O.y;
+                o.sum.z += O.z;
+                o.table = 1;
+                dbg.flags |= 1u;
+            } else {
+                o.rec_o = make_float4(so.x, so.y, so.z, 0.001f);
+                o.shadow_d = make_float4(inc.x, inc.y, inc.z, 1.0f);
+                o.rec_c = make_float4(O.x, O.y, O.z, 0.f);
+            }
             if (a.bounce + 1 < a.c.maxPathVertices) { // not the last vertex (:579-583): sample the next bounce
                 // EvaluateIndirectBRDF (:230-259) takes rng BY VALUE: its draws do not advance the path's stream,
                 // so the Rand(rng) of :614 returns the same number as the first of them.
@@ -367,6 +403,48 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
     __syncthreads(); // (waits for the DMA: an LDS-DMA is a pending LDS write on the VM counter)
     if (active)
         shade_pixel<FAST, true>(a, i, h, o, smem + lane * 8u, lane & 7u);
+    if (a.list) {
+        // Compacted tail (the sun table is on: most pixels have no ray left to trace).  A pixel WITHOUT a ray is finished here, in
+        // tile order: what gi_shadow_trace_kernel does for it after gathering its record in sorted order -- radiance[cur] += sum / spp
+        // on the last vertex of the last sample (the stand-in for NRC Resolve), otherwise carry the sum -- same operands, same
+        // order.  A pixel WITH a ray writes its 64-byte record and appends itself to one of the ray lists.
+        const bool trace = active && o.shadow_d.w != 0.0f;
+        const bool final_vertex = a.sample + 1 == a.c.samplesPerPixel && a.bounce + 1 >= a.c.maxPathVertices && !a.defer_resolve;
+        if (active && !trace) {
+            if (final_vertex) {
+                if (o.sum.x != 0.0f || o.sum.y != 0.0f || o.sum.z != 0.0f) {
+                    const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
+                    float4 r = a.radiance[i];
+                    r.x += o.sum.x * inv_spp;
+                    r.y += o.sum.y * inv_spp;
+                    r.z += o.sum.z * inv_spp;
+                    a.radiance[i] = r;
+                }
+            } else {
+                a.R.srec[4 * i + kSrSum] = o.sum;
+            }
+        }
+        const unsigned long long m = __ballot(trace);
+        if (m) {
+            const uint32_t seg = blockIdx.x % kListSegments;
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(a.list_counts + a.list_set * kListSegments + seg, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (trace) {
+                const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                a.list[(size_t)seg * a.list_cap + slot] = (uint32_t)i;
+                float4* rec = a.R.srec + 4 * i;
+                rec[kSrO] = o.rec_o;
+                rec[kSrD] = o.shadow_d;
+                rec[kSrContrib] = o.rec_c;
+                rec[kSrSum] = o.sum;
+            }
+        }
+        count_rays(a.shadow_counts, o.rays);
+        count_rays(a.table_counts, o.table);
+        return;
+    }
     // Store the 64-byte records of the wave's 8x8 tile.  Lane-per-pixel stores would write 16 bytes at a 64-byte stride
     // four times over; transposed through LDS, every store instruction writes two 512-byte runs (one tile row each).
     __syncthreads(); // every lane is done with its staged record: the buffer is reused
@@ -386,6 +464,7 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
             a.R.srec[4 * ((size_t)(py - a.row_begin) * a.W + px) + comp] = xpose[(row * 8 + col) * 4 + comp];
     }
     count_rays(a.shadow_counts, o.rays);
+    count_rays(a.table_counts, o.table);
 }
 
 // (A persistent-wave variant with per-lane ray refill was measured and dropped: lanes of a wave finish after
@@ -398,7 +477,19 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
     uint32_t x, y;
     size_t i = 0;
     bool valid;
-    if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
+    if (a.list) { // the compacted rays of the shade pass: list_cap / 64 waves per list, those behind a list's end leave at once
+        const uint32_t waves_per_list = a.list_cap / 64u;
+        const uint32_t seg = blockIdx.x / waves_per_list, first = (blockIdx.x - seg * waves_per_list) * 64u;
+        const uint32_t count = a.list_counts[a.list_set * kListSegments + seg];
+        if (blockIdx.x == 0) // the other set of counters is idle until the next shade launch fills it: clear it for that launch
+            for (uint32_t k = threadIdx.x; k < kListSegments; k += 64u)
+                a.list_counts[(a.list_set ^ 1u) * kListSegments + k] = 0u;
+        if (first >= count)
+            return;
+        valid = first + threadIdx.x < count;
+        if (valid)
+            i = a.list[(size_t)seg * a.list_cap + first + threadIdx.x];
+    } else if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
         const uint32_t j = blockIdx.x * 64u + threadIdx.x;
         valid = j < a.n_px;
         if (valid)
@@ -729,7 +820,11 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     // The shadow-ray sort pays for its six launches only on a dispatch large enough (measured, 1920 pixels wide: 136 rows GI
     // 169 us with it against 146 without, 272 rows 225 / 203, 544 rows 343 / 341, 1080 rows 590 / 605): unless the option was set
     // explicitly it is on from 1.5 M pixels.  Results do not depend on it (every pixel is written once, whatever the order).
-    const bool sort_shadow = g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow;
+    // With the sun table most shadow rays are answered in the shade pass; the rest are compacted into ray lists there and traced
+    // unsorted (the sort's six launches cost more than coherence is worth to the ~14 % that are left).
+    const bool use_table = g->sun_table; // (brought up to date below, before the first launch)
+    const bool compact = use_table && g->compact_shadow;
+    const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
     if (sort_shadow || g->sort_bounce) {
         if (!g->d_sort) {
             void* p = nullptr;
@@ -761,14 +856,35 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
     if (!g->d_block_counts) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t))); // {bounce, shadow} rays per workgroup
-        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow answered by the sun table} rays per workgroup
+        GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
         g->d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    a.table_counts = g->d_block_counts + 2 * g->n_block_counts;
+    // the sun-visibility table: brought up to date with this frame's sun (a rebuild only when the sun or the scene changed)
+    GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
+    a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
+    a.list = a.list_counts = nullptr;
+    a.list_cap = a.list_set = 0;
+    uint32_t list_waves = 0;
+    if (compact) {
+        const uint32_t wg_per_list = (uint32_t)((g->n_block_counts + kListSegments - 1) / kListSegments);
+        if (!g->d_list) {
+            void* p = nullptr;
+            GI_HIP(ctx, hipMalloc(&p, ((size_t)kListSegments * wg_per_list * 64u + 2u * kListSegments) * sizeof(uint32_t)));
+            GI_HIP(ctx, hipMemset(p, 0, 2u * kListSegments * sizeof(uint32_t))); // (the two counter sets sit in front of the lists)
+            g->allocs.push_back(p);
+            g->d_list = (uint32_t*)p;
+        }
+        a.list_counts = g->d_list;
+        a.list = g->d_list + 2u * kListSegments;
+        a.list_cap = wg_per_list * 64u;
+        list_waves = kListSegments * wg_per_list;
+    }
     const uint32_t n_vertices = c->maxPathVertices > 1 ? c->maxPathVertices - 1 : 1; // path vertices traced per sample
     for (uint32_t s = 0; s < c->samplesPerPixel; ++s) {
         a.sample = s;
@@ -787,11 +903,15 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             } else if (b > 1) {
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             }
+            a.list_set = g->list_epoch & 1u;
             if (kFastShade && !g->exact_shade)
                 hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
             else
                 hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
-            if (sort_shadow) {
+            if (a.list) {
+                hipLaunchKernelGGL(gi_shadow_trace_kernel, dim3(list_waves), block, 0, (hipStream_t)stream, a);
+                g->list_epoch++;
+            } else if (sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the
                 // sorted pixel indices land back in vals
                 GI_HIP(ctx, ray_sort_pairs(g->d_sort + a.first_px, g->d_sort + npx + a.first_px, g->d_sort + 2 * npx + a.first_px,
@@ -858,14 +978,15 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
     if (!g->d_block_counts) {
         void* p = nullptr;
-        GI_HIP(ctx, hipMalloc(&p, 2 * n_blocks * sizeof(uint32_t))); // {bounce, shadow} rays per workgroup
-        GI_HIP(ctx, hipMemset(p, 0, 2 * n_blocks * sizeof(uint32_t)));
+        GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow answered by the sun table} rays per workgroup
+        GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
         g->d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
+    a.table_counts = g->d_block_counts + 2 * g->n_block_counts;
     hipLaunchKernelGGL(pbr_direct_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
@@ -901,7 +1022,7 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
     GiState* g = ctx->gi;
     GI_GUARD(ctx);
     unsigned long long v[8] = {};
-    std::vector<uint32_t> counts(2 * g->n_block_counts);
+    std::vector<uint32_t> counts(3 * g->n_block_counts);
     GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (g->d_block_counts)
         GI_HIP(ctx, hipMemcpyAsync(counts.data(), g->d_block_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -912,9 +1033,12 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
         if (g->d_block_counts)
             GI_HIP(ctx, hipMemsetAsync(g->d_block_counts, 0, counts.size() * sizeof(uint32_t), (hipStream_t)stream));
     }
-    unsigned long long total = 0;
-    for (uint32_t c : counts)
-        total += c;
+    unsigned long long total = 0, table = 0;
+    for (size_t k = 0; k < 2 * g->n_block_counts; ++k)
+        total += counts[k];
+    for (size_t k = 2 * g->n_block_counts; k < counts.size(); ++k)
+        table += counts[k];
+    g->table_rays = table;
     v[0] = total;
     if (rays)
         *rays = total;
@@ -928,6 +1052,24 @@ int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5])
         return NEB_ERR_INVALID_ARG;
     for (int k = 0; k < 5; ++k)
         out[k] = ctx->gi->last_stats[k];
+    return NEB_OK;
+}
+
+int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream)
+{
+    if (!ctx || !ctx->gi || !out)
+        return NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    GI_GUARD(ctx);
+    unsigned long long sides[2] = {0, 0};
+    if (g->d_sun_counts && g->sun_table_state == 1) {
+        GI_HIP(ctx, hipMemcpyAsync(sides, g->d_sun_counts, sizeof(sides), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        GI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    }
+    out[0] = sides[0];
+    out[1] = sides[1];
+    out[2] = g->table_rays;
+    out[3] = g->sun_table_builds;
     return NEB_OK;
 }
 
@@ -1025,6 +1167,14 @@ int gi_set_defer_resolve(neb_ctx* ctx, int on)
     if (!ctx->gi)
         return NEB_ERR_STATE;
     ctx->gi->defer_resolve = on != 0;
+    return NEB_OK;
+}
+int gi_set_sun_table(neb_ctx* ctx, int on)
+{
+    if (!ctx->gi || on < 0 || on > 2)
+        return NEB_ERR_STATE;
+    ctx->gi->sun_table = on != 0;
+    ctx->gi->compact_shadow = on != 2; // 2 (A/B arm): the table answers, but the remaining rays keep the sorted / tiled shadow pass
     return NEB_OK;
 }
 int gi_set_debug_hits(neb_ctx* ctx, int on)

@@ -17,7 +17,7 @@ void gi_on_resize(GiState* g)
 {
     if (!g)
         return;
-    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts, g->d_sort, g->d_sort_temp};
+    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts, g->d_sort, g->d_sort_temp, g->d_list};
     for (void* p : stale) {
         if (!p)
             continue;
@@ -34,6 +34,7 @@ void gi_on_resize(GiState* g)
     g->n_block_counts = 0;
     g->d_sort = nullptr;
     g->d_sort_temp = nullptr;
+    g->d_list = nullptr;
 }
 
 void gi_destroy(GiState* g)
@@ -71,7 +72,7 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
         r[6] = make_float4(S.uvs[2 * i1 + 1], S.uvs[2 * i2], S.uvs[2 * i2 + 1], 0.f);
     }
     r[6].w = __uint_as_float(geom);
-    r[7].x = __uint_as_float(prim);
+    r[7] = make_float4(__uint_as_float(prim), __uint_as_float(kNoHint), __uint_as_float(kNoHint), 0.f); // (hints: gi_sun_table.hip)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         out[8 * (size_t)ti + k] = r[k];
@@ -1261,6 +1262,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     g->view.root = root_code;
     g->n_nodes = n_wide;
     g->bvh_depth = (uint32_t)max_depth;
+    g->sun_table_state = 0; // fresh shading records carry no sun-visibility flags yet
     g->built = true; // (h_tris stays: the scene can be rebuilt)
     return NEB_OK;
 }

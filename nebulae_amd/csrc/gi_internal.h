@@ -96,6 +96,11 @@ constexpr bool kFastShade = NEB_FAST_SHADE != 0;
 #define NEB_MAX_LEAF_TRIS 2 // 1..4 (the leaf code keeps count - 1 in two bits); measured 1/2/3/4: 1407 / 1390 / 1403 / 1500 us of GI per 1080p frame
 #endif
 constexpr int kMaxLeafTris = NEB_MAX_LEAF_TRIS;
+// The geometry word of a triangle's shading record (r6.w) carries the sun-visibility table in its two top bits
+// (gi_sun_table.hip): bit kLitShift = every shadow ray leaving the triangle on its +GN side is unoccluded, bit kLitShift + 1 = -GN side.
+constexpr uint32_t kLitShift = 30u, kGeomMask = (1u << kLitShift) - 1u;
+// ... and r7 = {PrimitiveIndex, occluder hint 0, hint 1, side the hints are for}: triangles most likely to shadow this one
+constexpr uint32_t kNoHint = 0xffffffffu;
 
 struct SceneView {
     const float4* tris;      // 3 x float4 per triangle: {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, geom, prim, -}
@@ -139,9 +144,20 @@ struct GiState {
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
-    uint32_t* d_block_counts = nullptr; // [2][n_block_counts]: bounce / shadow rays per workgroup
+    uint32_t* d_block_counts = nullptr; // [3][n_block_counts]: bounce rays / shadow rays / shadow rays answered by the sun table, per workgroup
     size_t n_block_counts = 0;
+    // the sun-visibility table in the shading records (gi_sun_table.hip)
+    bool sun_table = true;            // option "gi_sun_table"
+    int sun_table_state = 0;          // 0: the records carry no flags; 1: flags of sun_table_key
+    float sun_table_key[4] = {0, 0, 0, 0}; // {sunLightDirection, sunTanHalfAngle} the flags were built for
+    unsigned long long* d_sun_counts = nullptr; // sides proven lit {+, -} by the last build
+    uint32_t sun_table_builds = 0;
+    unsigned long long table_rays = 0; // shadow rays answered by the table as of the last neb_gi_ray_count
+    bool compact_shadow = true;       // with the table on: the rays it leaves are compacted into lists by the shade pass ("gi_sun_table" = 2: off)
+    uint32_t* d_list = nullptr;       // [2][kListSegments] counters, then [kListSegments][cap] pixel indices
+    uint32_t list_epoch = 0;          // shade launches so far: picks the counter set
 };
+hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream);
 
 void gi_on_resize(GiState* g);
 void gi_destroy(GiState* g);

@@ -1,0 +1,253 @@
+// gi_sun_table.hip -- the sun-visibility table: which (triangle, side) pairs are PROVABLY lit by the whole sun disk.
+//
+// Every shadow ray of the GI path points at the sun disk (assets/shaders/pathtracer.hlsl:533-575): it leaves the hit point by
+// GN * 1e-2 on the side the disk sample is on and goes along normalize(L + offset), |offset| <= tan(0.29 deg).  32 % of them end
+// unoccluded -- the expensive ones for an any-hit walk, which has no early exit to offer them -- and 95 % of those start on
+// a triangle from which NOTHING of the scene can be met by ANY ray of that family: a sunlit floor, the outer side of a roof.
+// That is a property of the triangle, the scene and the sun alone, so it is decided once per sun position: one thread per
+// triangle walks the BVH4 (the exact 128-byte nodes) for everything that reaches into the column its rays can sweep -- the
+// triangle's footprint along the sun direction, widened by tan(half angle) per unit climbed -- and asks the certificate of
+// lit_predicate.h (double precision, conservative: "cannot occlude" is certain) about every triangle found there, itself included.
+// Two bits per triangle land in the spare top bits of the geometry word of its 128-byte shading record, which gi_shade_kernel
+// has in registers anyway: a proven-lit ray costs no traversal, no sort slot worth of work and not one extra byte of traffic.
+// The answer is the traversal's own by construction (tests/test_gi_gpu.py: flags and radiance bit-identical with the table on
+// and off, every GI scene and the bench frame).  Rebuilt (a few ms) when sunLightDirection / sunTanHalfAngle change or the
+// scene is rebuilt -- the reference marks such a frame dynamic anyway (src/DeferredRenderer.cpp:169-171).
+//
+// This takes the place of the sun-space height map sized in round 3: a height map has to resolve the 1e-2 ray
+// offset against the slope of every lit surface (a 4096^2 map for a floor, and a max-plus filter for the cone), costs a
+// scattered fetch per ray, and is only as exact as its cells; the per-triangle certificate uses the exact geometry.
+#include "gi_device.h"
+#include "lit_predicate.h"
+
+namespace neb {
+
+struct SunTableArgs {
+    SceneView S;
+    lit::Frame F;
+    double scene_hmax; // highest point of the scene along L
+    float4* shade;     // the shading records (writable view of S.shade)
+    unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint
+};
+
+__device__ inline void node_child_box(const Bvh4Node& nd, int q, double lo[3], double hi[3])
+{
+    const float l0[4] = {nd.lox.x, nd.lox.y, nd.lox.z, nd.lox.w}, l1[4] = {nd.loy.x, nd.loy.y, nd.loy.z, nd.loy.w},
+                l2[4] = {nd.loz.x, nd.loz.y, nd.loz.z, nd.loz.w};
+    const float h0[4] = {nd.hix.x, nd.hix.y, nd.hix.z, nd.hix.w}, h1[4] = {nd.hiy.x, nd.hiy.y, nd.hiy.z, nd.hiy.w},
+                h2[4] = {nd.hiz.x, nd.hiz.y, nd.hiz.z, nd.hiz.w};
+    lo[0] = l0[q], lo[1] = l1[q], lo[2] = l2[q];
+    hi[0] = h0[q], hi[1] = h1[q], hi[2] = h2[q];
+}
+
+__global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
+{
+    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t flags = 0;
+    uint32_t hint[2] = {kNoHint, kNoHint};
+    bool hinted = false;
+    if (ti < a.S.n_tris) {
+        const float4 t0 = a.S.tris[3 * ti], t1 = a.S.tris[3 * ti + 1], t2 = a.S.tris[3 * ti + 2];
+        // the triangle the traverser tests: (v0, v0 + e1, v0 + e2) with e1, e2 as stored
+        const double v[3][3] = {{t0.x, t0.y, t0.z},
+                                {(double)t0.x + t0.w, (double)t0.y + t1.x, (double)t0.z + t1.y},
+                                {(double)t0.x + t1.z, (double)t0.y + t1.w, (double)t0.z + t2.x}};
+        const float4* rec = a.S.shade + 8 * (size_t)ti;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r6 = rec[6];
+        const uint32_t geom = __float_as_uint(r6.w) & kGeomMask;
+        const DevGeom g = a.S.geoms[geom];
+        lit::Receiver R[2];
+        R[0].valid = R[1].valid = false;
+        if (g.valid) { // (a submesh without its attribute streams ends the path at the hit: no shadow ray ever starts there)
+            const float n[3][3] = {{r0.x, r0.y, r0.z}, {r1.x, r1.y, r1.z}, {r2.x, r2.y, r2.z}};
+            double gn[3][3];
+            bool ok = true;
+            for (int i = 0; i < 3; ++i) {
+                // GN = normalize(xform_dir(M, normalize(sum b_i n_i))) lies in the cone of xform_dir(M, n_i): (p, 0) * M, row vectors
+                const double x = (double)n[i][0] * g.m[0] + (double)n[i][1] * g.m[3] + (double)n[i][2] * g.m[6];
+                const double y = (double)n[i][0] * g.m[1] + (double)n[i][1] * g.m[4] + (double)n[i][2] * g.m[7];
+                const double z = (double)n[i][0] * g.m[2] + (double)n[i][1] * g.m[5] + (double)n[i][2] * g.m[8];
+                const double l = sqrt(x * x + y * y + z * z);
+                ok = ok && l > 0.0 && l < 1e30;
+                gn[i][0] = x / l, gn[i][1] = y / l, gn[i][2] = z / l;
+            }
+            if (ok) {
+                lit::make_receiver(a.F, v, gn, +1, R[0]);
+                lit::make_receiver(a.F, v, gn, -1, R[1]);
+            }
+        }
+        bool alive[2] = {R[0].valid, R[1].valid};
+        // Occluder hints for the side the rays of this triangle start on (the one turned to the sun: the shader picks the side of
+        // GN the disk sample is on): the two triangles whose shadow covers most of the footprint.  gi_shade_kernel tries them
+        // with the traverser's own triangle test before it emits a shadow ray -- any hit answers "occluded" exactly.
+        const int primary = (R[0].valid && R[1].valid) ? (R[1].c_lo > R[0].c_lo ? 1 : 0) : (R[1].valid ? 1 : 0);
+        double best_area[2] = {0.0, 0.0};
+        if (R[0].valid || R[1].valid) {
+            // the column both sides' rays can sweep, in sun coordinates
+            double qa[2] = {1e300, -1e300}, qb[2] = {1e300, -1e300}, qh = 1e300;
+            for (int s = 0; s < 2; ++s)
+                if (R[s].valid) {
+                    const double reach = (a.scene_hmax - R[s].h_min + lit::kMarginH) * a.F.tau + lit::kMarginR;
+                    qa[0] = fmin(qa[0], R[s].bb_a[0] - reach), qa[1] = fmax(qa[1], R[s].bb_a[1] + reach);
+                    qb[0] = fmin(qb[0], R[s].bb_b[0] - reach), qb[1] = fmax(qb[1], R[s].bb_b[1] + reach);
+                    qh = fmin(qh, R[s].h_min - lit::kMarginH);
+                }
+            int stack[64];
+            int sp = 0;
+            int node = a.S.root;
+            auto test_leaf = [&](int code) {
+                const uint32_t c = (uint32_t)~code, first = c >> 2, count = (c & 3u) + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t tj = first + k;
+                    const float4 o0 = a.S.tris[3 * tj], o1 = a.S.tris[3 * tj + 1], o2 = a.S.tris[3 * tj + 2];
+                    const double w[3][3] = {{o0.x, o0.y, o0.z},
+                                            {(double)o0.x + o0.w, (double)o0.y + o1.x, (double)o0.z + o1.y},
+                                            {(double)o0.x + o1.z, (double)o0.y + o1.w, (double)o0.z + o2.x}};
+                    lit::Tri O;
+                    for (int i = 0; i < 3; ++i)
+                        lit::to_sun(a.F, w[i], O.a[i], O.b[i], O.h[i]);
+                    for (int s = 0; s < 2; ++s)
+                        if (alive[s] && lit::may_occlude(a.F, R[s], O))
+                            alive[s] = false;
+                    if (R[primary].valid && tj != ti) {
+                        const double c = lit::shadow_cover(R[primary], O);
+                        if (c > best_area[0]) {
+                            best_area[1] = best_area[0], hint[1] = hint[0];
+                            best_area[0] = c, hint[0] = tj;
+                        } else if (c > best_area[1]) {
+                            best_area[1] = c, hint[1] = tj;
+                        }
+                    }
+                }
+            };
+            if (node < 0) { // a scene of one leaf
+                test_leaf(node);
+                node = kTravDone;
+            }
+            while (node != kTravDone) { // (the whole column: a side that is already known to be shadowed still wants its hints)
+                const Bvh4Node nd = a.S.nodes[node];
+                const int ch[4] = {nd.child.x, nd.child.y, nd.child.z, nd.child.w};
+                node = kTravDone;
+                for (int q = 0; q < 4; ++q) {
+                    double lo[3], hi[3];
+                    node_child_box(nd, q, lo, hi);
+                    if (!(lo[0] <= hi[0])) // unused slot: inverted box
+                        continue;
+                    // sun-space bounds of the world box: centre +- |axis| . half extent (padded: the boxes are floats)
+                    const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+                    const double e[3] = {0.5 * (hi[0] - lo[0]) + 1e-5, 0.5 * (hi[1] - lo[1]) + 1e-5, 0.5 * (hi[2] - lo[2]) + 1e-5};
+                    const double ca = c[0] * a.F.A[0] + c[1] * a.F.A[1] + c[2] * a.F.A[2];
+                    const double ea = e[0] * fabs(a.F.A[0]) + e[1] * fabs(a.F.A[1]) + e[2] * fabs(a.F.A[2]);
+                    if (ca + ea < qa[0] || ca - ea > qa[1])
+                        continue;
+                    const double cb = c[0] * a.F.B[0] + c[1] * a.F.B[1] + c[2] * a.F.B[2];
+                    const double eb = e[0] * fabs(a.F.B[0]) + e[1] * fabs(a.F.B[1]) + e[2] * fabs(a.F.B[2]);
+                    if (cb + eb < qb[0] || cb - eb > qb[1])
+                        continue;
+                    const double chh = c[0] * a.F.L[0] + c[1] * a.F.L[1] + c[2] * a.F.L[2];
+                    const double eh = e[0] * fabs(a.F.L[0]) + e[1] * fabs(a.F.L[1]) + e[2] * fabs(a.F.L[2]);
+                    if (chh + eh < qh) // wholly below the lowest ray origin
+                        continue;
+                    if (ch[q] < 0) {
+                        test_leaf(ch[q]);
+                    } else if (node == kTravDone) {
+                        node = ch[q];
+                    } else if (sp < 64) {
+                        stack[sp++] = ch[q];
+                    } else { // cannot happen (neb_gi_build_bvh bounds the depth); if it did, no certificate
+                        alive[0] = alive[1] = false;
+                    }
+                }
+                if (node == kTravDone && sp > 0)
+                    node = stack[--sp];
+            }
+        }
+        flags = (alive[0] ? 1u : 0u) | (alive[1] ? 2u : 0u);
+        float4 w6 = r6;
+        w6.w = __uint_as_float(geom | (flags << kLitShift));
+        a.shade[8 * (size_t)ti + 6] = w6;
+        if (alive[primary])
+            hint[0] = hint[1] = kNoHint; // nothing to hint at: every ray of that side is answered by the lit bit
+        // r7 = {PrimitiveIndex, hint 0, hint 1, side the hints are for}
+        float4 w7 = rec[7];
+        w7.y = __uint_as_float(hint[0]);
+        w7.z = __uint_as_float(hint[1]);
+        w7.w = __uint_as_float((uint32_t)primary);
+        a.shade[8 * (size_t)ti + 7] = w7;
+        hinted = hint[0] != kNoHint;
+    }
+    const unsigned long long m0 = __ballot((flags & 1u) != 0u), m1 = __ballot((flags & 2u) != 0u), m2 = __ballot(hinted);
+    if ((threadIdx.x & 63u) == 0) {
+        if (m0)
+            atomicAdd(a.counts + 0, (unsigned long long)__popcll(m0));
+        if (m1)
+            atomicAdd(a.counts + 1, (unsigned long long)__popcll(m1));
+        if (m2)
+            atomicAdd(a.counts + 2, (unsigned long long)__popcll(m2));
+    }
+}
+
+__global__ void sun_table_clear_kernel(float4* shade, uint32_t n)
+{
+    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti < n) {
+        float4* p = shade + 8 * (size_t)ti + 6;
+        p->w = __uint_as_float(__float_as_uint(p->w) & kGeomMask);
+        p[1].y = p[1].z = __uint_as_float(kNoHint);
+    }
+}
+
+// Brings the table in the shading records up to date with (scene, sun) -- or clears it when the option is off.  Enqueue only.
+hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream)
+{
+    if (!g->built || g->n_tris == 0 || !g->view.shade)
+        return hipSuccess;
+    const float key[4] = {c.sunLightDirection[0], c.sunLightDirection[1], c.sunLightDirection[2], c.sunTanHalfAngle};
+    const bool want = g->sun_table;
+    if (!want) {
+        if (g->sun_table_state != 0) {
+            hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->n_tris);
+            g->sun_table_state = 0;
+        }
+        return hipGetLastError();
+    }
+    if (g->sun_table_state == 1 && !memcmp(key, g->sun_table_key, sizeof(key)))
+        return hipSuccess;
+    const float dd = key[0] * key[0] + key[1] * key[1] + key[2] * key[2];
+    if (!(dd > 0.0f) || !(dd < 1e30f) || !(key[3] >= 0.0f) || !(key[3] < 1.0f)) { // no usable sun: no certificate, every ray is traced
+        if (g->sun_table_state != 0)
+            hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->n_tris);
+        g->sun_table_state = 0;
+        return hipGetLastError();
+    }
+    if (!g->d_sun_counts) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, 4 * sizeof(unsigned long long));
+        if (e != hipSuccess)
+            return e;
+        g->allocs.push_back(p);
+        g->d_sun_counts = (unsigned long long*)p;
+    }
+    hipError_t e = hipMemsetAsync(g->d_sun_counts, 0, 4 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess)
+        return e;
+    SunTableArgs a;
+    a.S = g->view;
+    lit::make_frame(key, key[3], a.F);
+    double hmax = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        const double p[3] = {(k & 1) ? g->scene_max[0] : g->scene_min[0], (k & 2) ? g->scene_max[1] : g->scene_min[1],
+                             (k & 4) ? g->scene_max[2] : g->scene_min[2]};
+        hmax = fmax(hmax, p[0] * a.F.L[0] + p[1] * a.F.L[1] + p[2] * a.F.L[2]);
+    }
+    a.scene_hmax = hmax + 1e-3;
+    a.shade = const_cast<float4*>(g->view.shade);
+    a.counts = g->d_sun_counts;
+    hipLaunchKernelGGL(sun_table_kernel, dim3((g->n_tris + 63) / 64), dim3(64), 0, stream, a);
+    memcpy(g->sun_table_key, key, sizeof(key));
+    g->sun_table_state = 1;
+    g->sun_table_builds++;
+    return hipGetLastError();
+}
+
+} // namespace neb

@@ -1,0 +1,275 @@
+// lit_predicate.h -- the geometric certificate behind the sun-visibility table ("gi_sun_table", gi_build.hip / gi.hip).
+//
+// The shadow rays of the GI path all point at the sun disk (assets/shaders/pathtracer.hlsl:533-575: origin = hitP +- GN * 1e-2,
+// direction = normalize(L + (Bv sin + T cos) * sunTanHalfAngle * sqrt(u)), |offset| <= tan(half angle)).  For a triangle R of
+// the scene and a side sigma in {+1, -1} this header decides, CONSERVATIVELY, whether any such ray that starts on R (offset to
+// side sigma of its interpolated normal) can meet a triangle O of the scene.  If no triangle can -- R itself included -- every
+// shadow ray from (R, sigma) is unoccluded and the any-hit traversal can be skipped with the same answer.
+// "Cannot" must be certain; "may" costs only speed.  Everything is done in double precision in SUN COORDINATES
+// (a, b, h): h = p . L grows towards the sun, (a, b) span the plane perpendicular to it.  In these coordinates a ray from o
+// reaches q iff s = h_q - h_o > 0 and |q_ab - o_ab| <= s * tau: lateral drift is at most tau per unit climbed.
+//
+// Plain C++ (no HIP types) so that the CPU prototype / checker (tools/lit_proto.cpp) compiles the very same code.
+#pragma once
+#include <cmath>
+
+#ifdef __HIPCC__
+#define NEB_LIT_HD __host__ __device__ inline
+#else
+#define NEB_LIT_HD inline
+#endif
+
+namespace neb {
+namespace lit {
+
+constexpr double kOffset = 1e-2;      // the shadow ray leaves the surface by GN * 1e-2 (pathtracer.hlsl:560)
+constexpr double kMarginH = 2e-4;     // slack on heights: float rounding of hit points, directions and the traverser's triangle test
+constexpr double kMarginR = 2e-4;     // slack on lateral reach
+constexpr double kMinFacing = 0.05;   // |n . L| below this: the receiver is (nearly) edge-on to the sun, no certificate
+constexpr double kMinNormalDot = 0.25; // vertex normals further apart than this: the interpolated normal is not bounded well enough
+
+struct Frame {
+    double A[3], B[3], L[3]; // orthonormal, L towards the sun
+    double tau;              // tan(half angle of the sun disk), padded
+};
+
+NEB_LIT_HD void make_frame(const float sun_direction[3], float tan_half_angle, Frame& F)
+{
+    double l[3] = {-(double)sun_direction[0], -(double)sun_direction[1], -(double)sun_direction[2]};
+    const double n = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+    for (int k = 0; k < 3; ++k)
+        F.L[k] = l[k] / n;
+    // any unit vector not parallel to L
+    int m = 0;
+    if (std::fabs(F.L[1]) < std::fabs(F.L[m]))
+        m = 1;
+    if (std::fabs(F.L[2]) < std::fabs(F.L[m]))
+        m = 2;
+    double e[3] = {0, 0, 0};
+    e[m] = 1.0;
+    const double d = e[0] * F.L[0] + e[1] * F.L[1] + e[2] * F.L[2];
+    double a[3] = {e[0] - d * F.L[0], e[1] - d * F.L[1], e[2] - d * F.L[2]};
+    const double an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    for (int k = 0; k < 3; ++k)
+        F.A[k] = a[k] / an;
+    F.B[0] = F.L[1] * F.A[2] - F.L[2] * F.A[1];
+    F.B[1] = F.L[2] * F.A[0] - F.L[0] * F.A[2];
+    F.B[2] = F.L[0] * F.A[1] - F.L[1] * F.A[0];
+    F.tau = (double)tan_half_angle * (1.0 + 1e-3) + 1e-7;
+}
+
+struct Tri { // a triangle in sun coordinates
+    double a[3], b[3], h[3];
+};
+
+NEB_LIT_HD void to_sun(const Frame& F, const double p[3], double& a, double& b, double& h)
+{
+    a = p[0] * F.A[0] + p[1] * F.A[1] + p[2] * F.A[2];
+    b = p[0] * F.B[0] + p[1] * F.B[1] + p[2] * F.B[2];
+    h = p[0] * F.L[0] + p[1] * F.L[1] + p[2] * F.L[2];
+}
+
+// One side of a receiving triangle: where its shadow rays start.
+struct Receiver {
+    Tri t;
+    bool valid;              // false: no certificate possible (edge-on, degenerate, wild normals) -> never "lit"
+    double ga, gb, h0;       // the triangle's plane h = h0 + ga a + gb b
+    double grad1;            // |ga| + |gb|
+    double c_lo, c_hi;       // origins lie at plane(o_ab) + c_lo <= h_o <= plane(o_ab) + c_hi
+    double off_a[2], off_b[2]; // interval of the lateral origin offset
+    double en_a[3], en_b[3], en_c[3]; // outward unit edge normals of the projected triangle: n . (a, b) <= c inside
+    double en_off[3];        // support of the offset box along each edge normal
+    double h_min;            // lowest origin height
+    double bb_a[2], bb_b[2]; // lateral box of the origins
+};
+
+// v[i]: world-space vertices; gn[i]: world-space UNIT vertex normals as the shade kernel interpolates them
+// (normalize(xform_dir(M, n_i)); the interpolated GN is a normalised non-negative combination of them); sigma = +1 / -1.
+NEB_LIT_HD void make_receiver(const Frame& F, const double v[3][3], const double gn[3][3], int sigma, Receiver& R)
+{
+    R.valid = false;
+    for (int i = 0; i < 3; ++i)
+        to_sun(F, v[i], R.t.a[i], R.t.b[i], R.t.h[i]);
+    // plane over (a, b)
+    const double ua = R.t.a[1] - R.t.a[0], ub = R.t.b[1] - R.t.b[0], uh = R.t.h[1] - R.t.h[0];
+    const double wa = R.t.a[2] - R.t.a[0], wb = R.t.b[2] - R.t.b[0], wh = R.t.h[2] - R.t.h[0];
+    const double area2 = ua * wb - ub * wa; // twice the signed projected area
+    const double len_u = std::sqrt(ua * ua + ub * ub + uh * uh), len_w = std::sqrt(wa * wa + wb * wb + wh * wh);
+    if (!(len_u > 0.0) || !(len_w > 0.0))
+        return;
+    // face normal (unnormalised) = u x w; its h component is area2
+    const double nx = ub * wh - uh * wb, ny = uh * wa - ua * wh, nz = area2;
+    const double nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+    if (!(nn > 0.0) || std::fabs(nz) < kMinFacing * nn)
+        return;
+    R.ga = -nx / nz;
+    R.gb = -ny / nz;
+    R.h0 = R.t.h[0] - R.ga * R.t.a[0] - R.gb * R.t.b[0];
+    R.grad1 = std::fabs(R.ga) + std::fabs(R.gb);
+    // interval of the unit normal's sun components over the cone of the vertex normals
+    double dmin = 1.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j) {
+            const double d = gn[i][0] * gn[j][0] + gn[i][1] * gn[j][1] + gn[i][2] * gn[j][2];
+            dmin = d < dmin ? d : dmin;
+        }
+    if (!(dmin >= kMinNormalDot))
+        return;
+    const double grow = 1.0 / std::sqrt(dmin); // |sum c_i g_i| >= sqrt(dmin) sum c_i
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+    for (int i = 0; i < 3; ++i) {
+        double c[3];
+        to_sun(F, gn[i], c[0], c[1], c[2]);
+        const double len = std::sqrt(gn[i][0] * gn[i][0] + gn[i][1] * gn[i][1] + gn[i][2] * gn[i][2]);
+        if (!(len > 0.99 && len < 1.01))
+            return;
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = c[k] < lo[k] ? c[k] : lo[k];
+            hi[k] = c[k] > hi[k] ? c[k] : hi[k];
+        }
+    }
+    double off[3][2];
+    for (int k = 0; k < 3; ++k) {
+        double l = lo[k] < 0 ? lo[k] * grow : lo[k], h = hi[k] > 0 ? hi[k] * grow : hi[k];
+        l = l * kOffset * 1.001 - 1e-6;
+        h = h * kOffset * 1.001 + 1e-6;
+        if (sigma > 0) {
+            off[k][0] = l, off[k][1] = h;
+        } else {
+            off[k][0] = -h, off[k][1] = -l;
+        }
+    }
+    R.off_a[0] = off[0][0], R.off_a[1] = off[0][1];
+    R.off_b[0] = off[1][0], R.off_b[1] = off[1][1];
+    // h_o = plane(o_ab - off_ab) + off_h = plane(o_ab) + off_h - ga off_a - gb off_b
+    const double ga_hi = R.ga * off[0][0] > R.ga * off[0][1] ? R.ga * off[0][0] : R.ga * off[0][1];
+    const double gb_hi = R.gb * off[1][0] > R.gb * off[1][1] ? R.gb * off[1][0] : R.gb * off[1][1];
+    R.c_lo = off[2][0] - ga_hi - gb_hi;
+    const double ga_lo = R.ga * off[0][0] < R.ga * off[0][1] ? R.ga * off[0][0] : R.ga * off[0][1];
+    const double gb_lo = R.gb * off[1][0] < R.gb * off[1][1] ? R.gb * off[1][0] : R.gb * off[1][1];
+    R.c_hi = off[2][1] - ga_lo - gb_lo;
+    // outward edge normals of the projected triangle
+    const double sgn = area2 > 0 ? 1.0 : -1.0;
+    for (int e = 0; e < 3; ++e) {
+        const int i = e, j = (e + 1) % 3;
+        const double da = R.t.a[j] - R.t.a[i], db = R.t.b[j] - R.t.b[i];
+        const double len = std::sqrt(da * da + db * db);
+        if (!(len > 0.0))
+            return;
+        // for a counter-clockwise triangle the outward normal of edge i -> j is (db, -da)
+        R.en_a[e] = sgn * db / len;
+        R.en_b[e] = -sgn * da / len;
+        R.en_c[e] = R.en_a[e] * R.t.a[i] + R.en_b[e] * R.t.b[i];
+        const double sa = R.en_a[e] * R.off_a[0] > R.en_a[e] * R.off_a[1] ? R.en_a[e] * R.off_a[0] : R.en_a[e] * R.off_a[1];
+        const double sb = R.en_b[e] * R.off_b[0] > R.en_b[e] * R.off_b[1] ? R.en_b[e] * R.off_b[0] : R.en_b[e] * R.off_b[1];
+        R.en_off[e] = sa + sb;
+    }
+    double hmin = R.t.h[0], amin = R.t.a[0], amax = R.t.a[0], bmin = R.t.b[0], bmax = R.t.b[0];
+    for (int i = 1; i < 3; ++i) {
+        hmin = R.t.h[i] < hmin ? R.t.h[i] : hmin;
+        amin = R.t.a[i] < amin ? R.t.a[i] : amin;
+        amax = R.t.a[i] > amax ? R.t.a[i] : amax;
+        bmin = R.t.b[i] < bmin ? R.t.b[i] : bmin;
+        bmax = R.t.b[i] > bmax ? R.t.b[i] : bmax;
+    }
+    R.h_min = hmin + off[2][0];
+    R.bb_a[0] = amin + R.off_a[0], R.bb_a[1] = amax + R.off_a[1];
+    R.bb_b[0] = bmin + R.off_b[0], R.bb_b[1] = bmax + R.off_b[1];
+    R.valid = true;
+}
+
+// Can a shadow ray from receiver R meet triangle O?  false = certainly not.
+NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
+{
+    double hmax = O.h[0] > O.h[1] ? O.h[0] : O.h[1];
+    hmax = O.h[2] > hmax ? O.h[2] : hmax;
+    const double smax = hmax - R.h_min + kMarginH; // the most a ray can have climbed when it meets O
+    if (smax <= 0.0)
+        return false;
+    const double rho = smax * F.tau + kMarginR;    // ... and drifted sideways
+    // clip O (as a 3-D polygon) by the three vertical planes through R's edges, pushed out by the drift and the offset box
+    double pa[8], pb[8], ph[8], qa[8], qb[8], qh[8];
+    int n = 3;
+    for (int i = 0; i < 3; ++i)
+        pa[i] = O.a[i], pb[i] = O.b[i], ph[i] = O.h[i];
+    for (int e = 0; e < 3 && n > 0; ++e) {
+        const double na = R.en_a[e], nb = R.en_b[e];
+        const double c = R.en_c[e] + R.en_off[e] + rho * (std::fabs(na) + std::fabs(nb));
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            const double di = na * pa[i] + nb * pb[i] - c, dj = na * pa[j] + nb * pb[j] - c;
+            if (di <= 0.0) {
+                qa[m] = pa[i], qb[m] = pb[i], qh[m] = ph[i];
+                ++m;
+            }
+            if ((di <= 0.0) != (dj <= 0.0)) {
+                const double t = di / (di - dj);
+                qa[m] = pa[i] + t * (pa[j] - pa[i]);
+                qb[m] = pb[i] + t * (pb[j] - pb[i]);
+                qh[m] = ph[i] + t * (ph[j] - ph[i]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i)
+            pa[i] = qa[i], pb[i] = qb[i], ph[i] = qh[i];
+    }
+    if (n == 0)
+        return false;
+    // s = h_q - h_o <= [h_q - plane_R(q_ab)] + grad1 * rho - c_lo; linear over the clipped polygon: the maximum is at a vertex
+    const double bound = R.c_lo - R.grad1 * rho - kMarginH;
+    for (int i = 0; i < n; ++i) {
+        const double f = ph[i] - (R.h0 + R.ga * pa[i] + R.gb * pb[i]);
+        // (an intersection point is computed with rounding of ~1e-16 relative: covered by kMarginH)
+        if (!(f <= bound))
+            return true;
+    }
+    return false;
+}
+
+// How much of R's projected triangle lies in the shadow of O: the area of O's projection inside R's, counted only where that part
+// of O is above every ray origin of R.  Only RANKS occluder hints (gi_sun_table.hip): a hint is tried with the traverser's own
+// triangle test, so a poor estimate costs speed, never correctness.
+NEB_LIT_HD double shadow_cover(const Receiver& R, const Tri& O)
+{
+    double pa[8], pb[8], ph[8], qa[8], qb[8], qh[8];
+    int n = 3;
+    for (int i = 0; i < 3; ++i)
+        pa[i] = O.a[i], pb[i] = O.b[i], ph[i] = O.h[i];
+    for (int e = 0; e < 3 && n > 0; ++e) {
+        const double na = R.en_a[e], nb = R.en_b[e], c = R.en_c[e];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            const double di = na * pa[i] + nb * pb[i] - c, dj = na * pa[j] + nb * pb[j] - c;
+            if (di <= 0.0) {
+                qa[m] = pa[i], qb[m] = pb[i], qh[m] = ph[i];
+                ++m;
+            }
+            if ((di <= 0.0) != (dj <= 0.0)) {
+                const double t = di / (di - dj);
+                qa[m] = pa[i] + t * (pa[j] - pa[i]);
+                qb[m] = pb[i] + t * (pb[j] - pb[i]);
+                qh[m] = ph[i] + t * (ph[j] - ph[i]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i)
+            pa[i] = qa[i], pb[i] = qb[i], ph[i] = qh[i];
+    }
+    if (n < 3)
+        return 0.0;
+    double area2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        if (!(ph[i] - (R.h0 + R.ga * pa[i] + R.gb * pb[i]) > R.c_hi + 1e-3))
+            return 0.0; // this part of O is not (wholly) above the ray origins
+        area2 += pa[i] * pb[j] - pa[j] * pb[i];
+    }
+    return 0.5 * (area2 < 0 ? -area2 : area2);
+}
+
+} // namespace lit
+} // namespace neb

@@ -198,6 +198,12 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_traversal_stats(self._ctx, v), "neb_gi_traversal_stats")
         return dict(zip(("rays", "bounce_nodes", "bounce_tris", "shadow_nodes", "shadow_tris"), [int(x) for x in v]))
 
+    def sun_table_stats(self):
+        """{sides proven lit (+normal side / -normal side), shadow rays the table answered as of the last ray_count(), builds}"""
+        v = (C.c_uint64 * 4)()
+        self._check(self._lib.neb_gi_sun_table_stats(self._ctx, v, C.c_void_p(self.info.stream if self.info else 0)), "neb_gi_sun_table_stats")
+        return dict(zip(("lit_plus", "lit_minus", "rays_answered", "builds"), [int(x) for x in v]))
+
     def set_debug_hits(self, on=True):
         self.svgf.set_option("gi_debug_hits", int(on))
 

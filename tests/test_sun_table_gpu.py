@@ -1,0 +1,152 @@
+"""The sun-visibility table (nebulae_amd/csrc/gi_sun_table.hip, lit_predicate.h): shadow rays that start on a (triangle, side)
+PROVEN lit by the whole sun disk are answered without a traversal.  Its bar is not a tolerance: with the table on and off the
+frame must be the same bits -- radiance, per-pixel sun-visibility flags, ray counts -- on every GI scene, with several samples
+and bounces, at the bench size, and after the sun has moved (the table is rebuilt for the new sun)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nebulae_amd import scene as S
+from nebulae_amd.renderer import DeferredRenderer, RenderInfo
+from nebulae_amd.svgf import PLANE_RADIANCE, SLOT_CURRENT
+from test_gi_gpu import scenes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _frame(r, sc, cam, W, H, f, spp=1, vertices=2):
+    r.gi_ui.gi_samples_per_pixel = spp
+    r.gi_ui.max_path_vertices = vertices
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f))
+    r.submit_commands_gbuffer()
+    base = np.full((H, W, 4), 0.125, np.float32)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, base)
+    r.set_debug_hits(True)
+    r.ray_count(reset=True)
+    r.submit_commands_gi_pathtrace()
+    rad, hits, rays = r.svgf.download(PLANE_RADIANCE), r.download_hits(), r.ray_count()
+    return rad, hits, rays
+
+
+def _pair(W, H):
+    on, off = DeferredRenderer(), DeferredRenderer()
+    on.init(W, H)
+    off.init(W, H)
+    return on, off
+
+
+def test_three_way_table_lists_sorted_tail_and_no_table():
+    """"gi_sun_table" = 1 (table + compacted ray lists, the default), 2 (table, the remaining rays through the sorted pass) and
+    0 (every ray traced): one frame sequence with 2 spp and 3 path vertices, the same bits from all three."""
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    rs = [DeferredRenderer() for _ in range(3)]
+    for r, mode in zip(rs, (1, 2, 0)):
+        r.init(W, H)
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+        r.svgf.set_option("gi_sun_table", mode)
+        if mode == 2:
+            r.svgf.set_option("gi_sort_rays", 1)
+    for f in (2, 3):
+        out = [_frame(r, sc, cam, W, H, f, 2, 3) for r in rs]
+        _same(out[0], out[1])
+        _same(out[0], out[2])
+    for r in rs:
+        r.destroy()
+
+
+def _same(a, b):
+    (ra, ha, na), (rb, hb, nb) = a, b
+    assert np.array_equal(ra, rb), float(np.abs(ra - rb).max())
+    for k in ("t", "geometry", "primitive"):
+        assert np.array_equal(ha[k], hb[k]), k
+    assert np.array_equal(ha["flags"] & 1, hb["flags"] & 1)  # sun visible: the table's answer == the traversal's
+    assert na == nb                                         # a ray = a visibility query, however it is answered
+
+
+@pytest.mark.parametrize("name,spp,vertices", [("atrium_small", 1, 2), ("atrium_small", 3, 2), ("atrium_small", 2, 4), ("atrium_mixed_tex", 1, 2),
+                                               ("cornell", 2, 3), ("cornell_factors", 1, 2)])
+def test_table_on_and_off_give_the_same_bits(name, spp, vertices):
+    make, cam, W, H = scenes()[name]
+    sc = make()
+    on, off = _pair(W, H)
+    for f in (3, 4):
+        a = _frame(on, sc, cam, W, H, f, spp, vertices)
+        if f == 3:
+            off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f))
+            off.svgf.set_option("gi_sun_table", 0)
+        b = _frame(off, sc, cam, W, H, f, spp, vertices)
+        _same(a, b)
+    st, st_off = on.sun_table_stats(), off.sun_table_stats()
+    assert st["builds"] == 1 and st_off["builds"] == 0 and st_off["rays_answered"] == 0
+    if name.startswith("atrium"):  # an open court under the sun: a good share of the queries is answered by the table
+        vis = (a[1]["flags"] & 1).astype(bool) & (a[1]["t"] > 0)
+        assert st["lit_plus"] > 0.03 * sc.num_triangles and st["rays_answered"] >= 0.5 * vis.sum() * (1 if spp * (vertices - 1) == 1 else 0), (st, int(vis.sum()))
+        print(f"[{name} spp={spp} vertices={vertices}] sides proven lit {st['lit_plus']} + {st['lit_minus']} of {sc.num_triangles} triangles; "
+              f"{st['rays_answered']} of {a[2]} rays answered by the table; unoccluded (last sample / vertex 1) {int(vis.sum())}")
+    on.destroy()
+    off.destroy()
+
+
+@pytest.mark.parametrize("file,tex", [("cornell_box.glb", 1), ("DamagedHelmet_256.glb", 2)])
+def test_table_on_real_scenes(file, tex):
+    """the reference's own assets: the Cornell box's node rotation, the helmet's curved surface with interpolated normals"""
+    sc = S.load_gltf(os.path.join(GOLDEN, file), tex_upscale=tex)
+    cam = S.orbit_camera(origin=(0.0, 1.0, 0.0), distance=3.5) if "cornell" in file else S.orbit_camera(yaw_deg=20.0, pitch_deg=70.0, distance=2.6)
+    W, H = 320, 200
+    on, off = _pair(W, H)
+    off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    off.svgf.set_option("gi_sun_table", 0)
+    for f in (2, 5):
+        _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+    print(f"[{file}] {on.sun_table_stats()}")
+    on.destroy()
+    off.destroy()
+
+
+def test_the_table_follows_the_sun():
+    """sunLightDirection / the disk's diameter are per-frame constants (src/DeferredRenderer.cpp:403-421): a frame with another sun
+    gets another table -- the same bits as a fresh context that never had one."""
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    on, off = _pair(W, H)
+    off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    off.svgf.set_option("gi_sun_table", 0)
+    suns = [((0.5, -1.0, -0.2), 0.58), ((-0.3, -1.0, 0.4), 0.58), ((-0.3, -1.0, 0.4), 3.0), ((0.0, -1.0, 0.0), 0.0), ((0.5, -1.0, -0.2), 0.58)]
+    for f, (direction, diameter) in enumerate(suns, start=2):
+        for r in (on, off):
+            r.sun.direction, r.sun.rough_diameter = direction, diameter
+        _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+    assert on.sun_table_stats()["builds"] == len(suns)
+    # switching the option off clears the flags; on again rebuilds them
+    on.svgf.set_option("gi_sun_table", 0)
+    _same(_frame(on, sc, cam, W, H, 9), _frame(off, sc, cam, W, H, 9))
+    assert on.sun_table_stats()["rays_answered"] == 0
+    on.svgf.set_option("gi_sun_table", 1)
+    _same(_frame(on, sc, cam, W, H, 10), _frame(off, sc, cam, W, H, 10))
+    assert on.sun_table_stats()["rays_answered"] > 0 and on.sun_table_stats()["builds"] == len(suns) + 1
+    on.destroy()
+    off.destroy()
+
+
+def test_table_at_the_bench_size():
+    """BASELINE.json configs[2]: sponza-standin 1920x1080 -- 2 M visibility queries per frame, three frames (three RNG streams)."""
+    W, H = 1920, 1080
+    sc, cam = S.atrium_standin(), S.sponza_camera()
+    on, off = _pair(W, H)
+    off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    off.svgf.set_option("gi_sun_table", 0)
+    for f in (2, 3, 4):
+        a, b = _frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f)
+        _same(a, b)
+    st = on.sun_table_stats()
+    vis = (a[1]["flags"] & 1).astype(bool) & (a[1]["t"] > 0)
+    print(f"[bench size] sides proven lit {st['lit_plus']} + {st['lit_minus']} of {sc.num_triangles} triangles; {st['rays_answered']} of {a[2]} rays "
+          f"answered by the table = {st['rays_answered'] / max(int(vis.sum()), 1):.3f} of the {int(vis.sum())} unoccluded shadow rays")
+    assert st["rays_answered"] >= 0.8 * vis.sum()
+    torch.cuda.synchronize()
+    on.destroy()
+    off.destroy()
