@@ -84,7 +84,7 @@ struct GiArgs {
     // Shadow rays that still need a walk once the sun table has answered the rest (~14 % on the bench frame), compacted by the
     // shade pass: kListSegments lists, workgroup b appends to list b % kListSegments with ONE atomic per wave (spread over the
     // segments: a single hot word takes only ~90 atomics/us), each list sized for every pixel of its workgroups, so none can overflow.
-    uint32_t* list;              // [kListSegments][list_cap] pixel indices, or null: the uncompacted paths
+    float4* list;                // [kListSegments][list_cap] self-contained 64-byte ray records {origin, pixel}{direction, 1}{contribution, -}{sum, -}, or null: the uncompacted paths
     uint32_t* list_counts;       // [2][kListSegments]: the set this launch fills (list_set) and the one gi_shadow_trace_kernel clears for the next
     uint32_t list_cap, list_set;
     float smin[3], sinv[3];      // scene box for the Morton keys
@@ -109,6 +109,9 @@ __device__ __forceinline__ uint32_t gi_block()
 }
 constexpr uint32_t kShadeRuns = 16u, kRaygenRuns = 16u;
 constexpr uint32_t kListSegments = 128u;
+#ifndef NEB_LIST_WAVES
+#define NEB_LIST_WAVES 6 // waves per SIMD it is register-budgeted for (it is bound by latency, not by occupancy)
+#endif
 
 template <uint32_t RUNS = 0u>
 __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t& y, size_t& i)
@@ -298,16 +301,23 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
             o.rays = 1;
             const uint32_t side = transition ? 1u : 0u;
             bool hinted_hit = false;
-            if (a.sun_table && !((ts.lit >> side) & 1u) && ts.hint_side == side && ts.hint0 != kNoHint) {
-                // Occluder hints: the (up to) two triangles whose shadow covers most of this triangle (chosen once per sun position).
-                // They are tried with the traverser's own test on the very ray the shadow pass would walk -- same operands, same
-                // arithmetic -- so a hit is a hit of the any-hit traversal too: "occluded", exactly, without the walk.
-                const uint32_t h0 = ts.hint0, h1 = ts.hint1 != kNoHint ? ts.hint1 : ts.hint0;
-                const float4 a0 = a.S.tris[3 * h0], b0 = a.S.tris[3 * h0 + 1], c0 = a.S.tris[3 * h0 + 2];
-                const float4 a1 = a.S.tris[3 * h1], b1 = a.S.tris[3 * h1 + 1], c1 = a.S.tris[3 * h1 + 2];
+            if (a.sun_table && !((ts.lit >> side) & 1u) && ts.hint_side == side && ts.hint[0] != kNoHint) {
+                // Occluder hints: the (up to) four triangles that together shadow most of this triangle (chosen once per sun
+                // position).  They are tried with the traverser's own test on the very ray the shadow pass would walk -- same
+                // operands, same arithmetic -- so a hit is a hit of the any-hit traversal too: "occluded", exactly, without the
+                // walk.  Two at a time: the second pair is only fetched by the lanes the first pair did not stop.
                 float tt, uu, vv;
-                hinted_hit = intersect_tri_regs(a0, b0, c0, so, inc, 0.001f, kTraceMax, tt, uu, vv) ||
-                             intersect_tri_regs(a1, b1, c1, so, inc, 0.001f, kTraceMax, tt, uu, vv);
+#pragma unroll
+                for (int pair = 0; pair < kHints && !hinted_hit; pair += 2) {
+                    const uint32_t h0 = ts.hint[pair];
+                    if (h0 == kNoHint)
+                        break;
+                    const uint32_t h1 = ts.hint[pair + 1] != kNoHint ? ts.hint[pair + 1] : h0;
+                    const float4 a0 = a.S.tris[3 * h0], b0 = a.S.tris[3 * h0 + 1], c0 = a.S.tris[3 * h0 + 2];
+                    const float4 a1 = a.S.tris[3 * h1], b1 = a.S.tris[3 * h1 + 1], c1 = a.S.tris[3 * h1 + 2];
+                    hinted_hit = intersect_tri_regs(a0, b0, c0, so, inc, 0.001f, kTraceMax, tt, uu, vv) ||
+                                 intersect_tri_regs(a1, b1, c1, so, inc, 0.001f, kTraceMax, tt, uu, vv);
+                }
             }
             if (hinted_hit) {
                 o.table = 1; // occluded: nothing is added, no ray
@@ -366,7 +376,7 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
     }
     if (a.hits && a.bounce == 1) {
         if (a.stats)
-            dbg.flags |= trav_iters << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py)
+            dbg.flags |= min(trav_iters, 4095u) << 8; // diagnostics: traversal iterations of the bounce ray (tools/gi_divergence.py); bits 20..31: shadow-ray node visits
         a.hits[i] = dbg;
     }
 }
@@ -431,11 +441,10 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
             if (lane == 0)
                 base = atomicAdd(a.list_counts + a.list_set * kListSegments + seg, (uint32_t)__popcll(m));
             base = (uint32_t)__shfl((int)base, 0);
-            if (trace) {
+            if (trace) { // the ray goes into its list slot whole (tmin is the constant 1e-3: its word carries the pixel)
                 const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                a.list[(size_t)seg * a.list_cap + slot] = (uint32_t)i;
-                float4* rec = a.R.srec + 4 * i;
-                rec[kSrO] = o.rec_o;
+                float4* rec = a.list + 4 * ((size_t)seg * a.list_cap + slot);
+                rec[kSrO] = make_float4(o.rec_o.x, o.rec_o.y, o.rec_o.z, __uint_as_float((uint32_t)i));
                 rec[kSrD] = o.shadow_d;
                 rec[kSrContrib] = o.rec_c;
                 rec[kSrSum] = o.sum;
@@ -470,33 +479,9 @@ __global__ __launch_bounds__(64, NEB_SHADE_WAVES) void gi_shade_kernel(GiArgs a)
 // (A persistent-wave variant with per-lane ray refill was measured and dropped: lanes of a wave finish after
 // 23 steps on average and the slowest after ~55, so the refill bookkeeping cost more than the idle lanes it
 // recovered: 1.24 ms vs 0.52 ms for the bounce rays at 1080p.)
-__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(GiArgs a)
+// The shadow pass of one wave: lane l traces the shadow ray of pixel i (valid lanes) and finishes the pixel.
+__device__ __forceinline__ void shadow_wave(const GiArgs& a, size_t i, bool valid, int* stack_mem)
 {
-    __shared__ int stack_mem[kLdsStack * 64];
-    static_assert(kLdsStack * 64 * sizeof(int) >= 64 * 4 * sizeof(float4), "the shadow records are staged in the stack's LDS");
-    uint32_t x, y;
-    size_t i = 0;
-    bool valid;
-    if (a.list) { // the compacted rays of the shade pass: list_cap / 64 waves per list, those behind a list's end leave at once
-        const uint32_t waves_per_list = a.list_cap / 64u;
-        const uint32_t seg = blockIdx.x / waves_per_list, first = (blockIdx.x - seg * waves_per_list) * 64u;
-        const uint32_t count = a.list_counts[a.list_set * kListSegments + seg];
-        if (blockIdx.x == 0) // the other set of counters is idle until the next shade launch fills it: clear it for that launch
-            for (uint32_t k = threadIdx.x; k < kListSegments; k += 64u)
-                a.list_counts[(a.list_set ^ 1u) * kListSegments + k] = 0u;
-        if (first >= count)
-            return;
-        valid = first + threadIdx.x < count;
-        if (valid)
-            i = a.list[(size_t)seg * a.list_cap + first + threadIdx.x];
-    } else if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
-        const uint32_t j = blockIdx.x * 64u + threadIdx.x;
-        valid = j < a.n_px;
-        if (valid)
-            i = a.sort_order[j];
-    } else {
-        valid = gi_pixel(a, x, y, i);
-    }
     // The wave's 64 shadow records (64 bytes each, scattered: the pixels come in sorted order) are gathered cooperatively --
     // four lanes fetch the four 16-byte pieces of one record, sixteen records per instruction, by LDS-DMA into the memory
     // that serves as the traversal stack afterwards -- so the texture-address units see a quarter of the line lookups
@@ -524,6 +509,8 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
         Hit sh;
         const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), ro.w, kTraceMax, true, stack_mem + threadIdx.x, sh, a.stats != 0);
         if (a.stats) { // diagnostics only
+            if (a.hits && a.bounce == 1)
+                a.hits[i].flags |= min(sh.node_visits, 4095u) << 20; // node visits of the shadow ray (tools/shadow_tail_stats.py)
             atomicAdd(a.ray_counter + 3, (unsigned long long)sh.node_visits);
             atomicAdd(a.ray_counter + 4, (unsigned long long)sh.tri_tests);
         }
@@ -549,6 +536,83 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
         }
     } else {
         a.R.srec[4 * i + kSrSum] = sum;
+    }
+}
+
+// Every dispatched pixel once: in sorted order (a.sort_order) or in 8x8 tiles.
+__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    static_assert(kLdsStack * 64 * sizeof(int) >= 64 * 4 * sizeof(float4), "the shadow records are staged in the stack's LDS");
+    uint32_t x, y;
+    size_t i = 0;
+    bool valid;
+    if (a.sort_order) { // one lane per entry of the sorted order (every dispatched pixel appears exactly once)
+        const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+        valid = j < a.n_px;
+        if (valid)
+            i = a.sort_order[j];
+    } else {
+        valid = gi_pixel(a, x, y, i);
+    }
+    shadow_wave(a, i, valid, stack_mem);
+}
+
+// The compacted rays of the shade pass (a.list).  The lists are sized for every pixel (32 k waves' worth at 1080p) but hold ~8 % of
+// them, and what is left is bound by LATENCY: 160 k rays of <= 37 node visits each take 50 us because a lone wave needs ~0.8 us per
+// dependent step (profiles/r04*_tail*.txt: a launch of one wave per slot 82 us -- most of it dispatching waves that read a counter and
+// leave; with the tree warm in cache 52 instead of 56; two nodes per step 68).  So: a fixed grid, workgroup b takes chunks
+// b / kListSegments, + kListChunks, ... of list b % kListSegments -- one counter read, no scan -- and a ray comes out of its list slot
+// whole (64 bytes, consecutive slots: no gather through a pixel index).
+constexpr uint32_t kListChunks = 64u; // chunks of 64 rays per list taken in parallel: kListSegments x kListChunks = 8192 waves = the chip's wave slots
+__global__ __launch_bounds__(64, NEB_LIST_WAVES) void gi_shadow_list_kernel(GiArgs a)
+{
+    __shared__ int stack_mem[kLdsStack * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x % kListSegments, chunks = gridDim.x / kListSegments;
+    const uint32_t count = a.list_counts[a.list_set * kListSegments + seg];
+    if (blockIdx.x == 0) // the other set of counters is idle until the next shade launch fills it: clear it for that launch
+        for (uint32_t k = lane; k < kListSegments; k += 64u)
+            a.list_counts[(a.list_set ^ 1u) * kListSegments + k] = 0u;
+#ifdef NEB_TAIL_SKIP // timing-only build (wrong results): trace every NEB_TAIL_SKIP-th list -- is the tail bound by its rays or by its longest wave?
+    if (seg % NEB_TAIL_SKIP)
+        return;
+#endif
+    for (uint32_t first = (blockIdx.x / kListSegments) * 64u; first < count; first += chunks * 64u) {
+        if (first + lane >= count)
+            continue; // (the workgroup is this one wave: no barrier below)
+        const float4* rec = a.list + 4 * ((size_t)seg * a.list_cap + first + lane);
+        const float4 ro = rec[kSrO], rd = rec[kSrD], contrib = rec[kSrContrib];
+        float4 sum = rec[kSrSum];
+        const size_t i = __float_as_uint(ro.w);
+        Hit sh;
+        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, a.stats != 0);
+        if (a.stats) { // diagnostics only
+            if (a.hits && a.bounce == 1)
+                a.hits[i].flags |= min(sh.node_visits, 4095u) << 20;
+            atomicAdd(a.ray_counter + 3, (unsigned long long)sh.node_visits);
+            atomicAdd(a.ray_counter + 4, (unsigned long long)sh.tri_tests);
+        }
+        if (!occluded) { // radiance += BRDF * sunRadiance * throughput (:571-575)
+            sum.x += contrib.x;
+            sum.y += contrib.y;
+            sum.z += contrib.z;
+            if (a.hits && a.bounce == 1)
+                a.hits[i].flags |= 1u;
+        }
+        const bool last_vertex = a.bounce + 1 >= a.c.maxPathVertices;
+        if (a.sample + 1 == a.c.samplesPerPixel && last_vertex && !a.defer_resolve) { // stands in for NRC Resolve (as shadow_wave)
+            if (sum.x != 0.0f || sum.y != 0.0f || sum.z != 0.0f) {
+                const float inv_spp = 1.0f / (float)a.c.samplesPerPixel;
+                float4 r = a.radiance[i];
+                r.x += sum.x * inv_spp;
+                r.y += sum.y * inv_spp;
+                r.z += sum.z * inv_spp;
+                a.radiance[i] = r;
+            }
+        } else {
+            a.R.srec[4 * i + kSrSum] = sum;
+        }
     }
 }
 
@@ -868,22 +932,24 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     // the sun-visibility table: brought up to date with this frame's sun (a rebuild only when the sun or the scene changed)
     GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
     a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
-    a.list = a.list_counts = nullptr;
+    a.list = nullptr;
+    a.list_counts = nullptr;
     a.list_cap = a.list_set = 0;
     uint32_t list_waves = 0;
     if (compact) {
         const uint32_t wg_per_list = (uint32_t)((g->n_block_counts + kListSegments - 1) / kListSegments);
         if (!g->d_list) {
             void* p = nullptr;
-            GI_HIP(ctx, hipMalloc(&p, ((size_t)kListSegments * wg_per_list * 64u + 2u * kListSegments) * sizeof(uint32_t)));
-            GI_HIP(ctx, hipMemset(p, 0, 2u * kListSegments * sizeof(uint32_t))); // (the two counter sets sit in front of the lists)
+            // (64 bytes per slot, a slot per pixel: what the per-pixel shadow-record plane takes; the two counter sets sit in front)
+            GI_HIP(ctx, hipMalloc(&p, (size_t)kListSegments * wg_per_list * 64u * 64u + 4096u));
+            GI_HIP(ctx, hipMemset(p, 0, 4096u));
             g->allocs.push_back(p);
             g->d_list = (uint32_t*)p;
         }
         a.list_counts = g->d_list;
-        a.list = g->d_list + 2u * kListSegments;
+        a.list = (float4*)((char*)g->d_list + 4096);
         a.list_cap = wg_per_list * 64u;
-        list_waves = kListSegments * wg_per_list;
+        list_waves = kListSegments * (wg_per_list < kListChunks ? wg_per_list : kListChunks);
     }
     const uint32_t n_vertices = c->maxPathVertices > 1 ? c->maxPathVertices - 1 : 1; // path vertices traced per sample
     for (uint32_t s = 0; s < c->samplesPerPixel; ++s) {
@@ -909,7 +975,10 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             else
                 hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
             if (a.list) {
-                hipLaunchKernelGGL(gi_shadow_trace_kernel, dim3(list_waves), block, 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL(gi_shadow_list_kernel, dim3(list_waves), block, 0, (hipStream_t)stream, a);
+#ifdef NEB_TAIL_TWICE // timing-only build (wrong results): the same launch again, now with the tree in cache
+                hipLaunchKernelGGL(gi_shadow_list_kernel, dim3(list_waves), block, 0, (hipStream_t)stream, a);
+#endif
                 g->list_epoch++;
             } else if (sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the

@@ -3,7 +3,9 @@
 // Reference: src/nri/GIProcessedScene.cpp:16-137 (scene tables); RTAccelerationStructureBuilder.cpp:14-130 (driver
 // BVH, built on the GPU once -> replaced by an own device build: Morton sort, binned-SAH splits, collapse to a 4-wide
 // tree, all in HIP kernels).
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp> // (the one-time build: 64-bit key sort and prefix sums from ROCm's own primitives, not the CUB-compatible layer)
 
 #include <algorithm>
 #include <cstdlib>
@@ -72,7 +74,11 @@ __global__ void pack_shade_records_kernel(SceneView S, uint32_t n, float4* out)
         r[6] = make_float4(S.uvs[2 * i1 + 1], S.uvs[2 * i2], S.uvs[2 * i2 + 1], 0.f);
     }
     r[6].w = __uint_as_float(geom);
-    r[7] = make_float4(__uint_as_float(prim), __uint_as_float(kNoHint), __uint_as_float(kNoHint), 0.f); // (hints: gi_sun_table.hip)
+    r[7].x = __uint_as_float(prim);
+    {
+        const uint32_t none[kHints] = {kNoHint, kNoHint, kNoHint, kNoHint}; // (hints: gi_sun_table.hip)
+        pack_hints(none, 0u, r[7]);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         out[8 * (size_t)ti + k] = r[k];
@@ -1062,9 +1068,9 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
 #endif
     float4* d_plan = NEB_COLLAPSE_DP ? (float4*)dalloc(n2 * 16, false) : nullptr;
     size_t cub_bytes = 0, cub_b2 = 0, cub_b3 = 0;
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, cub_bytes, d_keys, d_keys2, (int)n, 0, 64, stream);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b2, d_flags, d_scan, (int)n, stream);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b3, d_icount, d_iscan, (int)n, stream);
+    (void)rocprim::radix_sort_keys(nullptr, cub_bytes, d_keys, d_keys2, (size_t)n, 0u, 64u, stream);
+    (void)rocprim::exclusive_scan(nullptr, cub_b2, d_flags, d_scan, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), stream);
+    (void)rocprim::exclusive_scan(nullptr, cub_b3, d_icount, d_iscan, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream);
     cub_bytes = std::max(cub_bytes, std::max(cub_b2, cub_b3));
     void* d_cub = dalloc(cub_bytes, false);
     if (oom) {
@@ -1101,7 +1107,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
 #endif
     hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, n, smin, sinv, axis_bits, index_bits, d_keys);
     BUILD_HIP(hipGetLastError());
-    BUILD_HIP(hipcub::DeviceRadixSort::SortKeys(d_cub, cub_bytes, d_keys, d_keys2, (int)n, 0, 64, stream));
+    BUILD_HIP(rocprim::radix_sort_keys(d_cub, cub_bytes, d_keys, d_keys2, (size_t)n, 0u, 64u, stream));
     hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, d_keys2, n, (1ull << index_bits) - 1ull, d_sorted);
     BUILD_HIP(hipGetLastError());
     // ---- binary topology: binned SAH, one level per pass ----
@@ -1140,7 +1146,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             const dim3 grid((n_segs + 255) / 256);
             hipLaunchKernelGGL(sah_count_kernel, grid, dim3(256), 0, stream, segs, (const SahSplit*)d_splits, n_segs, d_flags);
             BUILD_HIP(hipGetLastError());
-            BUILD_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_flags, d_scan, (int)n_segs, stream));
+            BUILD_HIP(rocprim::exclusive_scan(d_cub, cub_bytes, d_flags, d_scan, 0ull, (size_t)n_segs, rocprim::plus<unsigned long long>(), stream));
             hipLaunchKernelGGL(sah_emit_kernel, grid, dim3(256), 0, stream, N, segs, (const SahSplit*)d_splits, n_segs, (const unsigned long long*)d_flags,
                                (const unsigned long long*)d_scan, (const uint32_t*)idx_out, rs, ws, d_segs[(passes + 1u) & 1u]);
             BUILD_HIP(hipGetLastError());
@@ -1198,7 +1204,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             const dim3 grid((level_count + 127) / 128);
             hipLaunchKernelGGL(collapse_open_kernel, grid, dim3(128), 0, stream, a);
             BUILD_HIP(hipGetLastError());
-            BUILD_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_icount, d_iscan, (int)level_count, stream));
+            BUILD_HIP(rocprim::exclusive_scan(d_cub, cub_bytes, d_icount, d_iscan, 0u, (size_t)level_count, rocprim::plus<uint32_t>(), stream));
             hipLaunchKernelGGL(collapse_emit_kernel, grid, dim3(128), 0, stream, a);
             BUILD_HIP(hipGetLastError());
             uint32_t next = 0;

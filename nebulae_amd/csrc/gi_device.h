@@ -567,7 +567,7 @@ struct TriShade {
     float4 t0, t1, t2;
     uint32_t geom; // GeometryIndex() of the triangle (r6.w, low 30 bits); PrimitiveIndex() is r7.x (debug records only)
     uint32_t lit;  // sun-visibility table (r6.w, top 2 bits): bit 0 = shadow rays from the +GN side are all unoccluded, bit 1 = -GN side
-    uint32_t hint0, hint1, hint_side; // occluder hints (r7.yzw): triangles likely to shadow rays that start on side hint_side (0: +GN, 1: -GN)
+    uint32_t hint[kHints], hint_side; // occluder hints (r7.yzw): triangles likely to shadow rays that start on side hint_side (0: +GN, 1: -GN)
 };
 // `r` = the triangle's 8 x float4 record; piece k sits at r[k ^ swz] (swz = 0 in global memory; the copy the shade pass
 // stages in LDS is XOR-swizzled per lane to spread the banks)
@@ -587,9 +587,7 @@ template <typename Ptr> __device__ __forceinline__ TriShade load_tri_shade_at(Pt
     t.t1 = r[4 ^ swz];
     t.t2 = r[5 ^ swz];
     const float4 r7 = r[7 ^ swz];
-    t.hint0 = __float_as_uint(r7.y);
-    t.hint1 = __float_as_uint(r7.z);
-    t.hint_side = __float_as_uint(r7.w);
+    unpack_hints(r7, t.hint, t.hint_side);
     return t;
 }
 __device__ __forceinline__ TriShade load_tri_shade(const SceneView& S, uint32_t tri) { return load_tri_shade_at(S.shade + 8 * (size_t)tri, 0u); }

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
 {
     const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t flags = 0;
-    uint32_t hint[2] = {kNoHint, kNoHint};
+    uint32_t hint[kHints];
+    for (int h = 0; h < kHints; ++h)
+        hint[h] = kNoHint;
     bool hinted = false;
     if (ti < a.S.n_tris) {
         const float4 t0 = a.S.tris[3 * ti], t1 = a.S.tris[3 * ti + 1], t2 = a.S.tris[3 * ti + 2];
@@ -81,7 +83,12 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
         // GN the disk sample is on): the two triangles whose shadow covers most of the footprint.  gi_shade_kernel tries them
         // with the traverser's own triangle test before it emits a shadow ray -- any hit answers "occluded" exactly.
         const int primary = (R[0].valid && R[1].valid) ? (R[1].c_lo > R[0].c_lo ? 1 : 0) : (R[1].valid ? 1 : 0);
-        double best_area[2] = {0.0, 0.0};
+        // the kCand candidates that cover most sample origins so far (cover_mask), best first
+        constexpr int kCand = 8;
+        uint32_t cand_tri[kCand], cand_mask[kCand];
+        int cand_pop[kCand];
+        for (int k = 0; k < kCand; ++k)
+            cand_tri[k] = kNoHint, cand_mask[k] = 0u, cand_pop[k] = 0;
         if (R[0].valid || R[1].valid) {
             // the column both sides' rays can sweep, in sun coordinates
             double qa[2] = {1e300, -1e300}, qb[2] = {1e300, -1e300}, qh = 1e300;
@@ -110,12 +117,15 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                         if (alive[s] && lit::may_occlude(a.F, R[s], O))
                             alive[s] = false;
                     if (R[primary].valid && tj != ti) {
-                        const double c = lit::shadow_cover(R[primary], O);
-                        if (c > best_area[0]) {
-                            best_area[1] = best_area[0], hint[1] = hint[0];
-                            best_area[0] = c, hint[0] = tj;
-                        } else if (c > best_area[1]) {
-                            best_area[1] = c, hint[1] = tj;
+                        const uint32_t m = lit::cover_mask(R[primary], O);
+                        const int pc = __popc(m);
+                        if (pc > cand_pop[kCand - 1]) { // insertion into the sorted candidate list
+                            int at = kCand - 1;
+                            while (at > 0 && cand_pop[at - 1] < pc) {
+                                cand_tri[at] = cand_tri[at - 1], cand_mask[at] = cand_mask[at - 1], cand_pop[at] = cand_pop[at - 1];
+                                --at;
+                            }
+                            cand_tri[at] = tj, cand_mask[at] = m, cand_pop[at] = pc;
                         }
                     }
                 }
@@ -166,13 +176,26 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
         float4 w6 = r6;
         w6.w = __uint_as_float(geom | (flags << kLitShift));
         a.shade[8 * (size_t)ti + 6] = w6;
-        if (alive[primary])
-            hint[0] = hint[1] = kNoHint; // nothing to hint at: every ray of that side is answered by the lit bit
-        // r7 = {PrimitiveIndex, hint 0, hint 1, side the hints are for}
+        // greedy cover: up to kHints candidates, each the one that adds most samples not yet covered
+        if (!alive[primary]) { // (a lit side needs no hints: every ray of it is answered by the lit bit)
+            uint32_t covered = 0u;
+            for (int h = 0; h < kHints; ++h) {
+                int best = -1, gain = 0;
+                for (int k = 0; k < kCand; ++k) {
+                    const int gk = cand_tri[k] != kNoHint ? __popc(cand_mask[k] & ~covered) : 0;
+                    if (gk > gain)
+                        gain = gk, best = k;
+                }
+                if (best < 0)
+                    break;
+                hint[h] = cand_tri[best];
+                covered |= cand_mask[best];
+                cand_tri[best] = kNoHint;
+            }
+        }
+        // r7 = {PrimitiveIndex, then kHints x 21-bit triangle indices and the side they are for: see pack_hints}
         float4 w7 = rec[7];
-        w7.y = __uint_as_float(hint[0]);
-        w7.z = __uint_as_float(hint[1]);
-        w7.w = __uint_as_float((uint32_t)primary);
+        pack_hints(hint, (uint32_t)primary, w7);
         a.shade[8 * (size_t)ti + 7] = w7;
         hinted = hint[0] != kNoHint;
     }
@@ -193,7 +216,8 @@ __global__ void sun_table_clear_kernel(float4* shade, uint32_t n)
     if (ti < n) {
         float4* p = shade + 8 * (size_t)ti + 6;
         p->w = __uint_as_float(__float_as_uint(p->w) & kGeomMask);
-        p[1].y = p[1].z = __uint_as_float(kNoHint);
+        const uint32_t none[kHints] = {kNoHint, kNoHint, kNoHint, kNoHint};
+        pack_hints(none, 0u, p[1]);
     }
 }
 

@@ -228,6 +228,45 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
     return false;
 }
 
+// Which of kCoverSamples fixed sample origins of R (a triangular grid of barycentrics, offset to the middle of the origin box)
+// a ray towards the centre of the sun disk would leave through O: bit k of the mask.  Only RANKS occluder hints
+// (gi_sun_table.hip): a hint is tried with the traverser's own triangle test, so a poor estimate costs speed, never correctness.
+constexpr int kCoverSamples = 28;
+NEB_LIT_HD unsigned cover_mask(const Receiver& R, const Tri& O)
+{
+    // quick reject on the lateral boxes
+    double oa0 = O.a[0], oa1 = O.a[0], ob0 = O.b[0], ob1 = O.b[0];
+    for (int i = 1; i < 3; ++i) {
+        oa0 = O.a[i] < oa0 ? O.a[i] : oa0, oa1 = O.a[i] > oa1 ? O.a[i] : oa1;
+        ob0 = O.b[i] < ob0 ? O.b[i] : ob0, ob1 = O.b[i] > ob1 ? O.b[i] : ob1;
+    }
+    if (oa1 < R.bb_a[0] || oa0 > R.bb_a[1] || ob1 < R.bb_b[0] || ob0 > R.bb_b[1])
+        return 0u;
+    const double ua = O.a[1] - O.a[0], ub = O.b[1] - O.b[0], wa = O.a[2] - O.a[0], wb = O.b[2] - O.b[0];
+    const double det = ua * wb - ub * wa;
+    if (det == 0.0)
+        return 0u; // edge-on to the sun: no area to stand in
+    const double inv = 1.0 / det;
+    const double ma = 0.5 * (R.off_a[0] + R.off_a[1]), mb = 0.5 * (R.off_b[0] + R.off_b[1]), mc = 0.5 * (R.c_lo + R.c_hi);
+    unsigned mask = 0u;
+    int k = 0;
+    for (int r = 0; r < 7; ++r)
+        for (int c = 0; c < 7 - r; ++c, ++k) {
+            const double bu = (r + 1.0 / 3.0) / 7.0, bv = (c + 1.0 / 3.0) / 7.0;
+            const double pa = R.t.a[0] + bu * (R.t.a[1] - R.t.a[0]) + bv * (R.t.a[2] - R.t.a[0]) + ma;
+            const double pb = R.t.b[0] + bu * (R.t.b[1] - R.t.b[0]) + bv * (R.t.b[2] - R.t.b[0]) + mb;
+            const double da = pa - O.a[0], db = pb - O.b[0];
+            const double s = (da * wb - db * wa) * inv, t = (ua * db - ub * da) * inv; // barycentrics of the sample in O's projection
+            if (s < 0.0 || t < 0.0 || s + t > 1.0)
+                continue;
+            const double ho = O.h[0] + s * (O.h[1] - O.h[0]) + t * (O.h[2] - O.h[0]);
+            const double hr = R.h0 + R.ga * (pa - ma) + R.gb * (pb - mb) + mc;
+            if (ho > hr + 1e-3)
+                mask |= 1u << k;
+        }
+    return mask;
+}
+
 // How much of R's projected triangle lies in the shadow of O: the area of O's projection inside R's, counted only where that part
 // of O is above every ray origin of R.  Only RANKS occluder hints (gi_sun_table.hip): a hint is tried with the traverser's own
 // triangle test, so a poor estimate costs speed, never correctness.

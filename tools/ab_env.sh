@@ -20,6 +20,6 @@ build = sum(v for k, v in tot.items() if "ploc_" in k or "collapse_" in k)
 import json
 line = [l for l in open(sys.argv[2] + ".log") if l.startswith("{")]
 j = json.loads(line[-1]) if line else {"value": 0, "kernel_us": {"gi_trace": 0}}
-print("%-44s raygen_trace %.1f resume %.1f shade %.1f shadow %.1f | GI (events) %.1f us, %.1f fps" % (sys.argv[1], pick("gi_raygen_trace"), pick("gi_resume"), pick("gi_shade"), pick("gi_shadow_trace"), j["kernel_us"]["gi_trace"], j["value"]))
+print("%-44s raygen_trace %.1f resume %.1f shade %.1f shadow %.1f | GI (events) %.1f us, %.1f fps" % (sys.argv[1], pick("gi_raygen_trace"), pick("gi_resume"), pick("gi_shade"), pick("gi_shadow_"), j["kernel_us"]["gi_trace"], j["value"]))
 PY
 done

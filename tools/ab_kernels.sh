@@ -10,6 +10,6 @@ import csv, glob, sys
 f = glob.glob(f"gpurun_out/abk_{sys.argv[1]}/*/*kernel_stats.csv")[0]
 rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(f))}
 pick = lambda s: sum(v for k, v in rows.items() if s in k)
-print(sys.argv[1], "raygen_trace %.1f shade %.1f shadow %.1f" % (pick("gi_raygen_trace"), pick("gi_shade"), pick("gi_shadow_trace")))
+print(sys.argv[1], "raygen_trace %.1f shade %.1f shadow %.1f" % (pick("gi_raygen_trace"), pick("gi_shade"), pick("gi_shadow_")))
 PY
 done
