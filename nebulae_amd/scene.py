@@ -544,12 +544,17 @@ def cornell_standin(textured=False):
     return sc
 
 
-def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex_size=1024, seed=2025):
+def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex_size=1024, seed=2025, long_thin=False):
     """'sponza-standin': a colonnaded two-storey atrium with arches, drapes and clutter, in Sponza's
     local units under the node scale 0.00800000038 and inside its local AABB
-    (assets/sponza/Sponza.gltf accessor min/max: [-1921,-126,-1183] .. [1800,1429,1105])."""
+    (assets/sponza/Sponza.gltf accessor min/max: [-1921,-126,-1183] .. [1800,1429,1105]).
+    long_thin: the pathology of the real asset that a uniformly gridded stand-in lacks ("long thin triangles") --
+    the outer walls, gallery floors, their undersides and the roofs become full-length strips (aspect ratios of 50:1 to 120:1,
+    ~1 500 triangles that each cross a large part of the atrium) and 40 thin beams span the court, while the floor keeps the
+    bulk of the triangle budget: boxes of such triangles overlap everything along their length, which is what a BVH built from
+    centroids handles worst."""
     rng = np.random.default_rng(seed)
-    sc = Scene("sponza-standin")
+    sc = Scene("sponza-standin-longthin" if long_thin else "sponza-standin")
     S = 0.00800000037997961
     M = np.diag([S, S, S, 1.0]).astype(F)
     lo = np.array([-1920.9, -126.4, -1182.8])
@@ -648,23 +653,30 @@ def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex
     x0, x1, z0, z1 = lo[0], hi[0], lo[2], hi[2]
     yf, y2, yc = lo[1] + 126.0, 560.0, hi[1]
     ix0, ix1, iz0, iz1 = x0 + 700, x1 - 700, z0 + 520, z1 - 520  # inner court
+
+    def grid(nu, nv, strips_along_u):  # long_thin: one cell along the long side, the strips across it
+        return ((1, nv) if strips_along_u else (nu, 1)) if long_thin else (nu, nv)
     parts.append(plane(x0, x1, z0, z1, yf, 160, 96, bump=0.6))                      # floor
-    parts.append(plane(x0, ix0, z0, z1, y2, 40, 64))                               # gallery floors (4)
-    parts.append(plane(ix1, x1, z0, z1, y2, 40, 64))
-    parts.append(plane(ix0, ix1, z0, iz0, y2, 56, 24))
-    parts.append(plane(ix0, ix1, iz1, z1, y2, 56, 24))
-    parts.append(plane(x0, ix0, z0, z1, y2 - 20, 24, 40, up=False))                # gallery undersides (4)
-    parts.append(plane(ix1, x1, z0, z1, y2 - 20, 24, 40, up=False))
-    parts.append(plane(ix0, ix1, z0, iz0, y2 - 20, 40, 16, up=False))
-    parts.append(plane(ix0, ix1, iz1, z1, y2 - 20, 40, 16, up=False))
-    parts.append(plane(x0, ix0, z0, z1, yc, 16, 24, up=False))                     # roof over galleries (4); court open
-    parts.append(plane(ix1, x1, z0, z1, yc, 16, 24, up=False))
-    parts.append(plane(ix0, ix1, z0, iz0, yc, 24, 12, up=False))
-    parts.append(plane(ix0, ix1, iz1, z1, yc, 24, 12, up=False))
-    parts.append(wall((x0, z0), (x1, z0), yf, yc, 120, 48, flip=True))             # outer walls (4), facing inward
-    parts.append(wall((x1, z1), (x0, z1), yf, yc, 120, 48, flip=True))
-    parts.append(wall((x0, z1), (x0, z0), yf, yc, 80, 48, flip=True))
-    parts.append(wall((x1, z0), (x1, z1), yf, yc, 80, 48, flip=True))
+    parts.append(plane(x0, ix0, z0, z1, y2, *grid(40, 64, False)))                 # gallery floors (4)
+    parts.append(plane(ix1, x1, z0, z1, y2, *grid(40, 64, False)))
+    parts.append(plane(ix0, ix1, z0, iz0, y2, *grid(56, 24, True)))
+    parts.append(plane(ix0, ix1, iz1, z1, y2, *grid(56, 24, True)))
+    parts.append(plane(x0, ix0, z0, z1, y2 - 20, *grid(24, 40, False), up=False))  # gallery undersides (4)
+    parts.append(plane(ix1, x1, z0, z1, y2 - 20, *grid(24, 40, False), up=False))
+    parts.append(plane(ix0, ix1, z0, iz0, y2 - 20, *grid(40, 16, True), up=False))
+    parts.append(plane(ix0, ix1, iz1, z1, y2 - 20, *grid(40, 16, True), up=False))
+    parts.append(plane(x0, ix0, z0, z1, yc, *grid(16, 24, False), up=False))       # roof over galleries (4); court open
+    parts.append(plane(ix1, x1, z0, z1, yc, *grid(16, 24, False), up=False))
+    parts.append(plane(ix0, ix1, z0, iz0, yc, *grid(24, 12, True), up=False))
+    parts.append(plane(ix0, ix1, iz1, z1, yc, *grid(24, 12, True), up=False))
+    parts.append(wall((x0, z0), (x1, z0), yf, yc, *grid(120, 48, True), flip=True))  # outer walls (4), facing inward
+    parts.append(wall((x1, z1), (x0, z1), yf, yc, *grid(120, 48, True), flip=True))
+    parts.append(wall((x0, z1), (x0, z0), yf, yc, *grid(80, 48, True), flip=True))
+    parts.append(wall((x1, z0), (x1, z1), yf, yc, *grid(80, 48, True), flip=True))
+    if long_thin:  # 40 beams across the court, 2 290 x 12 x 12 units each (12 triangles of 190:1), at the two storeys
+        beams = [_box((ix0, y, z - 6.0), (ix1, y + 12.0, z + 6.0), uv_scale=8.0)
+                 for y in (y2 - 60.0, yc - 90.0) for z in np.linspace(iz0 + 40.0, iz1 - 40.0, 20)]
+        parts.append(_merge(beams))
     ncol = 0
     for storey, (ya, yb) in enumerate(((yf, y2 - 20), (y2, yc - 60))):
         for cx in np.linspace(ix0, ix1, 9):
