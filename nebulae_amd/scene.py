@@ -674,7 +674,9 @@ def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex
     parts.append(wall((x0, z1), (x0, z0), yf, yc, *grid(80, 48, True), flip=True))
     parts.append(wall((x1, z0), (x1, z1), yf, yc, *grid(80, 48, True), flip=True))
     if long_thin:  # 40 beams across the court, 2 290 x 12 x 12 units each (12 triangles of 190:1), at the two storeys
-        beams = [_box((ix0, y, z - 6.0), (ix1, y + 12.0, z + 6.0), uv_scale=8.0)
+        # (one texture repeat per ~20 beam widths: a map that repeated eight times across a 10 cm face would put 85 k texels on a world
+        # unit and turn the last ulp of a bounce direction -- ocml's against glibc's sinf -- into a different texel)
+        beams = [_box((ix0, y, z - 6.0), (ix1, y + 12.0, z + 6.0), uv_scale=0.05)
                  for y in (y2 - 60.0, yc - 90.0) for z in np.linspace(iz0 + 40.0, iz1 - 40.0, 20)]
         parts.append(_merge(beams))
     ncol = 0

@@ -42,12 +42,14 @@ def scenes():
         "cornell": (lambda: S.cornell_standin(textured=True), S.orbit_camera(), 256, 256),
         "cornell_factors": (lambda: S.cornell_standin(textured=False), S.orbit_camera(yaw_deg=10.0, pitch_deg=80.0, distance=2.6), 200, 152),
         "atrium_small": (lambda: S.atrium_standin(target_triangles=30000, n_submeshes=60, tex_size=64), S.sponza_camera(), 320, 184),
+        # the real Sponza's pathology: full-length wall / floor / roof strips and beams across the court (aspect ratios up to 190:1)
+        "atrium_longthin": (lambda: S.atrium_standin(target_triangles=60000, n_submeshes=70, tex_size=64, long_thin=True), S.sponza_camera(), 320, 184),
     }
 
 
 @pytest.mark.parametrize("name,spp,sort_rays",
                          [(n, s, m) for n in ("cornell", "cornell_factors", "atrium_small") for s, m in ((1, 0), (3, 1), (1, 3), (2, 2))]
-                         + [("atrium_mixed_tex", 1, 1)])
+                         + [("atrium_mixed_tex", 1, 1), ("atrium_longthin", 1, 1), ("atrium_longthin", 2, 0)])
 def test_gi_matches_oracle(name, spp, sort_rays):
     """sort_rays: the "gi_sort_rays" mask (bit 0 shadow rays, bit 1 bounce rays)."""
     make, cam, W, H = scenes()[name]
@@ -78,7 +80,12 @@ def test_gi_matches_oracle(name, spp, sort_rays):
     assert np.array_equal(got[..., 3], base[..., 3])  # alpha untouched
     assert rel_l2(got[..., :3], want[..., :3]) <= 2e-3
     # (the hit record covers the last sample only: with spp > 1 an earlier sample may still differ)
-    assert rel_l2(got[same][:, :3], want[same][:, :3]) <= (2e-5 if spp == 1 else 2e-4)
+    # long-thin: a 30-unit triangle puts 1e-7 * 30 of rounding into a hit point (tv = o - v0 cancels large coordinates), and the
+    # device's and the host's bounce directions differ by an ulp of sinf / cosf: on this scene's 64^2 high-contrast maps the texel
+    # fractions move by ~1e-3 on a few grazing hits (measured 3.7e-5 overall; the full-size scene with its 1024^2 maps: 1.2e-5 at
+    # 1080p, 7 of 2 073 600 hits / flags different, tools/gi_stats.py)
+    bar = 1e-4 if name == "atrium_longthin" else 2e-5
+    assert rel_l2(got[same][:, :3], want[same][:, :3]) <= (bar if spp == 1 else 2e-4)
     t_err = np.abs(hits["t"][same] - ohits["t"][same]) / np.maximum(np.abs(ohits["t"][same]), 1e-6)
     assert t_err.max() <= 1e-4
     r.destroy()

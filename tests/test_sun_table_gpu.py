@@ -67,7 +67,7 @@ def _same(a, b):
     assert na == nb                                         # a ray = a visibility query, however it is answered
 
 
-@pytest.mark.parametrize("name,spp,vertices", [("atrium_small", 1, 2), ("atrium_small", 3, 2), ("atrium_small", 2, 4), ("atrium_mixed_tex", 1, 2),
+@pytest.mark.parametrize("name,spp,vertices", [("atrium_small", 1, 2), ("atrium_small", 3, 2), ("atrium_small", 2, 4), ("atrium_mixed_tex", 1, 2), ("atrium_longthin", 1, 2),
                                                ("cornell", 2, 3), ("cornell_factors", 1, 2)])
 def test_table_on_and_off_give_the_same_bits(name, spp, vertices):
     make, cam, W, H = scenes()[name]
