@@ -886,8 +886,11 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     // explicitly it is on from 1.5 M pixels.  Results do not depend on it (every pixel is written once, whatever the order).
     // With the sun table most shadow rays are answered in the shade pass; the rest are compacted into ray lists there and traced
     // unsorted (the sort's six launches cost more than coherence is worth to the ~14 % that are left).
-    const bool use_table = g->sun_table; // (brought up to date below, before the first launch)
-    const bool compact = use_table && g->compact_shadow;
+    // the sun-visibility table: brought up to date with this frame's sun (a rebuild only when the sun or the scene changed -- and
+    // then only once the new sun has held for a second frame: a sun that is being dragged is traced the plain way meanwhile)
+    GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
+    a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
+    const bool compact = a.sun_table && g->compact_shadow;
     const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
     if (sort_shadow || g->sort_bounce) {
         if (!g->d_sort) {
@@ -929,9 +932,6 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     a.bounce_counts = g->d_block_counts;
     a.shadow_counts = g->d_block_counts + g->n_block_counts;
     a.table_counts = g->d_block_counts + 2 * g->n_block_counts;
-    // the sun-visibility table: brought up to date with this frame's sun (a rebuild only when the sun or the scene changed)
-    GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
-    a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
     a.list = nullptr;
     a.list_counts = nullptr;
     a.list_cap = a.list_set = 0;

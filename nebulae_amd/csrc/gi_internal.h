@@ -173,7 +173,8 @@ struct GiState {
     size_t n_block_counts = 0;
     // the sun-visibility table in the shading records (gi_sun_table.hip)
     bool sun_table = true;            // option "gi_sun_table"
-    int sun_table_state = 0;          // 0: the records carry no flags; 1: flags of sun_table_key
+    int sun_table_state = 0;          // 0: the records carry no flags; 1: flags of sun_table_key = this frame's sun; 2: flags of another sun (ignored)
+    float sun_table_pending[4] = {0, 0, 0, 0}; // a new sun seen once: the table follows when it is seen again
     float sun_table_key[4] = {0, 0, 0, 0}; // {sunLightDirection, sunTanHalfAngle} the flags were built for
     unsigned long long* d_sun_counts = nullptr; // sides proven lit {+, -} by the last build
     uint32_t sun_table_builds = 0;

@@ -235,8 +235,19 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         }
         return hipGetLastError();
     }
-    if (g->sun_table_state == 1 && !memcmp(key, g->sun_table_key, sizeof(key)))
+    if (g->sun_table_state != 0 && !memcmp(key, g->sun_table_key, sizeof(key))) {
+        g->sun_table_state = 1; // (back to the sun the flags were built for)
         return hipSuccess;
+    }
+    // A new sun.  The build takes milliseconds -- twenty frames' worth -- so a sun that is being dragged (a new direction every
+    // frame; the reference marks those frames dynamic, src/DeferredRenderer.cpp:169-171) is not chased: the flags in the records
+    // stay those of the old sun and are IGNORED (state 2: every shadow ray is traced, as without the table) until the same new sun
+    // has been seen on two consecutive dispatches.  The very first build has nothing to wait for.
+    if (g->sun_table_state != 0 && memcmp(key, g->sun_table_pending, sizeof(key))) {
+        memcpy(g->sun_table_pending, key, sizeof(key));
+        g->sun_table_state = 2;
+        return hipSuccess;
+    }
     const float dd = key[0] * key[0] + key[1] * key[1] + key[2] * key[2];
     if (!(dd > 0.0f) || !(dd < 1e30f) || !(key[3] >= 0.0f) || !(key[3] < 1.0f)) { // no usable sun: no certificate, every ray is traced
         if (g->sun_table_state != 0)

@@ -116,18 +116,40 @@ def test_the_table_follows_the_sun():
     off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
     off.svgf.set_option("gi_sun_table", 0)
     suns = [((0.5, -1.0, -0.2), 0.58), ((-0.3, -1.0, 0.4), 0.58), ((-0.3, -1.0, 0.4), 3.0), ((0.0, -1.0, 0.0), 0.0), ((0.5, -1.0, -0.2), 0.58)]
-    for f, (direction, diameter) in enumerate(suns, start=2):
+    f, builds = 2, 0
+    for idx, (direction, diameter) in enumerate(suns):
         for r in (on, off):
             r.sun.direction, r.sun.rough_diameter = direction, diameter
+        # a sun that has just moved is traced the plain way (no rebuild for a sun that is being dragged: the table follows once the
+        # same sun is seen a second time); the first sun of a scene is built at once
+        for rep in range(3):
+            _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+            st = on.sun_table_stats()
+            if (idx == 0 and rep == 0) or (idx > 0 and rep == 1):
+                builds += 1
+            assert st["builds"] == builds, (direction, rep, st)
+            assert (st["rays_answered"] > 0) == (idx == 0 or rep >= 1), (direction, rep, st)
+            f += 1
+    # a sun dragged through five positions, one per frame: not one rebuild
+    for k in range(5):
+        for r in (on, off):
+            r.sun.direction = (0.5 - 0.1 * k, -1.0, -0.2)
         _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
-    assert on.sun_table_stats()["builds"] == len(suns)
+        f += 1
+    assert on.sun_table_stats()["builds"] == builds + 0 and on.sun_table_stats()["rays_answered"] == 0
+    for r in (on, off):
+        r.sun.direction, r.sun.rough_diameter = suns[0]
+    _frame(on, sc, cam, W, H, f)
+    _frame(off, sc, cam, W, H, f)
+    _same(_frame(on, sc, cam, W, H, f + 1), _frame(off, sc, cam, W, H, f + 1))
+    builds = on.sun_table_stats()["builds"]
     # switching the option off clears the flags; on again rebuilds them
     on.svgf.set_option("gi_sun_table", 0)
     _same(_frame(on, sc, cam, W, H, 9), _frame(off, sc, cam, W, H, 9))
     assert on.sun_table_stats()["rays_answered"] == 0
     on.svgf.set_option("gi_sun_table", 1)
     _same(_frame(on, sc, cam, W, H, 10), _frame(off, sc, cam, W, H, 10))
-    assert on.sun_table_stats()["rays_answered"] > 0 and on.sun_table_stats()["builds"] == len(suns) + 1
+    assert on.sun_table_stats()["rays_answered"] > 0 and on.sun_table_stats()["builds"] == builds + 1
     on.destroy()
     off.destroy()
 
