@@ -596,13 +596,15 @@ def main(argv=None, rt=None, emit=None):
     w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme, link=link)
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
-    bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth()} if do_gi else None
+    bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth(), "build_ms": round(r.build_ms(), 2)} if do_gi else None
 
     # (frame 1 -- "camera moved": SVGF skipped -- ran in the set-up; frame 2 resets the history.  At least one warm-up frame runs so
     # that every timed frame is a steady-state denoised frame; `warmup_run` on the line says what ran)
     warmup_run = max(args.warmup, 1)
     dt, rays_total = w.timed(args.steps, warmup_run)
     assert all(w.ran_svgf), "SVGF was skipped inside the timed region"
+    if do_gi:  # (as of the ray count that ended the timed region: sides proven lit, shadow rays the table answered in those K frames)
+        bvh["sun_table"] = r.sun_table_stats()
     # the settled rate: the same K steps, timed the same way, once the context has run SETTLE_FRAMES frames in all
     settle_run = max(Workload.SETTLE_FRAMES - warmup_run - args.steps, 0)
     dt_settled, _ = w.timed(args.steps, settle_run)

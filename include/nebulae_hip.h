@@ -296,6 +296,8 @@ int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3]);
 int neb_gi_bvh_depth(const neb_ctx* ctx, uint32_t* depth);
 /* Passes (levels of the binary SAH tree) the last successful build took: diagnostics. */
 int neb_gi_build_passes(const neb_ctx* ctx, uint32_t* passes);
+/* Wall time in milliseconds of the last successful neb_gi_build_bvh (the build ends with a stream synchronisation). */
+int neb_gi_build_ms(const neb_ctx* ctx, float* ms);
 /* DeferredRenderer::SubmitCommandsGIPathtrace: radiance[cur].rgb += mean over spp of the path radiance
  * (stands in for NRC Resolve, DeferredRenderer.cpp:586).  Reads the ALBEDO / ROUGH_METAL / WORLDPOS planes and
  * normal[cur].  _rows: image rows [row0,row1) only (multi-GPU strips). */

@@ -85,6 +85,7 @@ def _gi_sigs():
         "neb_gi_scene_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "neb_gi_bvh_depth": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
         "neb_gi_build_passes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+        "neb_gi_build_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
         "neb_gi_scene_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
         "neb_gi_trace": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_void_p]),
         "neb_gi_trace_rows": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_uint32, C.c_uint32, C.c_void_p]),

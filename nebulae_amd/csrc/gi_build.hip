@@ -8,6 +8,7 @@
 #include <rocprim/device/device_scan.hpp> // (the one-time build: 64-bit key sort and prefix sums from ROCm's own primitives, not the CUB-compatible layer)
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 #include "gi_device.h"
@@ -186,6 +187,9 @@ __global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint6
 // ------------------------------------------------------------------------------------------------
 #ifndef NEB_SAH_BINS
 #define NEB_SAH_BINS 32
+#endif
+#ifndef NEB_SAH_BIG
+#define NEB_SAH_BIG 1 // the first levels' splits spread over the chip (sah_big_* kernels); 0: one workgroup per segment at every level
 #endif
 constexpr int kSahBins = NEB_SAH_BINS;
 
@@ -411,6 +415,369 @@ __global__ __launch_bounds__(kSahThreads) void sah_split_kernel(BinaryNodes N, c
         __syncthreads();
         if (tid == 0) {
             const uint32_t chunk = min((uint32_t)kSahThreads, end - base);
+            s_run[0] = run_l + chunk_lefts;
+            s_run[1] = run_r + (chunk - chunk_lefts);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- the same split for the FIRST levels, spread over the chip (round 4) ----
+// At the top of the tree a level has a handful of segments of 10^4 .. 10^5 primitives; one workgroup per segment (above) walks
+// such a run three times in strides of 1024 with LDS atomics in its way -- the root split alone took 6.4 ms of a 16-ms build.
+// Here a segment is cut into SLICES of kSahSlice primitives, one workgroup each: centroid bounds and bins are reduced per
+// slice in LDS and merged into per-segment global words with ordered-uint atomicMin / atomicMax and integer adds (all
+// order-independent), one small workgroup per segment evaluates the very same SAH candidates in the very same order, and the
+// stable partition becomes count -> per-segment scan over the slices -> scatter.  Same arithmetic, same tie-breaks, same
+// primitive order: the tree is bit-identical to the one-workgroup-per-segment build (tests/test_gi_gpu.py compares node
+// counts, depth and whole frames against the numbers of that build).
+constexpr uint32_t kSahSlice = 2048u;      // primitives per slice
+constexpr uint32_t kSahBigMaxSegs = 1024u; // segments of a level the slice index is built for (more: the level is not "big")
+struct SahBig {
+    uint32_t* slice_begin;  // [n_segs + 1] exclusive prefix of the segments' slice counts
+    uint32_t* cb;           // [n_segs][6] centroid bounds, ordered uints {min xyz, max xyz}
+    uint32_t* bins;         // [n_segs][4][kSahBins][7] {lo xyz, hi xyz (ordered uints), count}
+    uint32_t* slice_left;   // [n_slices] lefts in the slice, then (after the scan) lefts in the segment's slices before it
+};
+struct SahBigPick {
+    int axis, split;
+    uint32_t n_left, pad;
+    float cmin[3], scale[3];
+};
+
+__global__ __launch_bounds__(1024) void sah_big_index_kernel(const SahSegment* __restrict__ segs, uint32_t n_segs, SahBig B)
+{
+    __shared__ uint32_t s_scan[kSahBigMaxSegs];
+    const uint32_t tid = threadIdx.x;
+    uint32_t mine = 0;
+    if (tid < n_segs)
+        mine = (segs[tid].end - segs[tid].begin + kSahSlice - 1u) / kSahSlice;
+    s_scan[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < kSahBigMaxSegs; off <<= 1) {
+        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    if (tid < n_segs) {
+        B.slice_begin[tid + 1] = s_scan[tid];
+        if (tid == 0)
+            B.slice_begin[0] = 0u;
+        for (int q = 0; q < 3; ++q) {
+            B.cb[6 * tid + q] = 0xffffffffu;
+            B.cb[6 * tid + 3 + q] = 0u;
+        }
+    }
+    // the bins of every segment: lo = +max, hi = 0, count = 0
+    for (uint32_t k = tid; k < n_segs * 4u * kSahBins; k += 1024u) {
+        uint32_t* b = B.bins + 7u * k;
+        b[0] = b[1] = b[2] = 0xffffffffu;
+        b[3] = b[4] = b[5] = 0u;
+        b[6] = 0u;
+    }
+}
+
+// slice -> (segment, first primitive, one-past-last primitive); false: this block has no slice
+__device__ __forceinline__ bool sah_big_slice(const SahSegment* segs, uint32_t n_segs, const SahBig& B, uint32_t& seg, uint32_t& first, uint32_t& last, SahSegment& sg)
+{
+    const uint32_t total = B.slice_begin[n_segs];
+    if (blockIdx.x >= total)
+        return false;
+    uint32_t lo = 0, hi = n_segs - 1u; // the segment whose slices contain blockIdx.x
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (B.slice_begin[mid + 1] > blockIdx.x)
+            hi = mid;
+        else
+            lo = mid + 1u;
+    }
+    seg = lo;
+    sg = segs[seg];
+    first = sg.begin + (blockIdx.x - B.slice_begin[seg]) * kSahSlice;
+    last = min(sg.end, first + kSahSlice);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void sah_big_bounds_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, uint32_t n_segs, const uint32_t* __restrict__ idx_in, SahBig B)
+{
+    __shared__ uint32_t s_cmin[3], s_cmax[3];
+    uint32_t seg, first, last;
+    SahSegment sg;
+    if (!sah_big_slice(segs, n_segs, B, seg, first, last, sg))
+        return;
+    const int tid = threadIdx.x;
+    if (tid < 3) {
+        s_cmin[tid] = 0xffffffffu;
+        s_cmax[tid] = 0u;
+    }
+    __syncthreads();
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = first + tid; i < last; i += 256u) {
+        const uint32_t p = idx_in[i];
+        const float4 lo = N.lo[p], hi = N.hi[p];
+        const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+        for (int q = 0; q < 3; ++q) {
+            mn[q] = fminf(mn[q], c[q]);
+            mx[q] = fmaxf(mx[q], c[q]);
+        }
+    }
+    for (int q = 0; q < 3; ++q) {
+        atomicMin(&s_cmin[q], float_to_ordered(mn[q]));
+        atomicMax(&s_cmax[q], float_to_ordered(mx[q]));
+    }
+    __syncthreads();
+    if (tid < 3) {
+        atomicMin(&B.cb[6 * seg + tid], s_cmin[tid]);
+        atomicMax(&B.cb[6 * seg + 3 + tid], s_cmax[tid]);
+    }
+}
+
+__device__ __forceinline__ void sah_big_scale(const SahBig& B, uint32_t seg, float cmin[3], float scale[3])
+{
+    for (int q = 0; q < 3; ++q) {
+        cmin[q] = ordered_to_float(B.cb[6 * seg + q]);
+        const float ext = ordered_to_float(B.cb[6 * seg + 3 + q]) - cmin[q];
+        scale[q] = ext > 0.0f ? (float)kSahBins / ext : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sah_big_bin_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, uint32_t n_segs, const uint32_t* __restrict__ idx_in, SahBig B)
+{
+    __shared__ uint32_t s_lo[4][kSahBins][3], s_hi[4][kSahBins][3], s_cnt[4][kSahBins];
+    uint32_t seg, first, last;
+    SahSegment sg;
+    if (!sah_big_slice(segs, n_segs, B, seg, first, last, sg))
+        return;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 4 * kSahBins; k += 256) {
+        const int ax = k / kSahBins, b = k % kSahBins;
+        for (int q = 0; q < 3; ++q) {
+            s_lo[ax][b][q] = 0xffffffffu;
+            s_hi[ax][b][q] = 0u;
+        }
+        s_cnt[ax][b] = 0u;
+    }
+    __syncthreads();
+    float cmin[3], scale[3];
+    sah_big_scale(B, seg, cmin, scale);
+    const uint32_t half = sg.begin + (sg.end - sg.begin) / 2;
+    for (uint32_t i = first + tid; i < last; i += 256u) {
+        const uint32_t p = idx_in[i];
+        const float4 lo = N.lo[p], hi = N.hi[p];
+        const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+        const uint32_t l[3] = {float_to_ordered(lo.x), float_to_ordered(lo.y), float_to_ordered(lo.z)};
+        const uint32_t h[3] = {float_to_ordered(hi.x), float_to_ordered(hi.y), float_to_ordered(hi.z)};
+        for (int ax = 0; ax < 4; ++ax) {
+            const int b = ax < 3 ? sah_bin(c[ax], cmin[ax], scale[ax]) : (i < half ? 0 : 1);
+            for (int q = 0; q < 3; ++q) {
+                atomicMin(&s_lo[ax][b][q], l[q]);
+                atomicMax(&s_hi[ax][b][q], h[q]);
+            }
+            atomicAdd(&s_cnt[ax][b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 4 * kSahBins; k += 256) {
+        const int ax = k / kSahBins, b = k % kSahBins;
+        if (!s_cnt[ax][b])
+            continue;
+        uint32_t* g = B.bins + 7u * ((size_t)seg * 4u * kSahBins + (uint32_t)k);
+        for (int q = 0; q < 3; ++q) {
+            atomicMin(&g[q], s_lo[ax][b][q]);
+            atomicMax(&g[3 + q], s_hi[ax][b][q]);
+        }
+        atomicAdd(&g[6], s_cnt[ax][b]);
+    }
+}
+
+// one workgroup per segment: the SAH candidates of sah_split_kernel, evaluated on the merged bins, in the same order
+__global__ __launch_bounds__(128) void sah_big_pick_kernel(const SahSegment* __restrict__ segs, uint32_t n_segs, SahBig B, SahSplit* __restrict__ splits, SahBigPick* __restrict__ picks)
+{
+    constexpr int kT = 128;
+    __shared__ float s_cost[kT];
+    __shared__ int s_pick[kT];
+    const uint32_t seg = blockIdx.x;
+    const SahSegment sg = segs[seg];
+    const uint32_t* bins = B.bins + 7u * ((size_t)seg * 4u * kSahBins);
+    auto cnt = [&](int ax, int b) { return bins[7 * (ax * kSahBins + b) + 6]; };
+    auto blo = [&](int ax, int b, int q) { return ordered_to_float(bins[7 * (ax * kSahBins + b) + q]); };
+    auto bhi = [&](int ax, int b, int q) { return ordered_to_float(bins[7 * (ax * kSahBins + b) + 3 + q]); };
+    const int tid = threadIdx.x;
+    {
+        float cost = INFINITY;
+        int pick = -1;
+        for (int cand = tid; cand < 3 * (kSahBins - 1); cand += kT) {
+            const int ax = cand / (kSahBins - 1), sp = cand % (kSahBins - 1) + 1;
+            float3 llo = f3(INFINITY, INFINITY, INFINITY), lhi = f3(-INFINITY, -INFINITY, -INFINITY), rlo = llo, rhi = lhi;
+            uint32_t nl = 0, nr = 0;
+            for (int b = 0; b < kSahBins; ++b) {
+                const uint32_t c = cnt(ax, b);
+                if (!c)
+                    continue;
+                const float3 l3 = f3(blo(ax, b, 0), blo(ax, b, 1), blo(ax, b, 2)), h3 = f3(bhi(ax, b, 0), bhi(ax, b, 1), bhi(ax, b, 2));
+                if (b < sp) {
+                    llo = f3(fminf(llo.x, l3.x), fminf(llo.y, l3.y), fminf(llo.z, l3.z));
+                    lhi = f3(fmaxf(lhi.x, h3.x), fmaxf(lhi.y, h3.y), fmaxf(lhi.z, h3.z));
+                    nl += c;
+                } else {
+                    rlo = f3(fminf(rlo.x, l3.x), fminf(rlo.y, l3.y), fminf(rlo.z, l3.z));
+                    rhi = f3(fmaxf(rhi.x, h3.x), fmaxf(rhi.y, h3.y), fmaxf(rhi.z, h3.z));
+                    nr += c;
+                }
+            }
+            if (nl && nr) {
+                const float cst = box_half_area(llo, lhi) * (float)nl + box_half_area(rlo, rhi) * (float)nr;
+                if (cst < cost) {
+                    cost = cst;
+                    pick = cand;
+                }
+            }
+        }
+        s_cost[tid] = cost;
+        s_pick[tid] = pick;
+    }
+    __syncthreads();
+    for (int off = kT / 2; off > 0; off >>= 1) { // argmin; ties -> the smaller candidate index (as sah_split_kernel)
+        if (tid < off) {
+            const float c2 = s_cost[tid + off];
+            const int p2 = s_pick[tid + off];
+            if (p2 >= 0 && (s_pick[tid] < 0 || c2 < s_cost[tid] || (c2 == s_cost[tid] && p2 < s_pick[tid]))) {
+                s_cost[tid] = c2;
+                s_pick[tid] = p2;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int pick = s_pick[0];
+        const int axis = pick >= 0 ? pick / (kSahBins - 1) : 3;
+        const int split = pick >= 0 ? pick % (kSahBins - 1) + 1 : 1;
+        uint32_t n_left = 0;
+        for (int b = 0; b < split; ++b)
+            n_left += cnt(axis, b);
+        SahSplit sp;
+        sp.mid = sg.begin + n_left;
+        float l[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int b = 0; b < kSahBins; ++b) {
+            if (!cnt(axis, b))
+                continue;
+            float* d = b < split ? l : r;
+            for (int q = 0; q < 3; ++q) {
+                d[q] = fminf(d[q], blo(axis, b, q));
+                d[3 + q] = fmaxf(d[3 + q], bhi(axis, b, q));
+            }
+        }
+        for (int q = 0; q < 6; ++q) {
+            sp.lbox[q] = l[q];
+            sp.rbox[q] = r[q];
+        }
+        splits[seg] = sp;
+        SahBigPick pk;
+        pk.axis = axis;
+        pk.split = split;
+        pk.n_left = n_left;
+        pk.pad = 0;
+        sah_big_scale(B, seg, pk.cmin, pk.scale);
+        picks[seg] = pk;
+    }
+}
+
+__device__ __forceinline__ uint32_t sah_big_flag(const BinaryNodes& N, uint32_t p, uint32_t i, uint32_t half, const SahBigPick& pk)
+{
+    int b;
+    if (pk.axis < 3) {
+        const float4 lo = N.lo[p], hi = N.hi[p];
+        const float c = pk.axis == 0 ? 0.5f * (lo.x + hi.x) : (pk.axis == 1 ? 0.5f * (lo.y + hi.y) : 0.5f * (lo.z + hi.z));
+        b = sah_bin(c, pk.cmin[pk.axis], pk.scale[pk.axis]);
+    } else {
+        b = i < half ? 0 : 1;
+    }
+    return b < pk.split ? 1u : 0u;
+}
+
+// lefts per slice
+__global__ __launch_bounds__(256) void sah_big_count_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, uint32_t n_segs, const uint32_t* __restrict__ idx_in, SahBig B,
+                                                            const SahBigPick* __restrict__ picks)
+{
+    __shared__ uint32_t s_n;
+    uint32_t seg, first, last;
+    SahSegment sg;
+    if (!sah_big_slice(segs, n_segs, B, seg, first, last, sg))
+        return;
+    if (threadIdx.x == 0)
+        s_n = 0u;
+    __syncthreads();
+    const SahBigPick pk = picks[seg];
+    const uint32_t half = sg.begin + (sg.end - sg.begin) / 2;
+    uint32_t mine = 0;
+    for (uint32_t i = first + threadIdx.x; i < last; i += 256u)
+        mine += sah_big_flag(N, idx_in[i], i, half, pk);
+    atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        B.slice_left[blockIdx.x] = s_n;
+}
+
+// per segment: exclusive scan of its slices' left counts (a segment has at most n / kSahSlice slices: one thread walks them)
+__global__ void sah_big_scan_kernel(uint32_t n_segs, SahBig B)
+{
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= n_segs)
+        return;
+    uint32_t run = 0;
+    for (uint32_t k = B.slice_begin[seg]; k < B.slice_begin[seg + 1]; ++k) {
+        const uint32_t c = B.slice_left[k];
+        B.slice_left[k] = run;
+        run += c;
+    }
+}
+
+// stable partition of a slice into idx_out
+__global__ __launch_bounds__(256) void sah_big_scatter_kernel(BinaryNodes N, const SahSegment* __restrict__ segs, uint32_t n_segs, const uint32_t* __restrict__ idx_in,
+                                                              uint32_t* __restrict__ idx_out, SahBig B, const SahBigPick* __restrict__ picks)
+{
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_run[2];
+    uint32_t seg, first, last;
+    SahSegment sg;
+    if (!sah_big_slice(segs, n_segs, B, seg, first, last, sg))
+        return;
+    const int tid = threadIdx.x;
+    const SahBigPick pk = picks[seg];
+    const uint32_t half = sg.begin + (sg.end - sg.begin) / 2;
+    const uint32_t lefts_before = B.slice_left[blockIdx.x];            // lefts of the segment in the slices before this one
+    const uint32_t rights_before = (first - sg.begin) - lefts_before;  // ... and rights
+    if (tid == 0) {
+        s_run[0] = 0u;
+        s_run[1] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t base = first; base < last; base += 256u) {
+        const uint32_t i = base + tid;
+        uint32_t p = 0, flag = 0;
+        const bool in = i < last;
+        if (in) {
+            p = idx_in[i];
+            flag = sah_big_flag(N, p, i, half, pk);
+        }
+        s_scan[tid] = flag;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t incl = s_scan[tid], lb = incl - flag, chunk_lefts = s_scan[255];
+        const uint32_t run_l = s_run[0], run_r = s_run[1];
+        if (in) {
+            const uint32_t dst = flag ? sg.begin + lefts_before + run_l + lb : sg.begin + pk.n_left + rights_before + run_r + ((uint32_t)tid - lb);
+            idx_out[dst] = p;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t chunk = min(256u, last - base);
             s_run[0] = run_l + chunk_lefts;
             s_run[1] = run_r + (chunk - chunk_lefts);
         }
@@ -1012,6 +1379,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     hipStream_t stream = (hipStream_t)stream_;
     GI_GUARD(ctx);
     const uint32_t n = g->n_tris;
+    const auto t_build0 = std::chrono::steady_clock::now(); // (the build ends with a stream synchronisation: wall time = device time + launches)
     if (n == 0) { // empty scene: every ray misses
         g->built = true;
         g->n_nodes = 0;
@@ -1053,6 +1421,14 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     uint32_t* d_idx[2] = {(uint32_t*)dalloc((size_t)n * 4, false), (uint32_t*)dalloc((size_t)n * 4, false)};
     SahSegment* d_segs[2] = {(SahSegment*)dalloc((size_t)n * sizeof(SahSegment), false), (SahSegment*)dalloc((size_t)n * sizeof(SahSegment), false)};
     SahSplit* d_splits = (SahSplit*)dalloc((size_t)n * sizeof(SahSplit), false);
+    // the first levels, spread over the chip (sah_big_*): per-segment words for up to kSahBigMaxSegs segments, one word per slice
+    const uint32_t max_slices = n / kSahSlice + kSahBigMaxSegs + 1u;
+    SahBig big;
+    big.slice_begin = (uint32_t*)dalloc((kSahBigMaxSegs + 1u) * 4, false);
+    big.cb = (uint32_t*)dalloc(kSahBigMaxSegs * 6 * 4, false);
+    big.bins = (uint32_t*)dalloc((size_t)kSahBigMaxSegs * 4 * kSahBins * 7 * 4, false);
+    big.slice_left = (uint32_t*)dalloc((size_t)max_slices * 4, false);
+    SahBigPick* d_picks = (SahBigPick*)dalloc(kSahBigMaxSegs * sizeof(SahBigPick), false);
     unsigned long long* d_flags = (unsigned long long*)dalloc((size_t)n * 8, false);
     unsigned long long* d_scan = (unsigned long long*)dalloc((size_t)n * 8, false);
     uint32_t* d_state = (uint32_t*)dalloc(8 * 4, false); // two {segments of the next level, next node id} pairs + the collapse's level counter
@@ -1139,7 +1515,18 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             const SahSegment* segs = d_segs[passes & 1u];
             const uint32_t* idx_in = d_idx[passes & 1u];
             uint32_t* idx_out = d_idx[(passes + 1u) & 1u];
-            if ((size_t)n_segs * 2048 <= (size_t)n) // runs of 2048 primitives and more on average
+            if (NEB_SAH_BIG && (size_t)n_segs * 2048 <= (size_t)n && n_segs <= kSahBigMaxSegs) {
+                // runs of 2048 primitives and more on average: slices of kSahSlice primitives, one workgroup each (a run shorter than a
+                // slice is one slice); at most n / kSahSlice + n_segs slices exist, blocks beyond the real count leave at once
+                const dim3 sg_grid(n / kSahSlice + n_segs);
+                hipLaunchKernelGGL(sah_big_index_kernel, dim3(1), dim3(1024), 0, stream, segs, n_segs, big);
+                hipLaunchKernelGGL(sah_big_bounds_kernel, sg_grid, dim3(256), 0, stream, N, segs, n_segs, idx_in, big);
+                hipLaunchKernelGGL(sah_big_bin_kernel, sg_grid, dim3(256), 0, stream, N, segs, n_segs, idx_in, big);
+                hipLaunchKernelGGL(sah_big_pick_kernel, dim3(n_segs), dim3(128), 0, stream, segs, n_segs, big, d_splits, d_picks);
+                hipLaunchKernelGGL(sah_big_count_kernel, sg_grid, dim3(256), 0, stream, N, segs, n_segs, idx_in, big, (const SahBigPick*)d_picks);
+                hipLaunchKernelGGL(sah_big_scan_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, stream, n_segs, big);
+                hipLaunchKernelGGL(sah_big_scatter_kernel, sg_grid, dim3(256), 0, stream, N, segs, n_segs, idx_in, idx_out, big, (const SahBigPick*)d_picks);
+            } else if ((size_t)n_segs * 2048 <= (size_t)n) // (A/B arm NEB_SAH_BIG=0, or more long runs than the slice index holds)
                 hipLaunchKernelGGL(sah_split_kernel<1024>, dim3(n_segs), dim3(1024), 0, stream, N, segs, idx_in, idx_out, d_splits);
             else
                 hipLaunchKernelGGL(sah_split_kernel<256>, dim3(n_segs), dim3(256), 0, stream, N, segs, idx_in, idx_out, d_splits);
@@ -1268,6 +1655,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     g->view.root = root_code;
     g->n_nodes = n_wide;
     g->bvh_depth = (uint32_t)max_depth;
+    g->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     g->sun_table_state = 0; // fresh shading records carry no sun-visibility flags yet
     g->built = true; // (h_tris stays: the scene can be rebuilt)
     return NEB_OK;
@@ -1297,6 +1685,14 @@ int neb_gi_build_passes(const neb_ctx* ctx, uint32_t* passes)
     if (!ctx || !ctx->gi || !passes)
         return NEB_ERR_STATE;
     *passes = ctx->gi->build_passes;
+    return NEB_OK;
+}
+
+int neb_gi_build_ms(const neb_ctx* ctx, float* ms)
+{
+    if (!ctx || !ctx->gi || !ms)
+        return NEB_ERR_STATE;
+    *ms = ctx->gi->build_ms;
     return NEB_OK;
 }
 

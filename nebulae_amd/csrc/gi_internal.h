@@ -152,6 +152,7 @@ struct GiState {
     std::vector<float> h_tris; // 12 floats per triangle
     float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
     uint32_t n_tris = 0, n_nodes = 0, bvh_depth = 0, build_passes = 0;
+    float build_ms = 0.f; // wall time of the last successful neb_gi_build_bvh
     size_t texture_table_bytes = 0; // footprint tables + material bundles on the device
     uint32_t max_bvh_depth = 21; // (kLdsStack + kSpillStack) / 3: deeper trees are refused by neb_gi_build_bvh ("gi_max_bvh_depth" lowers it)
     bool built = false;

@@ -99,6 +99,12 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_bvh_depth(self._ctx, C.byref(d)), "neb_gi_bvh_depth")
         return d.value
 
+    def build_ms(self):
+        """wall time (ms) of the last BVH build"""
+        d = C.c_float()
+        self._check(self._lib.neb_gi_build_ms(self._ctx, C.byref(d)), "neb_gi_build_ms")
+        return float(d.value)
+
     def build_passes(self):
         d = C.c_uint32()
         self._check(self._lib.neb_gi_build_passes(self._ctx, C.byref(d)), "neb_gi_build_passes")

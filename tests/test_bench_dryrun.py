@@ -91,6 +91,12 @@ class DryRuntime:
             def bvh_depth(self):
                 return 2
 
+            def build_ms(self):
+                return 0.0
+
+            def sun_table_stats(self):
+                return {"lit_plus": 0, "lit_minus": 0, "rays_answered": 0, "builds": 0}
+
             def _rows(self):
                 return self.svgf.row_begin, self.svgf.row_end
 

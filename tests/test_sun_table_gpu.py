@@ -163,6 +163,9 @@ def test_table_at_the_bench_size():
     on, off = _pair(W, H)
     off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
     off.svgf.set_option("gi_sun_table", 0)
+    # the tree of the one-workgroup-per-segment SAH build of rounds 2-3 (profiles/r03m_bench.json: 54 506 wide nodes, 14 levels):
+    # the first levels' splits, now spread over the chip in slices (sah_big_* kernels), must give the very same tree
+    assert off.scene_info() == (262244, 54506) and off.bvh_depth() == 14 and 0.0 < off.build_ms() < 200.0
     for f in (2, 3, 4):
         a, b = _frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f)
         _same(a, b)
