@@ -137,17 +137,32 @@ __device__ __forceinline__ uint64_t expand_bits21(uint64_t v)
 // key = Morton code of the centroid (axis_bits per axis) above the triangle index (index_bits): the index makes every
 // key unique, and the code gets all the bits the index leaves (15 per axis for 262 k triangles; on the bench scene
 // 10 / 12 / 15 bits traverse equally fast, denser scenes need the resolution)
-__global__ void lbvh_morton_kernel(const float* __restrict__ tris12, uint32_t n, float3 smin, float3 sinv, uint32_t axis_bits,
-                                   uint32_t index_bits, uint64_t* keys)
+// `boxes` (2 x float4 per reference, or null): lo.w != 0 marks the box of a PIECE of a split triangle (reference splitting, below);
+// every other reference takes the box of its triangle's vertices, computed here as it always was.
+__device__ __forceinline__ void reference_box(const float* t, const float4* boxes, uint32_t i, float3& lo, float3& hi)
+{
+    if (boxes && boxes[2 * i].w != 0.0f) {
+        const float4 l = boxes[2 * i], h = boxes[2 * i + 1];
+        lo = f3(l.x, l.y, l.z);
+        hi = f3(h.x, h.y, h.z);
+        return;
+    }
+    const float3 v0 = f3(t[0], t[1], t[2]), v1 = f3(t[0] + t[3], t[1] + t[4], t[2] + t[5]), v2 = f3(t[0] + t[6], t[1] + t[7], t[2] + t[8]);
+    lo = f3(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
+    hi = f3(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
+}
+
+__global__ void lbvh_morton_kernel(const float* __restrict__ tris12, const float4* __restrict__ boxes, uint32_t n, float3 smin, float3 sinv,
+                                   uint32_t axis_bits, uint32_t index_bits, uint64_t* keys)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const float* t = tris12 + 12 * (size_t)i;
-    const float3 v0 = f3(t[0], t[1], t[2]), v1 = f3(t[0] + t[3], t[1] + t[4], t[2] + t[5]), v2 = f3(t[0] + t[6], t[1] + t[7], t[2] + t[8]);
-    const float cx = (fminf(v0.x, fminf(v1.x, v2.x)) + fmaxf(v0.x, fmaxf(v1.x, v2.x))) * 0.5f;
-    const float cy = (fminf(v0.y, fminf(v1.y, v2.y)) + fmaxf(v0.y, fmaxf(v1.y, v2.y))) * 0.5f;
-    const float cz = (fminf(v0.z, fminf(v1.z, v2.z)) + fmaxf(v0.z, fmaxf(v1.z, v2.z))) * 0.5f;
+    float3 blo, bhi;
+    reference_box(tris12 + 12 * (size_t)i, boxes, i, blo, bhi);
+    const float cx = (blo.x + bhi.x) * 0.5f;
+    const float cy = (blo.y + bhi.y) * 0.5f;
+    const float cz = (blo.z + bhi.z) * 0.5f;
     const float cells = (float)(1u << axis_bits), top = cells - 1.0f;
     const uint64_t qx = (uint64_t)fminf(fmaxf((cx - smin.x) * sinv.x * cells, 0.0f), top);
     const uint64_t qy = (uint64_t)fminf(fmaxf((cy - smin.y) * sinv.y * cells, 0.0f), top);
@@ -156,16 +171,21 @@ __global__ void lbvh_morton_kernel(const float* __restrict__ tris12, uint32_t n,
     keys[i] = (m << index_bits) | i;
 }
 
-__global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const uint64_t* __restrict__ keys, uint32_t n, uint64_t index_mask,
-                                   float4* out)
+__global__ void lbvh_gather_kernel(const float* __restrict__ tris12, const float4* __restrict__ boxes, const uint64_t* __restrict__ keys, uint32_t n,
+                                   uint64_t index_mask, float4* out, float4* boxes_out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const float* t = tris12 + 12 * (size_t)(keys[i] & index_mask);
+    const size_t src = (size_t)(keys[i] & index_mask);
+    const float* t = tris12 + 12 * src;
     out[3 * i] = make_float4(t[0], t[1], t[2], t[3]);
     out[3 * i + 1] = make_float4(t[4], t[5], t[6], t[7]);
     out[3 * i + 2] = make_float4(t[8], t[9], t[10], t[11]);
+    if (boxes) {
+        boxes_out[2 * i] = boxes[2 * src];
+        boxes_out[2 * i + 1] = boxes[2 * src + 1];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,15 +227,15 @@ struct SahSplit { // result of one segment's split
     float lbox[6], rbox[6];
 };
 
-__global__ void sah_init_kernel(const float4* __restrict__ tris, uint32_t n, BinaryNodes N, uint32_t* idx)
+__global__ void sah_init_kernel(const float4* __restrict__ tris, const float4* __restrict__ boxes, uint32_t n, BinaryNodes N, uint32_t* idx)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
-    const float3 v0 = f3(a.x, a.y, a.z), v1 = f3(a.x + a.w, a.y + b.x, a.z + b.y), v2 = f3(a.x + b.z, a.y + b.w, a.z + c.x);
-    N.lo[i] = make_float4(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)), __int_as_float(-1));
-    N.hi[i] = make_float4(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)), __int_as_float(-1));
+    float3 blo, bhi;
+    reference_box(reinterpret_cast<const float*>(tris + 3 * (size_t)i), boxes, i, blo, bhi);
+    N.lo[i] = make_float4(blo.x, blo.y, blo.z, __int_as_float(-1));
+    N.hi[i] = make_float4(bhi.x, bhi.y, bhi.z, __int_as_float(-1));
     N.size[i] = 1u;
     idx[i] = i;
 }
@@ -1369,6 +1389,195 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
     return NEB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reference splitting (round 4).  A triangle far larger than its neighbours -- a wall or floor strip that crosses the atrium, a beam
+// -- has a box that overlaps everything along its length, and a builder that sorts primitives by centroid can only put it high in
+// the tree, where every ray meets it (measured on the long-thin variant of the stand-in: 17.9 node visits per bounce ray against
+// 15.2).  The remedy of the split-BVH builders (Stich et al., "Spatial splits in bounding volume hierarchies", HPG 2009; as a
+// pre-pass: Ernst & Greiner's early split clipping, Karras & Aila 2013) is to let such a triangle appear in SEVERAL leaves, each
+// with the box of the piece of the triangle inside it: the triangle itself is never cut -- every copy is the whole triangle, tested
+// by the same arithmetic, so hits cannot change and no crack can open -- only its REFERENCES multiply.
+// Here, on the host, before the device build: references whose box area exceeds kSplitAreaFactor x the mean are halved along their
+// longest axis at the midpoint (largest first, until at most kSplitBudget x n extra references exist); a child's box is the
+// bounds of the triangle clipped to its half (Sutherland-Hodgman in double, rounded outwards).  A scene without such triangles
+// gets no extra reference and the very tree it had before (the stand-in, Cornell boxes, the helmet: asserted in the tests).
+// ------------------------------------------------------------------------------------------------
+#ifndef NEB_SPLIT_AREA_FACTOR
+#define NEB_SPLIT_AREA_FACTOR 16.0 // 0: no reference splitting (A/B arm).  Measured on the long-thin stand-in (profiles/r04_split_factors.txt),
+                                   // node visits per bounce ray / GI dispatch: off 17.9 / 580 us, 64: 17.5 / 581, 16: 16.2 / 575, 4: 16.5 / 574 (and the
+                                   // plain stand-in starts splitting its roof quads: 15.4 against 15.2, +4 % nodes).  At 16 the plain stand-in, the
+                                   // Cornell boxes and the helmet get no extra reference: their trees are the ones they always had.
+#endif
+constexpr double kSplitAreaFactor = NEB_SPLIT_AREA_FACTOR, kSplitBudget = 0.25;
+
+struct HostRef {
+    uint32_t tri;
+    float lo[3], hi[3];
+    bool clipped; // false: the whole triangle (the device computes its box from the vertices, as it always did)
+};
+
+static double half_area(const float lo[3], const float hi[3])
+{
+    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// bounds of triangle `t` (12 floats: v0, e1, e2, ...) clipped to the box [lo, hi]; false if nothing of it is inside
+static bool clipped_bounds(const float* t, const float lo[3], const float hi[3], float out_lo[3], float out_hi[3])
+{
+    double poly[16][3], tmp[16][3];
+    int n = 3;
+    for (int c = 0; c < 3; ++c) {
+        poly[0][c] = t[c];
+        poly[1][c] = (double)t[c] + t[3 + c];
+        poly[2][c] = (double)t[c] + t[6 + c];
+    }
+    for (int axis = 0; axis < 3 && n > 0; ++axis)
+        for (int side = 0; side < 2 && n > 0; ++side) {
+            const double plane = side == 0 ? (double)lo[axis] : (double)hi[axis], sgn = side == 0 ? 1.0 : -1.0;
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                const int j = (i + 1) % n;
+                const double di = sgn * (poly[i][axis] - plane), dj = sgn * (poly[j][axis] - plane);
+                if (di >= 0.0) {
+                    for (int c = 0; c < 3; ++c)
+                        tmp[m][c] = poly[i][c];
+                    ++m;
+                }
+                if ((di >= 0.0) != (dj >= 0.0)) {
+                    const double u = di / (di - dj);
+                    for (int c = 0; c < 3; ++c)
+                        tmp[m][c] = poly[i][c] + u * (poly[j][c] - poly[i][c]);
+                    tmp[m][axis] = plane;
+                    ++m;
+                }
+            }
+            n = m;
+            for (int i = 0; i < n; ++i)
+                for (int c = 0; c < 3; ++c)
+                    poly[i][c] = tmp[i][c];
+        }
+    if (n == 0)
+        return false;
+    for (int c = 0; c < 3; ++c) {
+        double mn = poly[0][c], mx = poly[0][c];
+        for (int i = 1; i < n; ++i) {
+            mn = std::min(mn, poly[i][c]);
+            mx = std::max(mx, poly[i][c]);
+        }
+        // outwards to float, and never beyond the box the piece was cut from
+        float fl = (float)mn, fh = (float)mx;
+        if ((double)fl > mn)
+            fl = std::nextafter(fl, -INFINITY);
+        if ((double)fh < mx)
+            fh = std::nextafter(fh, INFINITY);
+        out_lo[c] = std::max(fl, lo[c]);
+        out_hi[c] = std::min(fh, hi[c]);
+        if (out_lo[c] > out_hi[c])
+            out_lo[c] = out_hi[c] = 0.5f * (out_lo[c] + out_hi[c]);
+    }
+    return true;
+}
+
+// -> the references of the build, in triangle order (a split triangle's pieces follow one another); refs.size() == n_tris: no splits
+static void split_references(const std::vector<float>& tris12, std::vector<HostRef>& refs)
+{
+    const uint32_t n = (uint32_t)(tris12.size() / 12);
+    refs.resize(n);
+    double sum_area = 0.0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* t = &tris12[12 * (size_t)i];
+        HostRef& r = refs[i];
+        r.tri = i;
+        r.clipped = false;
+        for (int c = 0; c < 3; ++c) {
+            const float v0 = t[c], v1 = t[c] + t[3 + c], v2 = t[c] + t[6 + c];
+            r.lo[c] = std::min(v0, std::min(v1, v2));
+            r.hi[c] = std::max(v0, std::max(v1, v2));
+        }
+        sum_area += half_area(r.lo, r.hi);
+    }
+    if (kSplitAreaFactor <= 0.0 || n < 8)
+        return;
+    const double limit = kSplitAreaFactor * sum_area / n;
+    size_t budget = (size_t)(kSplitBudget * n);
+    // work list of the references above the limit, largest first (a heap of (area, index into `extra` or `refs`))
+    std::vector<std::pair<double, uint32_t>> heap;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double a = half_area(refs[i].lo, refs[i].hi);
+        if (a > limit)
+            heap.emplace_back(a, i);
+    }
+    if (heap.empty())
+        return;
+    std::make_heap(heap.begin(), heap.end());
+    std::vector<std::vector<HostRef>> pieces(n); // per split triangle: its current pieces
+    std::vector<std::pair<uint32_t, uint32_t>> where; // heap payload >= n: (triangle, piece index)
+    auto payload_ref = [&](uint32_t k) -> HostRef& { return k < n ? refs[k] : pieces[where[k - n].first][where[k - n].second]; };
+    while (!heap.empty() && budget > 0) {
+        std::pop_heap(heap.begin(), heap.end());
+        const uint32_t k = heap.back().second;
+        heap.pop_back();
+        HostRef cur = payload_ref(k);
+        int axis = 0;
+        for (int c = 1; c < 3; ++c)
+            if (cur.hi[c] - cur.lo[c] > cur.hi[axis] - cur.lo[axis])
+                axis = c;
+        const float mid = 0.5f * (cur.lo[axis] + cur.hi[axis]);
+        if (!(mid > cur.lo[axis] && mid < cur.hi[axis]))
+            continue; // cannot be halved any further
+        HostRef a = cur, b = cur;
+        float alo[3], ahi[3], blo[3], bhi[3];
+        for (int c = 0; c < 3; ++c)
+            alo[c] = blo[c] = cur.lo[c], ahi[c] = bhi[c] = cur.hi[c];
+        ahi[axis] = mid;
+        blo[axis] = mid;
+        const float* t = &tris12[12 * (size_t)cur.tri];
+        const bool ha = clipped_bounds(t, alo, ahi, a.lo, a.hi), hb = clipped_bounds(t, blo, bhi, b.lo, b.hi);
+        if (!ha || !hb)
+            continue; // (the triangle only touches one half: nothing to gain)
+        a.clipped = b.clipped = true;
+        std::vector<HostRef>& pc = pieces[cur.tri];
+        uint32_t ia, ib;
+        if (k < n) { // first split of this triangle: its two pieces replace the whole
+            pc.push_back(a);
+            pc.push_back(b);
+            ia = 0, ib = 1;
+        } else {
+            ia = where[k - n].second;
+            pc[ia] = a;
+            pc.push_back(b);
+            ib = (uint32_t)pc.size() - 1u;
+        }
+        --budget;
+        for (uint32_t which = 0; which < 2; ++which) {
+            const HostRef& r = which == 0 ? a : b;
+            const double area = half_area(r.lo, r.hi);
+            if (area > limit) {
+                uint32_t id;
+                if (which == 0 && k >= n) {
+                    id = k; // the slot of the piece that was split is reused by its first half
+                } else {
+                    where.emplace_back(cur.tri, which == 0 ? ia : ib);
+                    id = n + (uint32_t)where.size() - 1u;
+                }
+                heap.emplace_back(area, id);
+                std::push_heap(heap.begin(), heap.end());
+            }
+        }
+    }
+    std::vector<HostRef> out;
+    out.reserve(n + (size_t)(kSplitBudget * n) + 8);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (pieces[i].empty())
+            out.push_back(refs[i]);
+        else
+            for (const HostRef& r : pieces[i])
+                out.push_back(r);
+    }
+    refs.swap(out);
+}
+
 int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
 {
     if (!ctx)
@@ -1378,9 +1587,8 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_build_bvh: no scene (call neb_gi_set_scene first)");
     hipStream_t stream = (hipStream_t)stream_;
     GI_GUARD(ctx);
-    const uint32_t n = g->n_tris;
     const auto t_build0 = std::chrono::steady_clock::now(); // (the build ends with a stream synchronisation: wall time = device time + launches)
-    if (n == 0) { // empty scene: every ray misses
+    if (g->n_tris == 0) { // empty scene: every ray misses
         g->built = true;
         g->n_nodes = 0;
         g->bvh_depth = 0;
@@ -1392,6 +1600,24 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     // The whole build runs on the device: Morton keys -> radix sort -> binned-SAH splits level by level -> BVH4 collapse +
     // leaf-order triangle permutation -> shading records.  The host only reads back one counter per pass (segments / nodes of
     // the next level).
+    // The primitives of the build are REFERENCES: one per triangle, except that a triangle far larger than the rest is referenced
+    // by several pieces with clipped boxes (split_references above).  A reference carries a copy of its triangle.
+    std::vector<HostRef> refs;
+    split_references(g->h_tris, refs);
+    const uint32_t n = (uint32_t)refs.size();
+    const bool have_pieces = n != g->n_tris;
+    std::vector<float> h_refs;   // 12 floats per reference (the triangle), only when some triangle was split
+    std::vector<float> h_boxes;  // 2 x float4 per reference: {lo, flag}, {hi, 0}
+    if (have_pieces) {
+        h_refs.resize((size_t)n * 12);
+        h_boxes.resize((size_t)n * 8);
+        for (uint32_t i = 0; i < n; ++i) {
+            memcpy(&h_refs[12 * (size_t)i], &g->h_tris[12 * (size_t)refs[i].tri], 48);
+            float* b = &h_boxes[8 * (size_t)i];
+            b[0] = refs[i].lo[0], b[1] = refs[i].lo[1], b[2] = refs[i].lo[2], b[3] = refs[i].clipped ? 1.0f : 0.0f;
+            b[4] = refs[i].hi[0], b[5] = refs[i].hi[1], b[6] = refs[i].hi[2], b[7] = 0.0f;
+        }
+    }
     std::vector<void*> temps, fresh; // freed at the end / device arrays that outlive the build (freed again on failure)
     bool oom = false;
     auto dalloc = [&](size_t bytes, bool keep) -> void* {
@@ -1411,6 +1637,8 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     const size_t n2 = 2 * (size_t)n;
     float* d_tris12 = (float*)dalloc((size_t)n * 48, false);
     float4* d_sorted = (float4*)dalloc((size_t)n * 48, false); // Morton order
+    float4* d_boxes = have_pieces ? (float4*)dalloc((size_t)n * 32, false) : nullptr;        // per reference, input order
+    float4* d_boxes_sorted = have_pieces ? (float4*)dalloc((size_t)n * 32, false) : nullptr; // ... Morton order
     float4* d_final = (float4*)dalloc((size_t)n * 48, true);   // leaf order of the final tree
     uint64_t* d_keys = (uint64_t*)dalloc((size_t)n * 8, false);
     uint64_t* d_keys2 = (uint64_t*)dalloc((size_t)n * 8, false);
@@ -1467,7 +1695,9 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             return bail(NEB_ERR_HIP, #call, e_);          \
     } while (0)
     // ---- Morton order ----
-    BUILD_HIP(hipMemcpyAsync(d_tris12, g->h_tris.data(), (size_t)n * 48, hipMemcpyHostToDevice, stream));
+    BUILD_HIP(hipMemcpyAsync(d_tris12, have_pieces ? h_refs.data() : g->h_tris.data(), (size_t)n * 48, hipMemcpyHostToDevice, stream));
+    if (have_pieces)
+        BUILD_HIP(hipMemcpyAsync(d_boxes, h_boxes.data(), (size_t)n * 32, hipMemcpyHostToDevice, stream));
     const float3 smin = make_float3(g->scene_min[0], g->scene_min[1], g->scene_min[2]);
     // (per-axis normalisation: cubic cells -- all axes scaled by the longest extent -- traversed 12 % slower on the bench scene)
     const float3 sinv = make_float3(1.0f / fmaxf(g->scene_max[0] - g->scene_min[0], 1e-20f), 1.0f / fmaxf(g->scene_max[1] - g->scene_min[1], 1e-20f),
@@ -1481,13 +1711,14 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
 #else
     const uint32_t axis_bits = (64 - index_bits) / 3 < 21 ? (64 - index_bits) / 3 : 21;
 #endif
-    hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, n, smin, sinv, axis_bits, index_bits, d_keys);
+    hipLaunchKernelGGL(lbvh_morton_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, (const float4*)d_boxes, n, smin, sinv, axis_bits, index_bits, d_keys);
     BUILD_HIP(hipGetLastError());
     BUILD_HIP(rocprim::radix_sort_keys(d_cub, cub_bytes, d_keys, d_keys2, (size_t)n, 0u, 64u, stream));
-    hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, d_keys2, n, (1ull << index_bits) - 1ull, d_sorted);
+    hipLaunchKernelGGL(lbvh_gather_kernel, dim3(nb), dim3(256), 0, stream, d_tris12, (const float4*)d_boxes, d_keys2, n, (1ull << index_bits) - 1ull, d_sorted,
+                       d_boxes_sorted);
     BUILD_HIP(hipGetLastError());
     // ---- binary topology: binned SAH, one level per pass ----
-    hipLaunchKernelGGL(sah_init_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)d_sorted, n, N, d_idx[0]);
+    hipLaunchKernelGGL(sah_init_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)d_sorted, (const float4*)d_boxes_sorted, n, N, d_idx[0]);
     BUILD_HIP(hipGetLastError());
     uint32_t passes = 0;
     const uint32_t root_node = n; // (only meaningful when n > kMaxLeafTris)
@@ -1648,6 +1879,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
             }
     }
     g->allocs.insert(g->allocs.end(), fresh.begin(), fresh.end());
+    g->view.n_tris = n; // references: the length of the triangle and shading-record arrays (g->n_tris stays the scene's triangle count)
     g->view.tris = d_final;
     g->view.shade = d_shade;
     g->view.nodes = d_wide;
@@ -1667,7 +1899,7 @@ int neb_gi_scene_bytes(const neb_ctx* ctx, uint64_t out[3])
         return NEB_ERR_STATE;
     const neb::GiState* g = ctx->gi;
     out[0] = g->texture_table_bytes;
-    out[1] = g->built ? (uint64_t)g->n_tris * (48 + 128) : 0;
+    out[1] = g->built ? (uint64_t)g->view.n_tris * (48 + 128) : 0;
     out[2] = (uint64_t)g->n_nodes * (sizeof(neb::Bvh4Node) + sizeof(neb::Bvh4NodeQ));
     return NEB_OK;
 }

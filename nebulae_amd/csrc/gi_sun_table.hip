@@ -224,13 +224,13 @@ __global__ void sun_table_clear_kernel(float4* shade, uint32_t n)
 // Brings the table in the shading records up to date with (scene, sun) -- or clears it when the option is off.  Enqueue only.
 hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream)
 {
-    if (!g->built || g->n_tris == 0 || !g->view.shade)
+    if (!g->built || g->view.n_tris == 0 || !g->view.shade)
         return hipSuccess;
     const float key[4] = {c.sunLightDirection[0], c.sunLightDirection[1], c.sunLightDirection[2], c.sunTanHalfAngle};
     const bool want = g->sun_table;
     if (!want) {
         if (g->sun_table_state != 0) {
-            hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->n_tris);
+            hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->view.n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->view.n_tris);
             g->sun_table_state = 0;
         }
         return hipGetLastError();
@@ -251,7 +251,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     const float dd = key[0] * key[0] + key[1] * key[1] + key[2] * key[2];
     if (!(dd > 0.0f) || !(dd < 1e30f) || !(key[3] >= 0.0f) || !(key[3] < 1.0f)) { // no usable sun: no certificate, every ray is traced
         if (g->sun_table_state != 0)
-            hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->n_tris);
+            hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->view.n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->view.n_tris);
         g->sun_table_state = 0;
         return hipGetLastError();
     }
@@ -278,7 +278,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     a.scene_hmax = hmax + 1e-3;
     a.shade = const_cast<float4*>(g->view.shade);
     a.counts = g->d_sun_counts;
-    hipLaunchKernelGGL(sun_table_kernel, dim3((g->n_tris + 63) / 64), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(sun_table_kernel, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
     memcpy(g->sun_table_key, key, sizeof(key));
     g->sun_table_state = 1;
     g->sun_table_builds++;

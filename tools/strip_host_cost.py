@@ -14,12 +14,14 @@ from nebulae_amd.renderer import RenderInfo  # noqa: E402
 from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE  # noqa: E402
 
 sc, cam = S.atrium_standin(), S.sponza_camera()
+MODES = [int(m) for m in os.environ.get("NEB_SUN_TABLE_MODES", "1").split(",")]  # "gi_sun_table": 1 table + ray lists, 2 table + tiled / sorted pass, 0 off
 for N in (8, 8, 4, 2):  # (the first configuration also pays the process's one-time costs: listed twice)
-    for scheme in ("once", "per_level"):
+    for scheme, mode in [(sch, m) for sch in ("once", "per_level") for m in MODES]:
         part = strips.StripPartition(1920, 1080, N, 5, scheme=scheme)
         r = strips.StripRenderer(part, N // 2)
         r._swap_rows_begin = lambda planes, plan: (lambda: None)  # no peers here
         r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+        r.svgf.set_option("gi_sun_table", mode)
         r.submit_commands_gbuffer()
         torch.cuda.synchronize()
         for pl in (PLANE_NORMAL, PLANE_DEPTH):  # static camera: both slots hold the G-buffer
@@ -44,5 +46,5 @@ for N in (8, 8, 4, 2):  # (the first configuration also pays the process's one-t
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print(f"N = {N} ({part.H // N} rows), scheme {scheme}: host submits a frame in {(t1 - t0) / n * 1e6:.0f} us; wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
+        print(f"N = {N} ({part.H // N} rows), scheme {scheme}, gi_sun_table {mode}: host submits a frame in {(t1 - t0) / n * 1e6:.0f} us; wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
         r.destroy()
