@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
     size_t i;
     const bool active = gi_pixel<kRaygenRuns>(a, x, y, i);
     uint32_t rays = 0;
+    uint32_t wave_stamp[5] = {0u, 0u, 0u, 0u, 0u}; // diagnostics (a.stats): the closest-hit loop's wave stamps, see Hit
     if (active) {
         const float3 albedo = unpack_r11g11b10(a.albedo[i]);
         const uint2 wp = a.world_pos[i];
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
             a.R.state[i] = make_float4(V.x, V.y, V.z, __uint_as_float(rng));
         float4 h = make_float4(bounce ? -1.0f : -2.0f, 0.f, 0.f, 0.f); // -2: no bounce at all, nothing is added
         rays = bounce ? 1u : 0u;
+        wave_stamp[0] = wave_stamp[1] = wave_stamp[2] = wave_stamp[3] = wave_stamp[4] = 0u;
         if (a.bsort_keys) {
             a.bsort_keys[i] = bounce ? bounce_sort_key(org, dir, a.smin, a.sinv) : (1u << kSortBits) - 1u;
             a.bsort_vals[i] = (uint32_t)i;
@@ -194,6 +196,8 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
             if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only
+                wave_stamp[0] = hit.w_iters, wave_stamp[1] = hit.w_node_iters, wave_stamp[2] = hit.w_node_lanes, wave_stamp[3] = hit.w_leaf_iters,
+                wave_stamp[4] = hit.w_leaf_lanes;
                 atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
                 atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
                 a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2)); // loop iterations of this ray
@@ -202,6 +206,19 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         a.R.hit[i] = h;
     }
     count_rays(a.bounce_counts, rays);
+    if (a.stats) { // the stamps are wave-uniform among the lanes that walked longest: the wave's totals are the maxima over its lanes
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint32_t v = wave_stamp[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                v = max(v, (uint32_t)__shfl_xor((int)v, off));
+            if (threadIdx.x == 0)
+                atomicAdd(a.ray_counter + 6 + k, (unsigned long long)v);
+        }
+        if (threadIdx.x == 0)
+            atomicAdd(a.ray_counter + 5, 1ull);
+    }
 }
 
 // Closest-hit traversal of the bounce rays of path vertices >= 2 (vertex 1 is fused into ray generation).
@@ -1090,7 +1107,7 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
         return ctx ? gi_fail(ctx, NEB_ERR_STATE, "neb_gi_ray_count: no scene") : NEB_ERR_INVALID_ARG;
     GiState* g = ctx->gi;
     GI_GUARD(ctx);
-    unsigned long long v[8] = {};
+    unsigned long long v[16] = {};
     std::vector<uint32_t> counts(3 * g->n_block_counts);
     GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (g->d_block_counts)
@@ -1121,6 +1138,15 @@ int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5])
         return NEB_ERR_INVALID_ARG;
     for (int k = 0; k < 5; ++k)
         out[k] = ctx->gi->last_stats[k];
+    return NEB_OK;
+}
+
+int neb_gi_wave_stats(neb_ctx* ctx, uint64_t out[6])
+{
+    if (!ctx || !ctx->gi || !out)
+        return NEB_ERR_INVALID_ARG;
+    for (int k = 0; k < 6; ++k)
+        out[k] = ctx->gi->last_stats[5 + k];
     return NEB_OK;
 }
 

@@ -1378,7 +1378,7 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: upload", e);
     }
     void* ctr = nullptr;
-    if ((e = hipMalloc(&ctr, 8 * sizeof(unsigned long long))) != hipSuccess || (e = hipMemset(ctr, 0, 8 * sizeof(unsigned long long))) != hipSuccess) {
+    if ((e = hipMalloc(&ctr, 16 * sizeof(unsigned long long))) != hipSuccess || (e = hipMemset(ctr, 0, 16 * sizeof(unsigned long long))) != hipSuccess) {
         gi_destroy(g);
         return gi_fail(ctx, NEB_ERR_HIP, "neb_gi_set_scene: counter", e);
     }

@@ -217,6 +217,9 @@ struct Hit {
     float t, u, v;
     uint32_t tri;
     uint32_t node_visits, tri_tests; // traversal statistics (neb_gi_traversal_stats)
+    // wave stamps (STATS builds of the loop only; the same value in every lane that is still walking): iterations of the loop,
+    // iterations that ran a node phase / a leaf phase, and the lanes that were live in them (neb_gi_wave_stats)
+    uint32_t w_iters, w_node_iters, w_node_lanes, w_leaf_iters, w_leaf_lanes;
 };
 
 // Moeller-Trumbore in the operation order of oracle/trace_ref.cpp.  Before the oracle's own tests run, the undivided
@@ -321,6 +324,12 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
     const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
     constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
+        if (STATS) {
+            const uint32_t nn = (uint32_t)__popcll(__ballot(node >= 0));
+            hit.w_iters++;
+            hit.w_node_iters += nn ? 1u : 0u;
+            hit.w_node_lanes += nn;
+        }
         if (node >= 0) {
             if (STATS)
                 hit.node_visits++;
@@ -399,6 +408,11 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
         bool run_leaves = true;
         if (ANY_HIT && kLeafBatch > 1)
             run_leaves = __popcll(__ballot(holds_leaf)) >= kLeafBatch || __ballot(node >= 0) == 0ull;
+        if (STATS) {
+            const uint32_t nl = (uint32_t)__popcll(__ballot(holds_leaf && run_leaves));
+            hit.w_leaf_iters += nl ? 1u : 0u;
+            hit.w_leaf_lanes += nl;
+        }
         if (holds_leaf && run_leaves) {
             const uint32_t code = (uint32_t)~node;
             const uint32_t first = code >> 2, count = (code & 3u) + 1u;
@@ -444,6 +458,7 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     hit.t = tmax;
     hit.tri = ~0u;
     hit.node_visits = hit.tri_tests = 0;
+    hit.w_iters = hit.w_node_iters = hit.w_node_lanes = hit.w_leaf_iters = hit.w_leaf_lanes = 0;
     if (S.n_tris == 0)
         return false;
     bool found = false;

@@ -160,7 +160,7 @@ struct GiState {
     neb_gi_hit* d_hits = nullptr;
     bool debug_hits = false;
     float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
-    unsigned long long last_stats[8] = {};
+    unsigned long long last_stats[16] = {};
     bool defer_resolve = false;
     bool exact_shade = false; // "gi_exact_shade": gi_shade_kernel<false>, the oracle's C arithmetic
     bool sort_shadow = true;  // "gi_sort_rays" bit 0

@@ -204,6 +204,12 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_traversal_stats(self._ctx, v), "neb_gi_traversal_stats")
         return dict(zip(("rays", "bounce_nodes", "bounce_tris", "shadow_nodes", "shadow_tris"), [int(x) for x in v]))
 
+    def wave_stats(self):
+        """closest-hit pass, as of the last ray_count() with debug hits on: where its waves' loop iterations go"""
+        v = (C.c_uint64 * 6)()
+        self._check(self._lib.neb_gi_wave_stats(self._ctx, v), "neb_gi_wave_stats")
+        return dict(zip(("waves", "iterations", "node_iterations", "node_lanes", "leaf_iterations", "leaf_lanes"), [int(x) for x in v]))
+
     def sun_table_stats(self):
         """{sides proven lit (+normal side / -normal side), shadow rays the table answered as of the last ray_count(), builds}"""
         v = (C.c_uint64 * 4)()
