@@ -1,22 +1,28 @@
-// gi_sun_table.hip -- the sun-visibility table: which (triangle, side) pairs are PROVABLY lit by the whole sun disk.
+// gi_sun_table.hip -- the sun table: what can be known about a triangle's shadow rays before any of them is traced.
 //
 // Every shadow ray of the GI path points at the sun disk (assets/shaders/pathtracer.hlsl:533-575): it leaves the hit point by
-// GN * 1e-2 on the side the disk sample is on and goes along normalize(L + offset), |offset| <= tan(0.29 deg).  32 % of them end
-// unoccluded -- the expensive ones for an any-hit walk, which has no early exit to offer them -- and 95 % of those start on
-// a triangle from which NOTHING of the scene can be met by ANY ray of that family: a sunlit floor, the outer side of a roof.
-// That is a property of the triangle, the scene and the sun alone, so it is decided once per sun position: one thread per
-// triangle walks the BVH4 (the exact 128-byte nodes) for everything that reaches into the column its rays can sweep -- the
-// triangle's footprint along the sun direction, widened by tan(half angle) per unit climbed -- and asks the certificate of
-// lit_predicate.h (double precision, conservative: "cannot occlude" is certain) about every triangle found there, itself included.
-// Two bits per triangle land in the spare top bits of the geometry word of its 128-byte shading record, which gi_shade_kernel
-// has in registers anyway: a proven-lit ray costs no traversal, no sort slot worth of work and not one extra byte of traffic.
-// The answer is the traversal's own by construction (tests/test_gi_gpu.py: flags and radiance bit-identical with the table on
-// and off, every GI scene and the bench frame).  Rebuilt (a few ms) when sunLightDirection / sunTanHalfAngle change or the
-// scene is rebuilt -- the reference marks such a frame dynamic anyway (src/DeferredRenderer.cpp:169-171).
+// GN * 1e-2 on the side the disk sample is on and goes along normalize(L + offset), |offset| <= tan(0.29 deg).  Whether such a ray
+// can meet anything is to a large extent a property of the TRIANGLE it starts on, the scene and the sun -- so it is decided once
+// per sun position, one thread per triangle, which walks the BVH4 (the exact 128-byte nodes) for everything that reaches into the
+// column the triangle's rays can sweep (its footprint along the sun direction, widened by tan(half angle) per unit climbed):
+//   * LIT BITS (one per side): set when the certificate of lit_predicate.h (double precision, conservative: "cannot occlude" is
+//     certain) holds for every triangle found there, the receiver itself included.  On the bench frame 95 % of the unoccluded
+//     shadow rays start on such a (triangle, side).
+//   * OCCLUDER HINTS (up to four): the triangles that together shadow most of the receiver (greedy cover over 28 sample origins).
+//     gi_shade_kernel tries them with the traverser's own triangle test on the very ray -- a hit is the any-hit traversal's hit,
+//     exactly, by construction.  90 % of the occluded shadow rays end at a hint.
+// Both live in the spare bits / last 12 bytes of the triangle's 128-byte shading record, which gi_shade_kernel has in LDS anyway:
+// not one extra byte of traffic for the flags, 48 bytes per hint tried.  The answer is the traversal's own
+// (tests/test_sun_table_gpu.py: radiance, hit records and sun-visibility flags bit-identical with the table on and off, every GI scene
+// and the bench frame).  Rebuilt (15 ms at 262 k triangles) when sunLightDirection / sunTanHalfAngle have changed AND held for two
+// dispatches, or the scene is rebuilt; a sun that moves every frame -- the reference marks such frames dynamic,
+// src/DeferredRenderer.cpp:169-171 -- is traced the plain way meanwhile.
 //
-// This takes the place of the sun-space height map sized in round 3: a height map has to resolve the 1e-2 ray
-// offset against the slope of every lit surface (a 4096^2 map for a floor, and a max-plus filter for the cone), costs a
-// scattered fetch per ray, and is only as exact as its cells; the per-triangle certificate uses the exact geometry.
+// This takes the place of the sun-space height map sized in round 3: a height map has to resolve the 1e-2 ray offset against the
+// slope of every lit surface (a 4096^2 map for a floor, and a max-plus filter for the cone), costs a scattered fetch per ray, is only
+// as exact as its cells, and says nothing about the occluded rays; the per-triangle form uses the exact geometry.
+// (What the lit bits alone are worth: 8 us -- the unoccluded rays of an open court leave the tree after 3 node visits on average;
+// the hints and the compaction of what is left, gi.hip, are the other 77.)
 #include "gi_device.h"
 #include "lit_predicate.h"
 
