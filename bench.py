@@ -619,10 +619,17 @@ def main(argv=None, rt=None, emit=None):
     # which the SVGF chain is bracketed by ONE pair (every event is a packet of its own between two launches).  One GPU: the
     # chain is the library's own (temporal pass fused into level 0) and the per-kernel marks are its own events on the
     # launch stream (option svgf_profile -> neb_svgf_level_times); N > 1: the strip renderer's per-level events. ----
+    def avg(v):
+        """average over the profiled frames, without the one largest and the one smallest value (a frame in ~100 runs 150 us long
+        on these boxes, whatever it is made of: among 16 samples one such frame moved a plain mean by 10 us)"""
+        v = sorted(float(x) for x in v)
+        return float(np.mean(v[1:-1] if len(v) > 4 else v))
+
+    NPROF = 16
     ev, ev2, lt = [], [], []
     if world == 1:
         r.svgf.set_option("svgf_profile", 1)
-    for _ in range(8):
+    for _ in range(NPROF):
         e = {k: rt.event() for k in ("gi0", "gi1", "t0", "t1", "a1")}
         e["levels"] = [(rt.event(), rt.event()) for _ in range(L)]
         w.step(e)
@@ -631,7 +638,7 @@ def main(argv=None, rt=None, emit=None):
         ev.append(e)
     if world == 1:
         r.svgf.set_option("svgf_profile", 0)
-    for _ in range(8):
+    for _ in range(NPROF):
         e = {k: rt.event() for k in ("gi0", "gi1", "t0", "t1", "a1")}
         w.step(e)
         ev2.append(e)
@@ -639,30 +646,32 @@ def main(argv=None, rt=None, emit=None):
     lt2 = []
     if world == 1:
         r.svgf.set_option("svgf_profile", 2)
-        for _ in range(8):
+        for _ in range(NPROF):
             w.step()
             lt2.append(r.svgf.level_times())
         r.svgf.set_option("svgf_profile", 0)
     rt.synchronize()
-    rays_ev = (r.ray_count(reset=True) if do_gi else 0) // (3 if world == 1 else 2)  # (batches of 8 frames)
-    t_gi = float(np.mean([e["gi0"].elapsed_time(e["gi1"]) for e in ev])) * 1e-3
+    rays_ev = (r.ray_count(reset=True) if do_gi else 0) // (3 if world == 1 else 2)  # (batches of NPROF frames)
+    t_gi = avg([e["gi0"].elapsed_time(e["gi1"]) for e in ev]) * 1e-3
     fused = bracketed = False
+    atrous_samples = None
     if world == 1:
-        per_level = [float(np.mean([x[i] for x in lt])) * 1e-6 for i in range(L)]
-        t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev2])) * 1e-3
+        per_level = [avg([x[i] for x in lt]) * 1e-6 for i in range(L)]
+        t_temporal = avg([e["t0"].elapsed_time(e["t1"]) for e in ev2]) * 1e-3
         fused = w.fused_chain
         if fused:
             t_temporal = 0.0  # (the held-back call: the pass runs inside level 0's kernel)
-        t_svgf_chain = float(np.mean([e["t0"].elapsed_time(e["a1"]) for e in ev2])) * 1e-3  # temporal + all levels, two events
+        t_svgf_chain = avg([e["t0"].elapsed_time(e["a1"]) for e in ev2]) * 1e-3  # temporal + all levels, two events
         # the roofline's kernel = a pure a-trous level (levels 1.. of the fused chain; every level otherwise)
         pure = per_level[1:] if (fused and L > 1) else per_level
         t_atrous = float(np.mean(pure)) if pure else 0.0
         bracketed = fused and L > 1 and all(len(x) == 2 for x in lt2)
         if bracketed:  # average launch duration over the L - 1 pure levels, timed as one interval
-            t_atrous = float(np.mean([x[1] for x in lt2])) * 1e-6 / (L - 1)
+            t_atrous = avg([x[1] for x in lt2]) * 1e-6 / (L - 1)
+            atrous_samples = [round(float(x[1]) / (L - 1), 2) for x in lt2]
     else:
-        t_temporal = float(np.mean([e["t0"].elapsed_time(e["t1"]) for e in ev])) * 1e-3
-        per_level = [float(np.mean([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev])) * 1e-3 for i in range(L)]
+        t_temporal = avg([e["t0"].elapsed_time(e["t1"]) for e in ev]) * 1e-3
+        per_level = [avg([e["levels"][i][0].elapsed_time(e["levels"][i][1]) for e in ev]) * 1e-3 for i in range(L)]
         # (with N > 1 the first level's interval also holds the halo exchange it overlaps with, and every level but the last
         # filters a few extra rows: the roofline line is then taken over the levels after the first)
         t_atrous = float(np.mean(per_level if L == 1 else per_level[1:]))
@@ -721,7 +730,7 @@ def main(argv=None, rt=None, emit=None):
                        "scene_device_bytes": scene_bytes, "bvh": bvh, "library_build_id": library_build_id()},
             "frames_per_s_with_final_gather": fps_with_gather,
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
-            "gi_kernel_mrays_per_s": (rays_ev / 8 / t_gi / 1e6) if do_gi else None,
+            "gi_kernel_mrays_per_s": (rays_ev / NPROF / t_gi / 1e6) if do_gi else None,
             "weak_scaling": weak,
             "config5": config5,
             "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": None if fused else t_temporal * 1e6,
@@ -735,6 +744,8 @@ def main(argv=None, rt=None, emit=None):
                                     if fused else "svgf_atrous_lds_kernel (mean over the levels of a frame)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": ATROUS_BYTES_PX * own_px,
+                         # the per-frame samples behind `achieved` (us per pure level; the average leaves out the largest and the smallest)
+                         "launch_us_samples": atrous_samples,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
                          # the contract prices this kernel against HBM; what binds it in fact is instruction issue
                          "limiter": "VALU issue: 25 taps x (12 three-operand instructions + v_log + v_exp) per pixel" if valu else None, "valu": valu},
