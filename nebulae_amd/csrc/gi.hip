@@ -109,6 +109,9 @@ __device__ __forceinline__ uint32_t gi_block()
 }
 constexpr uint32_t kShadeRuns = 16u, kRaygenRuns = 16u;
 constexpr uint32_t kListSegments = 128u;
+#ifndef NEB_TAIL_STAMPS
+#define NEB_TAIL_STAMPS 0
+#endif
 #ifndef NEB_LIST_WAVES
 #define NEB_LIST_WAVES 6 // waves per SIMD it is register-budgeted for (it is bound by latency, not by occupancy)
 #endif
@@ -581,11 +584,18 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
 // leave; with the tree warm in cache 52 instead of 56; two nodes per step 68).  So: a fixed grid, workgroup b takes chunks
 // b / kListSegments, + kListChunks, ... of list b % kListSegments -- one counter read, no scan -- and a ray comes out of its list slot
 // whole (64 bytes, consecutive slots: no gather through a pixel index).
+#if NEB_TAIL_STAMPS // diagnostics build: per wave {start, end (s_memrealtime, 100 MHz), rays, max node visits}
+__device__ unsigned long long g_tail_stamps[8192 * 4];
+#endif
 constexpr uint32_t kListChunks = 64u; // chunks of 64 rays per list taken in parallel: kListSegments x kListChunks = 8192 waves = the chip's wave slots
 __global__ __launch_bounds__(64, NEB_LIST_WAVES) void gi_shadow_list_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
     const uint32_t lane = threadIdx.x;
+#if NEB_TAIL_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    uint32_t st_rays = 0, st_visits = 0;
+#endif
     const uint32_t seg = blockIdx.x % kListSegments, chunks = gridDim.x / kListSegments;
     const uint32_t count = a.list_counts[a.list_set * kListSegments + seg];
     if (blockIdx.x == 0) // the other set of counters is idle until the next shade launch fills it: clear it for that launch
@@ -603,7 +613,13 @@ __global__ __launch_bounds__(64, NEB_LIST_WAVES) void gi_shadow_list_kernel(GiAr
         float4 sum = rec[kSrSum];
         const size_t i = __float_as_uint(ro.w);
         Hit sh;
+#if NEB_TAIL_STAMPS
+        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, true);
+        st_rays += 1;
+        st_visits = max(st_visits, sh.node_visits);
+#else
         const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, a.stats != 0);
+#endif
         if (a.stats) { // diagnostics only
             if (a.hits && a.bounce == 1)
                 a.hits[i].flags |= min(sh.node_visits, 4095u) << 20;
@@ -631,7 +647,32 @@ __global__ __launch_bounds__(64, NEB_LIST_WAVES) void gi_shadow_list_kernel(GiAr
             a.R.srec[4 * i + kSrSum] = sum;
         }
     }
+#if NEB_TAIL_STAMPS
+    {
+        uint32_t r = st_rays, v = st_visits;
+        for (int off = 32; off > 0; off >>= 1) {
+            r += (uint32_t)__shfl_xor((int)r, off);
+            v = max(v, (uint32_t)__shfl_xor((int)v, off));
+        }
+        if (lane == 0 && blockIdx.x < 8192u) {
+            g_tail_stamps[4 * blockIdx.x + 0] = t_start;
+            g_tail_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            g_tail_stamps[4 * blockIdx.x + 2] = r;
+            g_tail_stamps[4 * blockIdx.x + 3] = v;
+        }
+    }
+#endif
 }
+
+#if NEB_TAIL_STAMPS
+} // namespace neb
+extern "C" int neb_debug_tail_stamps(unsigned long long* host)
+{
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(neb::g_tail_stamps), sizeof(neb::g_tail_stamps)) == hipSuccess ? 0 : -1;
+}
+namespace neb {
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // G-buffer producer ("next" row f2): primary visibility through the same BVH
