@@ -112,6 +112,9 @@ constexpr uint32_t kListSegments = 128u;
 #ifndef NEB_TAIL_STAMPS
 #define NEB_TAIL_STAMPS 0
 #endif
+#ifndef NEB_LIST_QUAD_BELOW
+#define NEB_LIST_QUAD_BELOW 1500000u // dispatches of fewer pixels walk their ray lists with four lanes per ray (row strips; a 1080p frame does not)
+#endif
 #ifndef NEB_LIST_WAVES
 #define NEB_LIST_WAVES 6 // waves per SIMD it is register-budgeted for (it is bound by latency, not by occupancy)
 #endif
@@ -588,6 +591,13 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_shadow_trace_kernel(Gi
 __device__ unsigned long long g_tail_stamps[8192 * 4];
 #endif
 constexpr uint32_t kListChunks = 64u; // chunks of 64 rays per list taken in parallel: kListSegments x kListChunks = 8192 waves = the chip's wave slots
+// QUAD: four lanes per ray (traverse_any_quad, gi_device.h), 16 rays per wave at a time.  Which one runs is a matter of how many rays there
+// are (measured, profiles/r04_tail_stamps.txt and tools/strip_host_cost.py): the 160 k rays a whole 1080p frame leaves put 2.5 one-lane-per-ray
+// waves on every SIMD, which is then bound by instruction issue -- four lanes per ray are four times the waves for the same ~23 M
+// wave-instructions: 57.6 us against 53.7.  The 20-80 k rays of a row strip leave most SIMDs with one wave or none, a wave is bound by
+// the length of its own dependent chain, and a quarter of the arithmetic per lane shortens it: a 135 / 270 / 540-row strip's frame
+// 212 / 278 / 404 us against 227 / 294 / 419.  Same results either way.
+template <bool QUAD>
 __global__ __launch_bounds__(64, NEB_LIST_WAVES) void gi_shadow_list_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kLdsStack * 64];
@@ -605,20 +615,33 @@ __global__ __launch_bounds__(64, NEB_LIST_WAVES) void gi_shadow_list_kernel(GiAr
     if (seg % NEB_TAIL_SKIP)
         return;
 #endif
-    for (uint32_t first = (blockIdx.x / kListSegments) * 64u; first < count; first += chunks * 64u) {
-        if (first + lane >= count)
+    static_assert(kLdsStack * 64 >= 16 * 64, "a quad's LDS column holds the whole 64-entry stack");
+    constexpr uint32_t kRaysPerWave = QUAD ? 16u : 64u;
+    const uint32_t slot = QUAD ? lane >> 2 : lane; // the ray of the wave's chunk this lane works on
+    for (uint32_t first = (blockIdx.x / kListSegments) * kRaysPerWave; first < count; first += chunks * kRaysPerWave) {
+        if (first + slot >= count)
             continue; // (the workgroup is this one wave: no barrier below)
-        const float4* rec = a.list + 4 * ((size_t)seg * a.list_cap + first + lane);
+        const float4* rec = a.list + 4 * ((size_t)seg * a.list_cap + first + slot);
         const float4 ro = rec[kSrO], rd = rec[kSrD], contrib = rec[kSrContrib];
         float4 sum = rec[kSrSum];
         const size_t i = __float_as_uint(ro.w);
         Hit sh;
+        bool occluded;
+        if constexpr (QUAD) {
+            occluded = a.stats ? traverse_any_quad<true>(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, stack_mem + slot, sh.node_visits, sh.tri_tests)
+                               : traverse_any_quad<false>(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, stack_mem + slot, sh.node_visits, sh.tri_tests);
+            if ((lane & 3u) != 0u)
+                continue; // the quad's first lane finishes the pixel
+        } else {
 #if NEB_TAIL_STAMPS
-        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, true);
+            occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, true);
+#else
+            occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, a.stats != 0);
+#endif
+        }
+#if NEB_TAIL_STAMPS
         st_rays += 1;
         st_visits = max(st_visits, sh.node_visits);
-#else
-        const bool occluded = traverse(a.S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), 0.001f, kTraceMax, true, stack_mem + lane, sh, a.stats != 0);
 #endif
         if (a.stats) { // diagnostics only
             if (a.hits && a.bounce == 1)
@@ -1033,10 +1056,10 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
             else
                 hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
             if (a.list) {
-                hipLaunchKernelGGL(gi_shadow_list_kernel, dim3(list_waves), block, 0, (hipStream_t)stream, a);
-#ifdef NEB_TAIL_TWICE // timing-only build (wrong results): the same launch again, now with the tree in cache
-                hipLaunchKernelGGL(gi_shadow_list_kernel, dim3(list_waves), block, 0, (hipStream_t)stream, a);
-#endif
+                if (a.n_px < NEB_LIST_QUAD_BELOW)
+                    hipLaunchKernelGGL(gi_shadow_list_kernel<true>, dim3(list_waves), block, 0, (hipStream_t)stream, a);
+                else
+                    hipLaunchKernelGGL(gi_shadow_list_kernel<false>, dim3(list_waves), block, 0, (hipStream_t)stream, a);
                 g->list_epoch++;
             } else if (sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the

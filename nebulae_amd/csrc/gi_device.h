@@ -474,6 +474,101 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     return found;
 }
 
+// Any-hit walk of ONE ray by FOUR lanes (a quad: lanes 4 k .. 4 k + 3), for the latency-bound tail (gi_shadow_list_kernel: the
+// few shadow rays the sun table leaves have the machine to themselves, and a lone wave is bound by the length of its dependent
+// instruction chain -- ~250 instructions per step of the one-lane-per-ray loop).  Lane q of the quad decodes and tests child q of
+// the BVH4 node (a quarter of the arithmetic; the node's 64 bytes are read by all four lanes: one line), the four verdicts meet in
+// a ballot, every lane of the quad keeps the same stack pointer and reads and writes the same LDS column; in a leaf
+// lanes 0 and 1 test its (up to) two triangles.  Same nodes, same box arithmetic (slab_key_t on the same plane distances), same
+// triangle test on the same operands, same visiting order as traverse_core<true, .>: the answer is the traversal's.
+// `stack`: this quad's LDS column -- entry k at stack[16 * k] -- 64 entries deep (the builder bounds the tree: 3 x 21 pending nodes).
+template <bool STATS>
+__device__ __forceinline__ bool traverse_any_quad(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* stack, uint32_t& node_visits,
+                                                  uint32_t& tri_tests)
+{
+    node_visits = tri_tests = 0;
+    if (S.n_tris == 0)
+        return false;
+    const float dd = dot3(d, d), oo = dot3(o, o);
+    if (!(dd > 0.0f && dd < __builtin_inff() && oo < __builtin_inff())) // (see traverse_t: such a ray does not start)
+        return false;
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qbase = lane & 60u;
+    const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
+    constexpr uint32_t kMiss = 0xffffffffu;
+    int node = S.root, sp = 0;
+    bool found = false;
+    auto push = [&](int v) { // (all four lanes store the same word: each lane's later read is ordered behind its OWN store, no cross-lane fence needed)
+        stack[16 * sp] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> int {
+        --sp;
+        return stack[16 * sp];
+    };
+    while (node != kTravDone) {
+        if (node >= 0) {
+            if (STATS)
+                node_visits++;
+            const char* nodes = reinterpret_cast<const char*>(S.qnodes);
+            const uint32_t nb = (uint32_t)node << 6;
+            const float4 p0 = *reinterpret_cast<const float4*>(nodes + nb);
+            const float4 p1 = *reinterpret_cast<const float4*>(nodes + (nb + 16u));
+            const uint4 p2 = *reinterpret_cast<const uint4*>(nodes + (nb + 32u));
+            const int4 ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
+            const float sx = p0.w * inv.x, sy = p1.x * inv.y, sz = p1.y * inv.z;
+            const float bx = fmaf(p0.x, inv.x, -oinv.x), by = fmaf(p0.y, inv.y, -oinv.y), bz = fmaf(p0.z, inv.z, -oinv.z);
+            const uint32_t lox = __float_as_uint(p1.z), loy = __float_as_uint(p1.w);
+            const uint32_t qnx = negx ? p2.y : lox, qfx = negx ? lox : p2.y;
+            const uint32_t qny = negy ? p2.z : loy, qfy = negy ? loy : p2.z;
+            const uint32_t qnz = negz ? p2.w : p2.x, qfz = negz ? p2.x : p2.w;
+            auto un = [&](uint32_t w) { return (float)((w >> (8u * q)) & 0xffu); };
+            const uint32_t key = slab_key_t(fmaf(un(qnx), sx, bx), fmaf(un(qny), sy, by), fmaf(un(qnz), sz, bz), fmaf(un(qfx), sx, bx),
+                                            fmaf(un(qfy), sy, by), fmaf(un(qfz), sz, bz), tmin, tmax, q);
+            const uint32_t m = (uint32_t)(__ballot(key != kMiss) >> qbase) & 0xfu; // bit c: child c of this quad's node is hit
+            // the order of traverse_core's any-hit branch: go on with the first hit child in slot order, stack the others
+            node = kTravDone;
+            if (m & 8u)
+                node = ch.w;
+            if (m & 4u) {
+                if (node != kTravDone)
+                    push(node);
+                node = ch.z;
+            }
+            if (m & 2u) {
+                if (node != kTravDone)
+                    push(node);
+                node = ch.y;
+            }
+            if (m & 1u) {
+                if (node != kTravDone)
+                    push(node);
+                node = ch.x;
+            }
+            if (node == kTravDone && sp)
+                node = pop();
+        }
+        if (node < 0 && node != kTravDone) {
+            const uint32_t code = (uint32_t)~node;
+            const uint32_t first = code >> 2, count = (code & 3u) + 1u;
+            if (STATS)
+                tri_tests += count;
+            // lanes 0 .. count - 1 take one triangle each (count <= kMaxLeafTris <= 4); the others repeat the last one
+            const uint32_t ti = first + min(q, count - 1u);
+            float t, u, v;
+            const bool h = intersect_tri(S.tris, ti, o, d, tmin, tmax, t, u, v);
+            if ((uint32_t)(__ballot(h) >> qbase) & 0xfu) {
+                found = true;
+                node = kTravDone;
+            } else {
+                node = sp ? pop() : kTravDone;
+            }
+        }
+    }
+    return found;
+}
+
 // `stats` (wave-uniform, diagnostics) selects the instantiation that also counts node visits and triangle tests.
 __device__ __forceinline__ bool traverse(const SceneView& S, float3 o, float3 d, float tmin, float tmax, bool any_hit, int* lds_stack,
                                          Hit& hit, bool stats = false)
