@@ -308,16 +308,20 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
             const float3 V = normalize3<FAST>(-dir); // :522
             uint32_t rng = __float_as_uint(pth.w);
             const float a0 = rand01(rng), a1 = rand01(rng);
-            const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<FAST>(a1);
+            // The GEOMETRY of the shadow ray -- the sun's frame, the disk sample, the direction -- is computed in the oracle's
+            // arithmetic under both policies (IEEE square root and division, det_sincosf): a visibility query is a discrete
+            // outcome, and a direction that differs in its last ulp (hardware rsq / sin / cos) flips about one query in eight
+            // million at a silhouette -- 5e-4 of a frame's L2 norm each time.  ~150 instructions per hit in a pass bound by
+            // memory; the BRDF and the surface reconstruction keep the 1-ulp hardware forms (no discrete outcome hangs on them).
+            const float angle = a0 * 2.0f * 3.1415926535f, dist = fsqrt<false>(a1);
             const float3 sun_dir = f3(a.c.sunLightDirection[0], a.c.sunLightDirection[1], a.c.sunLightDirection[2]);
             const float3 sun_rad = f3(a.c.sunLightRadiance[0], a.c.sunLightRadiance[1], a.c.sunLightRadiance[2]);
-            const float3 L = normalize3<FAST>(-sun_dir);
-            const float3 Bv = normalize3<FAST>(perpendicular(L));
+            const float3 L = normalize3<false>(-sun_dir);
+            const float3 Bv = normalize3<false>(perpendicular(L));
             const float3 T = cross3(Bv, L);
-            // (the disk offset is scaled by tan(0.29 deg) = 0.005: the ~1e-6 error of v_sin / v_cos moves the direction by
-            // less than an ulp, so the hardware forms are safe here; the hemisphere sampler keeps sinf / cosf)
-            const float sn_a = FAST ? __sinf(angle) : sinf(angle), cs_a = FAST ? __cosf(angle) : cosf(angle);
-            const float3 inc = normalize3<FAST>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
+            float sn_a, cs_a;
+            det_sincosf(angle, sn_a, cs_a);
+            const float3 inc = normalize3<false>(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
             const bool transition = dot3(surf.GN, inc) <= 0.0f;
             const float3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
             const float3 O = evaluate_direct_brdf<FAST>(surf, V, L) * sun_rad * throughput; // :573-574
@@ -857,7 +861,9 @@ __global__ __launch_bounds__(64) void pbr_direct_kernel(GiArgs a)
         const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
         const float3 Bv = normalize3(perpendicular(L));
         const float3 T = cross3(Bv, L);
-        const float3 inc = normalize3(L + (Bv * sinf(angle) + T * cosf(angle)) * a.c.sunTanHalfAngle * dist);
+        float sn_a, cs_a;
+        det_sincosf(angle, sn_a, cs_a);
+        const float3 inc = normalize3(L + (Bv * sn_a + T * cs_a) * a.c.sunTanHalfAngle * dist);
         Hit h;
         rays = 1;
         const bool occluded = traverse(a.S, worldPos + SN * 1e-2f, inc, 0.0f, 3.402823466e+38f, true, stack_mem + threadIdx.x, h);

@@ -33,10 +33,29 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b)
 // 3e-5 relative L2 against the oracle -- and so do the G-buffer / direct-light producers.
 template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 template <bool FAST> __device__ __forceinline__ float fsqrt(float x) { return FAST ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+// sin / cos of an angle in [0, 2 pi] by a FIXED sequence of IEEE operations (rintf, exact products inside fmaf, two polynomials on
+// [-pi/4, pi/4], quadrant selection): HLSL's sin / cos are implementation-defined hardware approximations (pathtracer.hlsl's
+// bounce direction, brdf.hlsli:166-185, and sun-disk sample, :533-557), so a restatement has to pick an algorithm -- and when the
+// CPU oracle and the device pick THE SAME one, every bounce ray is the same bits on both sides and the only closest hits that can
+// still differ are exact ties.  (With libm's sinf on one side and ocml's on the other the directions differed in the last ulp, and at
+// 3840 x 2160 some twenty rays per frame grazed an edge differently: hit against miss, one of them 1.5e-3 of a frame's L2 norm.)
+// Accuracy ~1 ulp; coefficients: the Cephes single-precision minimax polynomials.  The same text lives in oracle/trace_ref.cpp and
+// nebulae_amd/csrc/gi_device.h.
+__device__ __forceinline__ void det_sincosf(float x, float& s, float& c)
+{
+    const float k = rintf(x * 0.636619772367581343f);                         // nearest multiple of pi / 2
+    float r = fmaf(-k, 1.57079637050628662109375f, x);                        // x - k * pi/2, the product exact inside the fma
+    r = fmaf(-k, -4.37113900018624283e-8f, r);                                // ... the low part of pi / 2
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+// pow(x, 5) as x^2 * x^2 * x under both policies (the oracle's form too: libm's powf and ocml's differ in the last ulp)
 template <bool FAST> __device__ __forceinline__ float fpow5(float x)
 {
-    if (!FAST)
-        return powf(x, 5.0f);
     const float x2 = x * x;
     return x2 * x2 * x;
 }
@@ -154,7 +173,13 @@ template <bool FAST = false> __device__ __forceinline__ float specular_probabili
 template <bool FAST = false, bool FAST_TRIG = false> __device__ __forceinline__ float3 cosine_hemisphere_aligned(float u0, float u1, float3 sn) // brdf.hlsli:166-185
 {
     const float a = fsqrt<FAST>(u0), b = kPiTwo * u1;
-    const float3 z = f3(a * (FAST_TRIG ? __cosf(b) : cosf(b)), a * (FAST_TRIG ? __sinf(b) : sinf(b)), fsqrt<FAST>(1.0f - u0));
+    float sb, cb;
+    if (FAST_TRIG) {
+        sb = __sinf(b), cb = __cosf(b);
+    } else {
+        det_sincosf(b, sb, cb);
+    }
+    const float3 z = f3(a * cb, a * sb, fsqrt<FAST>(1.0f - u0));
     const float3 up = fabsf(sn.z) < 0.999f ? f3(0, 0, 1) : f3(1, 0, 0);
     const float3 tx = normalize3<FAST>(cross3(up, sn));
     const float3 ty = cross3(sn, tx);

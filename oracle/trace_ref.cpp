@@ -126,6 +126,28 @@ inline uint32_t small_float_encode(float f, int mbits)
     return bits > max_bits ? max_bits : bits;
 }
 
+
+// sin / cos of an angle in [0, 2 pi] by a FIXED sequence of IEEE operations (rintf, exact products inside fmaf, two polynomials on
+// [-pi/4, pi/4], quadrant selection): HLSL's sin / cos are implementation-defined hardware approximations (pathtracer.hlsl's
+// bounce direction, brdf.hlsli:166-185, and sun-disk sample, :533-557), so a restatement has to pick an algorithm -- and when the
+// CPU oracle and the device pick THE SAME one, every bounce ray is the same bits on both sides and the only closest hits that can
+// still differ are exact ties.  (With libm's sinf on one side and ocml's on the other the directions differed in the last ulp, and at
+// 3840 x 2160 some twenty rays per frame grazed an edge differently: hit against miss, one of them 1.5e-3 of a frame's L2 norm.)
+// Accuracy ~1 ulp; coefficients: the Cephes single-precision minimax polynomials.  The same text lives in oracle/trace_ref.cpp and
+// nebulae_amd/csrc/gi_device.h.
+inline void det_sincosf(float x, float& s, float& c)
+{
+    const float k = rintf(x * 0.636619772367581343f);                         // nearest multiple of pi / 2
+    float r = fmaf(-k, 1.57079637050628662109375f, x);                        // x - k * pi/2, the product exact inside the fma
+    r = fmaf(-k, -4.37113900018624283e-8f, r);                                // ... the low part of pi / 2
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    s = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+}
+
 // ---- brdf.hlsli ----
 inline float luminance(V3 c) { return c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f; }
 inline V3 specular_f0(V3 albedo, float metal)
@@ -135,7 +157,10 @@ inline V3 specular_f0(V3 albedo, float metal)
 inline V3 diffuse_reflectance(V3 albedo, float metal) { return albedo * (1.0f - metal); }
 inline V3 fresnel_schlick(V3 f0, float vdoth) // brdf.hlsli:22-25 (as written: 1 - VdotH^5)
 {
-    float k = 1.0f - powf(vdoth, 5.0f);
+    // pow(x, 5) as the product x^2 * x^2 * x (the same on the device): libm's powf and ocml's differ in the last ulp, which moved the
+    // diffuse probability and -- once in ten million pixels -- the outcome of Rand < pd
+    const float v2 = vdoth * vdoth;
+    float k = 1.0f - v2 * v2 * vdoth;
     return {f0.x + (1.0f - f0.x) * k, f0.y + (1.0f - f0.y) * k, f0.z + (1.0f - f0.z) * k};
 }
 inline float specular_probability(float vdotn, V3 f0, V3 albedo) // brdf.hlsli:129-143
@@ -148,8 +173,9 @@ inline float specular_probability(float vdotn, V3 f0, V3 albedo) // brdf.hlsli:1
 }
 inline V3 cosine_hemisphere_aligned(float u0, float u1, V3 sn) // brdf.hlsli:166-185
 {
-    float a = sqrtf(u0), b = PI_TWO * u1;
-    V3 z = {a * cosf(b), a * sinf(b), sqrtf(1.0f - u0)};
+    float a = sqrtf(u0), b = PI_TWO * u1, sb, cb;
+    det_sincosf(b, sb, cb);
+    V3 z = {a * cb, a * sb, sqrtf(1.0f - u0)};
     V3 up = fabsf(sn.z) < 0.999f ? v3(0, 0, 1) : v3(1, 0, 0);
     V3 tx = normalize(cross(up, sn));
     V3 ty = cross(sn, tx);
@@ -645,6 +671,17 @@ trace_ref_scene* trace_ref_scene_create(const trace_ref_geometry* geoms, uint32_
             B.bmin[i] = v3(std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z)));
             B.bmax[i] = v3(std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z)));
             B.cen[i] = (B.bmin[i] + B.bmax[i]) * 0.5f;
+            // The boxes are PADDED (1e-5 of the largest coordinate, at least 1e-6): the slab test below is plain float arithmetic, an
+            // axis-aligned triangle has a box of zero thickness, and a ray that meets such a triangle on its rim could be turned away by
+            // the box although the triangle test would accept it -- seen once in ~10 M rays as a hit the device reports (its boxes are
+            // rounded outwards) and this tracer missed.  The acceleration structure must never decide a hit: only the triangle test does.
+            {
+                const float m = std::max(std::max(std::max(fabsf(B.bmin[i].x), fabsf(B.bmax[i].x)), std::max(fabsf(B.bmin[i].y), fabsf(B.bmax[i].y))),
+                                         std::max(fabsf(B.bmin[i].z), fabsf(B.bmax[i].z)));
+                const float pad = std::max(1e-5f * m, 1e-6f);
+                B.bmin[i] = B.bmin[i] - v3(pad, pad, pad);
+                B.bmax[i] = B.bmax[i] + v3(pad, pad, pad);
+            }
             B.idx[i] = (uint32_t)i;
         }
         s->nodes.reserve(2 * n);
@@ -747,7 +784,9 @@ extern "C" uint64_t trace_ref_gi(const trace_ref_scene* s, uint32_t W, uint32_t 
                     V3 L = normalize(-sun_dir);
                     V3 Bv = normalize(perpendicular(L));
                     V3 T = cross(Bv, L);
-                    V3 inc = normalize(L + (Bv * sinf(angle) + T * cosf(angle)) * c->sunTanHalfAngle * dist);
+                    float sn_a, cs_a;
+                    det_sincosf(angle, sn_a, cs_a);
+                    V3 inc = normalize(L + (Bv * sn_a + T * cs_a) * c->sunTanHalfAngle * dist);
                     bool transition = dot(surf.GN, inc) <= 0.0f;
                     V3 so = hitP + (transition ? -surf.GN : surf.GN) * 1e-2f;
                     Hit sh;
@@ -947,7 +986,9 @@ extern "C" uint64_t trace_ref_pbr_direct(const trace_ref_scene* s, uint32_t W, u
             const float angle = a0 * 2.0f * 3.1415926535f, dist = sqrtf(a1);
             const V3 Bv = normalize(perpendicular(L));
             const V3 T = cross(Bv, L);
-            const V3 inc = normalize(L + (Bv * sinf(angle) + T * cosf(angle)) * c->sunTanHalfAngle * dist);
+            float sn_a, cs_a;
+            det_sincosf(angle, sn_a, cs_a);
+            const V3 inc = normalize(L + (Bv * sn_a + T * cs_a) * c->sunTanHalfAngle * dist);
             Hit h;
             rays++;
             const bool occluded = trace(s, right, worldPos + SN * 1e-2f, inc, 0.0f, 3.402823466e+38f, true, h);
