@@ -46,6 +46,9 @@
 #ifndef NEB_ATROUS_WX16
 #define NEB_ATROUS_WX16 1
 #endif
+#ifndef NEB_ATROUS_PK // 1: the levels of the fused chain evaluate a texel's taps for the lane's two output rows as packed fp32 pairs (`tap2_geometry` / `tap2_weight`); 0: A/B arm
+#define NEB_ATROUS_PK 1
+#endif
 #ifndef NEB_ATROUS_STAMPS // diagnostic builds only (tools/atrous_stamps.py): per-wave phase times from s_memtime
 #define NEB_ATROUS_STAMPS 0
 #endif
@@ -282,6 +285,80 @@ __device__ __forceinline__ float tap_weight(float h0x, float h0y, float h0z, flo
     e = fmaf(-fabsf(z0 - tB.w), cz, e);
     e = fmaf(-fabsf(lum0 - tA.w), cl, e);
     return NEB_TAP_EXP2(e);
+}
+
+// ---- two output rows per instruction (round 4) ----
+// A lane filters R = 2 output rows of one column, and four of the six staged rows it walks are taps of BOTH: the two taps share the
+// texel and differ in the centre pixel only.  gfx950's packed fp32 forms do two IEEE operations per instruction at 2.09 ns per
+// wave-instruction where a plain v_fma_f32 takes 1.24 and v_mul / v_add / v_sub 1.35-1.38 (tools/ubench_bank.hip): 16-25 % less issue
+// time per operation, and every lane of a pair rounds exactly as the scalar instruction does -- `tap2_geometry` + `tap2_weight` are `tap_weight` twice,
+// bit for bit (the separate kernels, the direct kernel and the strip path keep the scalar form and still agree with the chain).
+// The texel's component is broadcast to both halves by op_sel; what the compiler does not match by itself (a high-half broadcast
+// in v_pk_add_f32, the free [0, 1] clamp on the packed fma) is written out.
+typedef float neb_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ neb_f2 bc2(float s) { return (neb_f2){s, s}; }
+__device__ __forceinline__ neb_f2 pk_fma(neb_f2 x, neb_f2 y, neb_f2 z) { return __builtin_elementwise_fma(x, y, z); }
+// {p.y + q.x, p.y + q.y}
+__device__ __forceinline__ neb_f2 pk_add_hi(neb_f2 p, neb_f2 q)
+{
+    neb_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(p), "v"(q));
+    return r;
+}
+// clamp01({x.x * p.x + z.x, x.y * p.x + z.y})
+__device__ __forceinline__ neb_f2 pk_fma_lo_clamp(neb_f2 x, neb_f2 p, neb_f2 z)
+{
+    neb_f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(r) : "v"(x), "v"(p), "v"(z));
+    return r;
+}
+// {c.x * l.x + k.a, c.x * l.y + k.b}: (a, b) = (x, y), or (y, x) when SWAP.  l comes out of v_log_f32, and a transcendental's result needs a wait
+// state before an ordinary VALU instruction may read it: the compiler inserts one for its own instructions and cannot see into an `asm` (the
+// first version of this function read the registers BEFORE the logarithm had landed), so the asm carries its own s_nop.  Why asm at all: c and
+// k are loop-invariant, and written as vector code the broadcast {c.x, c.x} and the swapped {k.y, k.x} are hoisted out of the tile loop as
+// fourteen more registers (two of the last-level kernels then spill) instead of being the op_sel bits of this one instruction.
+template <bool SWAP>
+__device__ __forceinline__ neb_f2 pk_fma_const(neb_f2 c, neb_f2 l, neb_f2 k)
+{
+#if NEB_ATROUS_PK == 2 // A/B arm: left to the compiler
+    return pk_fma(__builtin_shufflevector(c, c, 0, 0), l, SWAP ? __builtin_shufflevector(k, k, 1, 0) : k);
+#else
+    neb_f2 r;
+    if constexpr (SWAP)
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(c), "v"(l), "v"(k));
+    else
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(c), "v"(l), "v"(k));
+    return r;
+#endif
+}
+// The taps of one texel for the lane's two output rows, in three phases so that the caller can run each phase for all texels of a group before the next
+// (a v_log / v_exp result needs a wait state before it is read, and the wave really waits: with a texel's phases back to back the level ran 1.1 us longer):
+// h0* = the two centre normals halved, nz0 / nl0 = MINUS the centre depths / luminances (|t - z0| = |z0 - t| exactly), pc = {phiNormal, cz},
+// lk = the two taps' constants in the order SWAP says.
+struct Tap2 {
+    neb_f2 l, dz, dl; // log2 of the halved, clamped dot products; depth and luminance differences (sign irrelevant)
+};
+__device__ __forceinline__ Tap2 tap2_geometry(neb_f2 h0x, neb_f2 h0y, neb_f2 h0z, neb_f2 nz0, neb_f2 nl0, float4 tA, float4 tB)
+{
+    const neb_f2 bxy = {tB.x, tB.y}, bzw = {tB.z, tB.w}, azw = {tA.z, tA.w};
+    neb_f2 d = h0x * __builtin_shufflevector(bxy, bxy, 0, 0);
+    d = pk_fma(h0y, __builtin_shufflevector(bxy, bxy, 1, 1), d);
+    d = pk_fma_lo_clamp(h0z, bzw, d);
+    Tap2 t;
+    t.l = (neb_f2){NEB_TAP_LOG2(d.x), NEB_TAP_LOG2(d.y)};
+    t.dz = pk_add_hi(bzw, nz0);
+    t.dl = pk_add_hi(azw, nl0);
+    return t;
+}
+template <bool SWAP>
+__device__ __forceinline__ neb_f2 tap2_weight(const Tap2& t, neb_f2 cl, neb_f2 pc, neb_f2 lk)
+{
+    neb_f2 e = pk_fma_const<SWAP>(pc, t.l, lk);
+    e.x = fmaf(-fabsf(t.dz.x), pc.y, e.x);
+    e.y = fmaf(-fabsf(t.dz.y), pc.y, e.y);
+    e.x = fmaf(-fabsf(t.dl.x), cl.x, e.x);
+    e.y = fmaf(-fabsf(t.dl.y), cl.y, e.y);
+    return (neb_f2){NEB_TAP_EXP2(e.x), NEB_TAP_EXP2(e.y)};
 }
 
 // The a-trous output store.  A plain store leaves its line dirty in the XCD's L2, and what is dirty when the kernel ends is
@@ -584,6 +661,19 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         }
     if constexpr (IN == kInLum)
         asm volatile("" : "+v"(cz), "+v"(phiN));
+    // the packed tap's constants: {phiNormal, cz}, and per |dx| the pairs {lkp[.][0], lkp[.][1]} and {lkp[.][1], lkp[.][2]} (read straight
+    // or swapped by op_sel): 14 registers where the scalar form holds 8
+    constexpr bool kPacked = NEB_ATROUS_PK && R == 2 && IN == kInLum;
+    neb_f2 pcz = {phiN, cz}, lkq[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        lkq[i][0] = (neb_f2){lkp[i][0], lkp[i][1]};
+        lkq[i][1] = (neb_f2){lkp[i][1], lkp[i][2]};
+        if constexpr (kPacked)
+            asm volatile("" : "+v"(lkq[i][0]), "+v"(lkq[i][1]));
+    }
+    if constexpr (kPacked)
+        asm volatile("" : "+v"(pcz));
 
     NEB_STAMP(0);
     while (have) {
@@ -749,39 +839,111 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                 }
             }
         };
-        load_group(0);
+        if constexpr (kPacked) {
+            // the lane's two output rows side by side (see tap2_geometry): staged row ir is tap dy = ir - 2 of row 0 and ir - 3 of row 1
+            const neb_f2 h0x = {n0x[0], n0x[1]}, h0y = {n0y[0], n0y[1]}, h0z = {n0z[0], n0z[1]};
+            const neb_f2 nz0 = {-z0[0], -z0[1]}, nl0 = {-lum0[0], -lum0[1]}, cl2 = {cl[0], cl[1]};
+            neb_f2 sr2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sb2 = {0.f, 0.f}, sw2 = {0.f, 0.f};
+            load_group(0);
 #pragma unroll
-        for (int g = 0; g < 2 * (R + 4); ++g) {
-            const int ir = g >> 1;
-            if ((g & 1) == 0 && ir < NLOAD && have_next)
-                issue_load(ir, nt);
-            if (g + 1 < 2 * (R + 4))
-                load_group(g + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 2 * (R + 4); ++g) {
+                const int ir = g >> 1;
+                if ((g & 1) == 0 && ir < NLOAD && have_next)
+                    issue_load(ir, nt);
+                if (g + 1 < 2 * (R + 4))
+                    load_group(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int kMaxGroup = 3;
+                const int ng = (g & 1) ? 2 : 3; // texels of this group: dx = -2, -1, 0 or 1, 2
+                if (ir == 0 || ir == R + 3) { // taps of one row only (dy = -2 of row 0, dy = +2 of row 1)
+                    const int k = ir == 0 ? 0 : 1;
 #pragma unroll
-            for (int j = 0; j < ((g & 1) ? 2 : 3); ++j) {
-                const int dx = (g & 1) ? j + 1 : j - 2;
-                const float4 tA = gA[g & 1][j];
-                const float4 tB = gB[g & 1][j];
+                    for (int j = 0; j < ng; ++j) {
+                        const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
+                        const float4 tA = gA[g & 1][j];
+                        const float4 tB = gB[g & 1][j];
+                        const float w = tap_weight(h0x[k], h0y[k], h0z[k], z0[k], lum0[k], cl2[k], tA, tB, pcz.x, pcz.y, lkq[adx][1].y);
+                        sr2[k] = fmaf(w, tA.x, sr2[k]);
+                        sg2[k] = fmaf(w, tA.y, sg2[k]);
+                        sb2[k] = fmaf(w, tA.z, sb2[k]);
+                        sw2[k] += w;
+                    }
+                } else {
+                    Tap2 t[kMaxGroup];
+                    neb_f2 w[kMaxGroup];
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const int dy = ir - k - 2;
-                    if (dy < -2 || dy > 2)
-                        continue;
-                    const float w = tap_weight(n0x[k], n0y[k], n0z[k], z0[k], lum0[k], cl[k], tA, tB, phiN, cz, lkp[dx < 0 ? -dx : dx][dy < 0 ? -dy : dy]);
-                    sr[k] = fmaf(w, tA.x, sr[k]);
-                    sg[k] = fmaf(w, tA.y, sg[k]);
-                    sb[k] = fmaf(w, tA.z, sb[k]);
-                    sw[k] += w;
+                    for (int j = 0; j < ng; ++j)
+                        t[j] = tap2_geometry(h0x, h0y, h0z, nz0, nl0, gA[g & 1][j], gB[g & 1][j]);
+#if NEB_ATROUS_PK != 3
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                    for (int j = 0; j < ng; ++j) {
+                        const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
+                        // (|dy0|, |dy1|) = (1, 2), (0, 1), (1, 0), (2, 1) for ir = 1 .. 4: the constant pairs {0, 1} and {1, 2}, straight or swapped
+                        w[j] = (ir == 1)   ? tap2_weight<false>(t[j], cl2, pcz, lkq[adx][1])
+                               : (ir == 2) ? tap2_weight<false>(t[j], cl2, pcz, lkq[adx][0])
+                               : (ir == 3) ? tap2_weight<true>(t[j], cl2, pcz, lkq[adx][0])
+                                           : tap2_weight<true>(t[j], cl2, pcz, lkq[adx][1]);
+                    }
+#if NEB_ATROUS_PK != 3
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                    for (int j = 0; j < ng; ++j) {
+                        const float4 tA = gA[g & 1][j];
+                        const neb_f2 axy = {tA.x, tA.y}, azw = {tA.z, tA.w};
+                        sr2 = pk_fma(w[j], __builtin_shufflevector(axy, axy, 0, 0), sr2);
+                        sg2 = pk_fma(w[j], __builtin_shufflevector(axy, axy, 1, 1), sg2);
+                        sb2 = pk_fma(w[j], __builtin_shufflevector(azw, azw, 0, 0), sb2);
+                        sw2 += w[j];
+                    }
                 }
+                asm volatile("" : "+v"(sr2), "+v"(sg2), "+v"(sb2), "+v"(sw2)); // (pinned for the reason given below)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // Pin the partial sums here: they only feed the predicated store below, so LLVM would
-            // otherwise sink ALL the arithmetic under that branch and keep every staged texel live
-            // (spilling ~1.3 KB per lane).  The sched_barrier keeps one group's ds_reads per region.
 #pragma unroll
-            for (int k = 0; k < R; ++k)
-                asm volatile("" : "+v"(sr[k]), "+v"(sg[k]), "+v"(sb[k]), "+v"(sw[k]));
-            __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < R; ++k) {
+                sr[k] = sr2[k];
+                sg[k] = sg2[k];
+                sb[k] = sb2[k];
+                sw[k] = sw2[k];
+            }
+        } else {
+            load_group(0);
+#pragma unroll
+            for (int g = 0; g < 2 * (R + 4); ++g) {
+                const int ir = g >> 1;
+                if ((g & 1) == 0 && ir < NLOAD && have_next)
+                    issue_load(ir, nt);
+                if (g + 1 < 2 * (R + 4))
+                    load_group(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < ((g & 1) ? 2 : 3); ++j) {
+                    const int dx = (g & 1) ? j + 1 : j - 2;
+                    const float4 tA = gA[g & 1][j];
+                    const float4 tB = gB[g & 1][j];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const int dy = ir - k - 2;
+                        if (dy < -2 || dy > 2)
+                            continue;
+                        const float w = tap_weight(n0x[k], n0y[k], n0z[k], z0[k], lum0[k], cl[k], tA, tB, phiN, cz, lkp[dx < 0 ? -dx : dx][dy < 0 ? -dy : dy]);
+                        sr[k] = fmaf(w, tA.x, sr[k]);
+                        sg[k] = fmaf(w, tA.y, sg[k]);
+                        sb[k] = fmaf(w, tA.z, sb[k]);
+                        sw[k] += w;
+                    }
+                }
+                // Pin the partial sums here: they only feed the predicated store below, so LLVM would
+                // otherwise sink ALL the arithmetic under that branch and keep every staged texel live
+                // (spilling ~1.3 KB per lane).  The sched_barrier keeps one group's ds_reads per region.
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    asm volatile("" : "+v"(sr[k]), "+v"(sg[k]), "+v"(sb[k]), "+v"(sw[k]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         NEB_STAMP(4);
 #pragma unroll
