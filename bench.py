@@ -217,12 +217,14 @@ def measured_valu(width, height, levels):
         return None
     insts = sum(v["SQ_INSTS_VALU"] for v in per) / len(per)
     # priced at the measured issue cost of this kernel's own instruction mix with three waves per SIMD (tools/ubench_bank.hip:
-    # 1.25 ns per three-operand wave-instruction, + 3.4 ns for each v_exp / v_log) -- NOT at SQ_ACTIVE_INST_VALU, which
+    # 1.25 ns per three-operand wave-instruction, 2.09 per packed pair (round 4: 100 v_pk_* per pixel -- four of a pixel's five tap
+    # rows are evaluated for two output rows at once), + 3.4 ns for each v_exp / v_log) -- NOT at SQ_ACTIVE_INST_VALU, which
     # charges 4 cycles per instruction
     transcendental = 2 * 25 * width * height / 64.0
+    packed = 100 * width * height / 64.0
     return {"lane_instructions_per_pixel": insts * 64.0 / (width * height),
-            "issue_us_per_launch": (insts * 1.25e-3 + transcendental * 3.4e-3) / 1024.0,
-            "ns_per_wave_instruction": 1.25, "ns_extra_per_transcendental": 3.4, "source": name}
+            "issue_us_per_launch": ((insts - packed) * 1.25e-3 + packed * 2.09e-3 + transcendental * 3.4e-3) / 1024.0,
+            "ns_per_wave_instruction": 1.25, "ns_per_packed_pair": 2.09, "ns_extra_per_transcendental": 3.4, "source": name}
 
 
 def host_cores():
@@ -748,7 +750,7 @@ def main(argv=None, rt=None, emit=None):
                          "launch_us_samples": atrous_samples,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
                          # the contract prices this kernel against HBM; what binds it in fact is instruction issue
-                         "limiter": "VALU issue: 25 taps x (12 three-operand instructions + v_log + v_exp) per pixel" if valu else None, "valu": valu},
+                         "limiter": "VALU issue: 25 taps x (12 fp32 operations -- ten of them as packed pairs in four taps of five -- + v_log + v_exp) per pixel; the 30 ds_read_b128 per pixel keep the LDS pipe ~75 % busy beside it" if valu else None, "valu": valu},
             "temporal_roofline": (None if (fused or t_temporal <= 0) else
                                   {"achieved": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": TEMPORAL_BYTES_PX * own_px / t_temporal / 1e9 / HBM_PEAK_GBPS}),
