@@ -99,6 +99,77 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float s)
         asm volatile(INIT_REGS REP8("v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_pk_fma_f32 v[12:13], v[20:21], v[30:31], v[12:13]\n v_pk_fma_f32 v[14:15], v[22:23], v[28:29], v[14:15]\n"
                                     "v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_pk_fma_f32 v[12:13], v[20:21], v[30:31], v[12:13]\n v_pk_fma_f32 v[14:15], v[22:23], v[28:29], v[14:15]\n") LOOP_END
                      : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 20) // v_perm_b32 (byte select from two registers by a selector register)
+        asm volatile(INIT_REGS REP8("v_perm_b32 v8, v17, v26, v24\n v_perm_b32 v9, v18, v27, v24\n v_perm_b32 v10, v19, v24, v25\n v_perm_b32 v11, v16, v25, v24\n"
+                                    "v_perm_b32 v12, v21, v30, v24\n v_perm_b32 v13, v22, v31, v24\n v_perm_b32 v14, v23, v28, v24\n v_perm_b32 v15, v20, v29, v24\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 21)
+        asm volatile(INIT_REGS REP8("v_and_or_b32 v8, v17, v26, v24\n v_and_or_b32 v9, v18, v27, v24\n v_and_or_b32 v10, v19, v24, v25\n v_and_or_b32 v11, v16, v25, v24\n"
+                                    "v_and_or_b32 v12, v21, v30, v24\n v_and_or_b32 v13, v22, v31, v24\n v_and_or_b32 v14, v23, v28, v24\n v_and_or_b32 v15, v20, v29, v24\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 22)
+        asm volatile(INIT_REGS REP8("v_bfe_u32 v8, v17, 8, 8\n v_bfe_u32 v9, v18, 8, 8\n v_bfe_u32 v10, v19, 16, 8\n v_bfe_u32 v11, v16, 8, 8\n"
+                                    "v_bfe_u32 v12, v21, 8, 8\n v_bfe_u32 v13, v22, 16, 8\n v_bfe_u32 v14, v23, 8, 8\n v_bfe_u32 v15, v20, 8, 8\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 23)
+        asm volatile(INIT_REGS REP8("v_lshl_or_b32 v8, v17, 15, v24\n v_lshl_or_b32 v9, v18, 15, v24\n v_lshl_or_b32 v10, v19, 15, v25\n v_lshl_or_b32 v11, v16, 15, v24\n"
+                                    "v_lshl_or_b32 v12, v21, 15, v24\n v_lshl_or_b32 v13, v22, 15, v24\n v_lshl_or_b32 v14, v23, 15, v24\n v_lshl_or_b32 v15, v20, 15, v24\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 24)
+        asm volatile(INIT_REGS REP8("v_cvt_f32_u32 v8, v17\n v_cvt_f32_u32 v9, v18\n v_cvt_f32_u32 v10, v19\n v_cvt_f32_u32 v11, v16\n"
+                                    "v_cvt_f32_u32 v12, v21\n v_cvt_f32_u32 v13, v22\n v_cvt_f32_u32 v14, v23\n v_cvt_f32_u32 v15, v20\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 25) // mixed-precision fma: an fp16 half of a register as a source
+        asm volatile(INIT_REGS REP8("v_fma_mix_f32 v8, v17, v26, v8 op_sel_hi:[1,0,0]\n v_fma_mix_f32 v9, v18, v27, v9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 v10, v19, v24, v10 op_sel_hi:[1,0,0]\n v_fma_mix_f32 v11, v16, v25, v11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                                    "v_fma_mix_f32 v12, v21, v30, v12 op_sel_hi:[1,0,0]\n v_fma_mix_f32 v13, v22, v31, v13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 v14, v23, v28, v14 op_sel_hi:[1,0,0]\n v_fma_mix_f32 v15, v20, v29, v15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 26)
+        asm volatile(INIT_REGS REP8("v_and_b32 v8, v17, v26\n v_and_b32 v9, v18, v27\n v_or_b32 v10, v19, v24\n v_or_b32 v11, v16, v25\n"
+                                    "v_and_b32 v12, v21, v30\n v_and_b32 v13, v22, v31\n v_or_b32 v14, v23, v28\n v_or_b32 v15, v20, v29\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 27) // VOP3 encoding reading VCC
+        asm volatile("s_mov_b64 vcc, 0x5555\n" INIT_REGS REP8("v_cndmask_b32_e64 v8, v17, v26, vcc\n v_cndmask_b32_e64 v9, v18, v27, vcc\n v_cndmask_b32_e64 v10, v19, v24, vcc\n v_cndmask_b32_e64 v11, v16, v25, vcc\n"
+                                    "v_cndmask_b32_e64 v12, v21, v30, vcc\n v_cndmask_b32_e64 v13, v22, v31, vcc\n v_cndmask_b32_e64 v14, v23, v28, vcc\n v_cndmask_b32_e64 v15, v20, v29, vcc\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS, "vcc");
+    if constexpr (MODE == 28) // compare into VCC + select from VCC, as compilers write it (4 pairs)
+        asm volatile(INIT_REGS REP8("v_cmp_lt_f32_e32 vcc, v17, v26\n v_cndmask_b32_e32 v8, v18, v27, vcc\n v_cmp_lt_f32_e32 vcc, v19, v24\n v_cndmask_b32_e32 v10, v16, v25, vcc\n"
+                                    "v_cmp_lt_f32_e32 vcc, v21, v30\n v_cndmask_b32_e32 v12, v22, v31, vcc\n v_cmp_lt_f32_e32 vcc, v23, v28\n v_cndmask_b32_e32 v14, v20, v29, vcc\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS, "vcc");
+    if constexpr (MODE == 29) // compare into an SGPR pair + select from it (VOP3 both)
+        asm volatile(INIT_REGS REP8("v_cmp_lt_f32_e64 s[22:23], v17, v26\n v_cndmask_b32_e64 v8, v18, v27, s[22:23]\n v_cmp_lt_f32_e64 s[24:25], v19, v24\n v_cndmask_b32_e64 v10, v16, v25, s[24:25]\n"
+                                    "v_cmp_lt_f32_e64 s[26:27], v21, v30\n v_cndmask_b32_e64 v12, v22, v31, s[26:27]\n v_cmp_lt_f32_e64 s[28:29], v23, v28\n v_cndmask_b32_e64 v14, v20, v29, s[28:29]\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS, "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29");
+    if constexpr (MODE == 30) // the same with independent work between compare and select
+        asm volatile(INIT_REGS REP8("v_cmp_lt_f32_e32 vcc, v17, v26\n v_fma_f32 v9, v18, v27, v9\n v_cndmask_b32_e32 v8, v18, v27, vcc\n v_fma_f32 v11, v16, v25, v11\n"
+                                    "v_cmp_lt_f32_e32 vcc, v21, v30\n v_fma_f32 v13, v22, v31, v13\n v_cndmask_b32_e32 v12, v22, v31, vcc\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS, "vcc");
+    if constexpr (MODE == 31) // v_pk_fma_f32 and v_fma_f32 alternating
+        asm volatile(INIT_REGS REP8("v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_fma_f32 v12, v21, v30, v12\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_fma_f32 v13, v22, v31, v13\n v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_fma_f32 v14, v23, v28, v14\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 32) // v_cvt_f32_ubyteN and v_fma_f32 alternating
+        asm volatile(INIT_REGS REP8("v_cvt_f32_ubyte0 v8, v17\n v_fma_f32 v12, v21, v30, v12\n v_cvt_f32_ubyte1 v9, v18\n v_fma_f32 v13, v22, v31, v13\n v_cvt_f32_ubyte2 v10, v19\n v_fma_f32 v14, v23, v28, v14\n v_cvt_f32_ubyte3 v11, v16\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 33) // v_max / v_min and v_fma_f32 alternating
+        asm volatile(INIT_REGS REP8("v_max_f32 v8, v26, v17\n v_fma_f32 v12, v21, v30, v12\n v_min_f32 v9, v27, v18\n v_fma_f32 v13, v22, v31, v13\n v_max_f32 v10, v24, v19\n v_fma_f32 v14, v23, v28, v14\n v_min_f32 v11, v25, v16\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 34) // v_exp / v_log and v_fma_f32 alternating
+        asm volatile(INIT_REGS REP8("v_exp_f32 v8, v17\n v_fma_f32 v12, v21, v30, v12\n v_log_f32 v9, v18\n v_fma_f32 v13, v22, v31, v13\n v_exp_f32 v10, v19\n v_fma_f32 v14, v23, v28, v14\n v_log_f32 v11, v16\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 35) // v_exp / v_log only
+        asm volatile(INIT_REGS REP8("v_exp_f32 v8, v17\n v_log_f32 v9, v18\n v_exp_f32 v10, v19\n v_log_f32 v11, v16\n v_exp_f32 v8, v17\n v_log_f32 v9, v18\n v_exp_f32 v10, v19\n v_log_f32 v11, v16\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 36) // fma with an SGPR source and three-VGPR fma alternating
+        asm volatile(INIT_REGS REP8("v_fma_f32 v8, v17, %3, v8\n v_fma_f32 v12, v21, v30, v12\n v_fma_f32 v9, v18, %3, v9\n v_fma_f32 v13, v22, v31, v13\n v_fma_f32 v10, v19, %3, v10\n v_fma_f32 v14, v23, v28, v14\n v_fma_f32 v11, v16, %3, v11\n v_fma_f32 v15, v20, v29, v15\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 37) // v_pk_fma_f32 and v_cvt_f32_ubyteN alternating
+        asm volatile(INIT_REGS REP8("v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_cvt_f32_ubyte0 v8, v17\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_cvt_f32_ubyte1 v9, v18\n v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_cvt_f32_ubyte2 v10, v19\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_cvt_f32_ubyte3 v11, v16\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 38) // one v_pk_fma_f32 per two v_fma_f32 (3 + 5)
+        asm volatile(INIT_REGS REP8("v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_fma_f32 v12, v21, v30, v12\n v_fma_f32 v13, v22, v31, v13\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_fma_f32 v14, v23, v28, v14\n v_fma_f32 v15, v20, v29, v15\n v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_fma_f32 v12, v21, v30, v12\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
+    if constexpr (MODE == 39) // v_exp / v_log and v_pk_fma_f32 alternating
+        asm volatile(INIT_REGS REP8("v_exp_f32 v8, v17\n v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_log_f32 v9, v18\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n v_exp_f32 v10, v19\n v_pk_fma_f32 v[8:9], v[16:17], v[26:27], v[8:9]\n v_log_f32 v11, v16\n v_pk_fma_f32 v[10:11], v[18:19], v[24:25], v[10:11]\n") LOOP_END
+                     : "=&v"(res) : "v"(r), "s"(iters), "s"(s) : CLOBBERS);
     if constexpr (MODE == 6)
         asm volatile(INIT_REGS REP8("v_fmac_f32 v8, v17, v26\n v_fmac_f32 v9, v18, v27\n v_fmac_f32 v10, v19, v24\n v_fmac_f32 v11, v16, v25\n"
                                     "v_fmac_f32 v12, v21, v30\n v_fmac_f32 v13, v22, v31\n v_fmac_f32 v14, v23, v28\n v_fmac_f32 v15, v20, v29\n") LOOP_END
@@ -125,9 +196,26 @@ static void run(const char* name, int blocks_per_cu, int per_iter)
     hipFree(out);
 }
 
-int main()
+int main(int argc, char**)
 {
+    const bool only_new = argc > 1; // any argument: only the compare / select forms
     for (int w : {3, 8}) {
+        if (only_new) {
+            run<27>("v_cndmask_b32_e64 v, v, v, vcc (VOP3 reading VCC)", w, 64);
+            run<28>("v_cmp_lt_f32 vcc + v_cndmask_b32_e32 ... vcc (pairs)", w, 64);
+            run<29>("v_cmp_lt_f32_e64 s[n:n+1] + v_cndmask_b32_e64 (pairs)", w, 64);
+            run<30>("v_cmp vcc, fma, v_cndmask_e32 vcc, fma", w, 64);
+            run<31>("v_pk_fma_f32, v_fma_f32 alternating", w, 64);
+            run<32>("v_cvt_f32_ubyteN, v_fma_f32 alternating", w, 64);
+            run<33>("v_max/min_f32, v_fma_f32 alternating", w, 64);
+            run<34>("v_exp/log_f32, v_fma_f32 alternating", w, 64);
+            run<35>("v_exp/log_f32 only", w, 64);
+            run<36>("v_fma_f32 with SGPR source, v_fma_f32 alternating", w, 64);
+            run<37>("v_pk_fma_f32, v_cvt_f32_ubyteN alternating", w, 64);
+            run<38>("3 v_pk_fma_f32 + 5 v_fma_f32", w, 64);
+            run<39>("v_exp/log_f32, v_pk_fma_f32 alternating", w, 64);
+            continue;
+        }
         run<0>("fma v, v, s, const (1 VGPR source)", w, 64);
         run<3>("fma v, v, s, v (2 VGPR sources, 2 banks)", w, 64);
         run<1>("fma v, v, v, v (3 VGPR sources, 3 banks)", w, 64);
@@ -146,6 +234,17 @@ int main()
         run<17>("v_fma_f32 v, -|v|, v, v clamp (modifiers)", w, 64);
         run<18>("v_fma_f32 v, v, -1.0, v (a - b as an fma)", w, 64);
         run<19>("v_pk_fma_f32 (per instruction = two fmas per lane)", w, 64);
+        run<20>("v_perm_b32 v, v, v, v", w, 64);
+        run<21>("v_and_or_b32 v, v, v, v", w, 64);
+        run<22>("v_bfe_u32 v, v, imm, imm", w, 64);
+        run<23>("v_lshl_or_b32 v, v, imm, v", w, 64);
+        run<24>("v_cvt_f32_u32 v, v", w, 64);
+        run<25>("v_fma_mix_f32 v, v.h, v, v (fp16 half as a source)", w, 64);
+        run<26>("v_and_b32 / v_or_b32 v, v, v (VOP2)", w, 64);
+        run<27>("v_cndmask_b32_e64 v, v, v, vcc (VOP3 reading VCC)", w, 64);
+        run<28>("v_cmp_lt_f32 vcc + v_cndmask_b32_e32 ... vcc (pairs)", w, 64);
+        run<29>("v_cmp_lt_f32_e64 s[n:n+1] + v_cndmask_b32_e64 (pairs)", w, 64);
+        run<30>("v_cmp vcc, fma, v_cndmask_e32 vcc, fma", w, 64);
         run<4>("tap mix: 12 three-source fma + v_log + v_exp", w, 112);
         run<5>("tap mix with the transcendentals as fma", w, 112);
     }
