@@ -49,6 +49,9 @@
 #ifndef NEB_ATROUS_PK // 1: the levels of the fused chain evaluate a texel's taps for the lane's two output rows as packed fp32 pairs (`tap2_geometry` / `tap2_weight`); 0: A/B arm
 #define NEB_ATROUS_PK 1
 #endif
+#ifndef NEB_ATROUS_PK_FUSED // the same in the fused temporal + level-0 kernel (tap constants as scalar operands of two plain fmas, one texel at a time:
+#define NEB_ATROUS_PK_FUSED 1 // it has no registers to spare; 47.9 -> 46.2 us); 0: A/B arm
+#endif
 #ifndef NEB_ATROUS_STAMPS // diagnostic builds only (tools/atrous_stamps.py): per-wave phase times from s_memtime
 #define NEB_ATROUS_STAMPS 0
 #endif
@@ -287,6 +290,17 @@ __device__ __forceinline__ float tap_weight(float h0x, float h0y, float h0z, flo
     return NEB_TAP_EXP2(e);
 }
 
+// the same with MINUS the centre depth and luminance (what the packed form keeps in its register pairs): |t + (-z0)| = |z0 - t| exactly
+__device__ __forceinline__ float tap_weight_neg(float h0x, float h0y, float h0z, float nz0, float nl0, float cl, float4 tA, float4 tB, float phiN, float cz,
+                                                float lkp)
+{
+    const float dh = half_dot_max0(fmaf(h0z, tB.z, fmaf(h0y, tB.y, h0x * tB.x)));
+    float e = fmaf(phiN, NEB_TAP_LOG2(dh), lkp);
+    e = fmaf(-fabsf(tB.w + nz0), cz, e);
+    e = fmaf(-fabsf(tA.w + nl0), cl, e);
+    return NEB_TAP_EXP2(e);
+}
+
 // ---- two output rows per instruction (round 4) ----
 // A lane filters R = 2 output rows of one column, and four of the six staged rows it walks are taps of BOTH: the two taps share the
 // texel and differ in the centre pixel only.  gfx950's packed fp32 forms do two IEEE operations per instruction at 2.09 ns per
@@ -350,10 +364,16 @@ __device__ __forceinline__ Tap2 tap2_geometry(neb_f2 h0x, neb_f2 h0y, neb_f2 h0z
     t.dl = pk_add_hi(azw, nl0);
     return t;
 }
-template <bool SWAP>
+template <bool SWAP, bool KS>
 __device__ __forceinline__ neb_f2 tap2_weight(const Tap2& t, neb_f2 cl, neb_f2 pc, neb_f2 lk)
 {
-    neb_f2 e = pk_fma_const<SWAP>(pc, t.l, lk);
+    neb_f2 e;
+    if constexpr (KS) { // the constants are scalar operands (the fused kernel, at its register budget): two plain fmas, one SGPR source each
+        e.x = fmaf(pc.x, t.l.x, SWAP ? lk.y : lk.x);
+        e.y = fmaf(pc.x, t.l.y, SWAP ? lk.x : lk.y);
+    } else {
+        e = pk_fma_const<SWAP>(pc, t.l, lk);
+    }
     e.x = fmaf(-fabsf(t.dz.x), pc.y, e.x);
     e.y = fmaf(-fabsf(t.dz.y), pc.y, e.y);
     e.x = fmaf(-fabsf(t.dl.x), cl.x, e.x);
@@ -566,9 +586,11 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         } else {
             o.first = 0;
             toff_regular = false;
+            int tid = threadIdx.x; // (opaque for the same reason: lr and lc of every k would be held for the whole kernel)
+            asm volatile("" : "+v"(tid));
 #pragma unroll
             for (int k = 0; k < NLOAD; ++k) {
-                const int i = threadIdx.x + THREADS * k;
+                const int i = tid + THREADS * k;
                 const int lr = i / COLS, lc = i - lr * COLS;
                 // clamp to the image (svgf_atrous.hlsl:65), then to the resident rows: a partial tile also stages rows
                 // that no valid output taps; on a row strip those may lie outside the allocation, so they are
@@ -663,16 +685,18 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         asm volatile("" : "+v"(cz), "+v"(phiN));
     // the packed tap's constants: {phiNormal, cz}, and per |dx| the pairs {lkp[.][0], lkp[.][1]} and {lkp[.][1], lkp[.][2]} (read straight
     // or swapped by op_sel): 14 registers where the scalar form holds 8
-    constexpr bool kPacked = NEB_ATROUS_PK && R == 2 && IN == kInLum;
+    constexpr bool kPacked = NEB_ATROUS_PK && R == 2 && (IN == kInLum || (IN == kInFused && NEB_ATROUS_PK_FUSED));
+    constexpr bool kLkScalar = IN != kInLum;
+    constexpr bool kPhased = NEB_ATROUS_PK != 3 && IN == kInLum; // (the fused kernel has no registers for a whole group's intermediate values)
     neb_f2 pcz = {phiN, cz}, lkq[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         lkq[i][0] = (neb_f2){lkp[i][0], lkp[i][1]};
         lkq[i][1] = (neb_f2){lkp[i][1], lkp[i][2]};
-        if constexpr (kPacked)
+        if constexpr (kPacked && !kLkScalar)
             asm volatile("" : "+v"(lkq[i][0]), "+v"(lkq[i][1]));
     }
-    if constexpr (kPacked)
+    if constexpr (kPacked && !kLkScalar)
         asm volatile("" : "+v"(pcz));
 
     NEB_STAMP(0);
@@ -862,11 +886,29 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                         const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
                         const float4 tA = gA[g & 1][j];
                         const float4 tB = gB[g & 1][j];
-                        const float w = tap_weight(h0x[k], h0y[k], h0z[k], z0[k], lum0[k], cl2[k], tA, tB, pcz.x, pcz.y, lkq[adx][1].y);
+                        const float w = tap_weight_neg(h0x[k], h0y[k], h0z[k], nz0[k], nl0[k], cl2[k], tA, tB, pcz.x, pcz.y, lkq[adx][1].y);
                         sr2[k] = fmaf(w, tA.x, sr2[k]);
                         sg2[k] = fmaf(w, tA.y, sg2[k]);
                         sb2[k] = fmaf(w, tA.z, sb2[k]);
                         sw2[k] += w;
+                    }
+                } else if constexpr (kLkScalar) {
+                    // the fused kernel: one texel at a time (its staging phase leaves no registers for a whole group's intermediate values)
+#pragma unroll
+                    for (int j = 0; j < ng; ++j) {
+                        const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
+                        const float4 tA = gA[g & 1][j];
+                        const Tap2 t = tap2_geometry(h0x, h0y, h0z, nz0, nl0, tA, gB[g & 1][j]);
+                        const neb_f2 w = (ir == 1)   ? tap2_weight<false, true>(t, cl2, pcz, lkq[adx][1])
+                                         : (ir == 2) ? tap2_weight<false, true>(t, cl2, pcz, lkq[adx][0])
+                                         : (ir == 3) ? tap2_weight<true, true>(t, cl2, pcz, lkq[adx][0])
+                                                     : tap2_weight<true, true>(t, cl2, pcz, lkq[adx][1]);
+                        const neb_f2 axy = {tA.x, tA.y}, azw = {tA.z, tA.w};
+                        sr2 = pk_fma(w, __builtin_shufflevector(axy, axy, 0, 0), sr2);
+                        sg2 = pk_fma(w, __builtin_shufflevector(axy, axy, 1, 1), sg2);
+                        sb2 = pk_fma(w, __builtin_shufflevector(azw, azw, 0, 0), sb2);
+                        sw2 += w;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
                     Tap2 t[kMaxGroup];
@@ -874,21 +916,19 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
 #pragma unroll
                     for (int j = 0; j < ng; ++j)
                         t[j] = tap2_geometry(h0x, h0y, h0z, nz0, nl0, gA[g & 1][j], gB[g & 1][j]);
-#if NEB_ATROUS_PK != 3
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
+                    if constexpr (kPhased)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < ng; ++j) {
                         const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
                         // (|dy0|, |dy1|) = (1, 2), (0, 1), (1, 0), (2, 1) for ir = 1 .. 4: the constant pairs {0, 1} and {1, 2}, straight or swapped
-                        w[j] = (ir == 1)   ? tap2_weight<false>(t[j], cl2, pcz, lkq[adx][1])
-                               : (ir == 2) ? tap2_weight<false>(t[j], cl2, pcz, lkq[adx][0])
-                               : (ir == 3) ? tap2_weight<true>(t[j], cl2, pcz, lkq[adx][0])
-                                           : tap2_weight<true>(t[j], cl2, pcz, lkq[adx][1]);
+                        w[j] = (ir == 1)   ? tap2_weight<false, kLkScalar>(t[j], cl2, pcz, lkq[adx][1])
+                               : (ir == 2) ? tap2_weight<false, kLkScalar>(t[j], cl2, pcz, lkq[adx][0])
+                               : (ir == 3) ? tap2_weight<true, kLkScalar>(t[j], cl2, pcz, lkq[adx][0])
+                                           : tap2_weight<true, kLkScalar>(t[j], cl2, pcz, lkq[adx][1]);
                     }
-#if NEB_ATROUS_PK != 3
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
+                    if constexpr (kPhased)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < ng; ++j) {
                         const float4 tA = gA[g & 1][j];
