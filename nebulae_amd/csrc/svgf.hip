@@ -52,6 +52,9 @@
 #ifndef NEB_ATROUS_PK_FUSED // the same in the fused temporal + level-0 kernel (tap constants as scalar operands of two plain fmas, one texel at a time:
 #define NEB_ATROUS_PK_FUSED 1 // it has no registers to spare; 47.9 -> 46.2 us); 0: A/B arm
 #endif
+#ifndef NEB_ATROUS_PK_CLASSIC // and in the separate levels (row strips, svgf_fuse = 0), which prefetch the next tile's radiance into registers
+#define NEB_ATROUS_PK_CLASSIC 1
+#endif
 #ifndef NEB_ATROUS_STAMPS // diagnostic builds only (tools/atrous_stamps.py): per-wave phase times from s_memtime
 #define NEB_ATROUS_STAMPS 0
 #endif
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
         asm volatile("" : "+v"(cz), "+v"(phiN));
     // the packed tap's constants: {phiNormal, cz}, and per |dx| the pairs {lkp[.][0], lkp[.][1]} and {lkp[.][1], lkp[.][2]} (read straight
     // or swapped by op_sel): 14 registers where the scalar form holds 8
-    constexpr bool kPacked = NEB_ATROUS_PK && R == 2 && (IN == kInLum || (IN == kInFused && NEB_ATROUS_PK_FUSED));
+    constexpr bool kPacked = NEB_ATROUS_PK && R == 2 && (IN == kInLum || (IN == kInFused && NEB_ATROUS_PK_FUSED) || (IN == kInClassic && NEB_ATROUS_PK_CLASSIC));
     constexpr bool kLkScalar = IN != kInLum;
     constexpr bool kPhased = NEB_ATROUS_PK != 3 && IN == kInLum; // (the fused kernel has no registers for a whole group's intermediate values)
     neb_f2 pcz = {phiN, cz}, lkq[3][2];
