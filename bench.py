@@ -57,8 +57,10 @@ def parse(argv=None):
     ap.add_argument("--sort-rays", type=int, default=-1, help="GI ray sorting mask: bit 0 shadow rays, bit 1 bounce rays (-1 = library default)")
     ap.add_argument("--sun-table", type=int, default=int(os.environ.get("NEB_BENCH_SUN_TABLE", "-1")),
                     help="GI sun-visibility table: 1 on, 0 off (every shadow ray traced; same results), -1 = library default (on)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="run the GI stages of frame f+1 on a side stream while frame f is denoised (measured: +1 %%, off by default)")
+    ap.add_argument("--overlap", nargs="?", const="on", default="auto", choices=("auto", "on", "off"),
+                    help="run the GI stages of frame f+1 on a side stream (deferred resolve) while frame f is denoised.  auto (default): only "
+                         "where a rank's strip is at most 0.6 M pixels -- N >= 4 strips of the 1080p frame -- whose short launches leave the chip "
+                         "idle (tools/strip_overlap.py: 135-row strip 207 -> 183 us per frame, 270 rows 270 -> 244, 540 rows +-0, whole frame 4 %% slower)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the weak-scaling leg (the frame that grows with N)")
     ap.add_argument("--scene", default=None, help="a .gltf / .glb file to render instead of the procedural Sponza stand-in "
                     "(e.g. a real sponza-gltf-pbr/Sponza.glb, the reference's default scene: src/Nebulae.cpp:36)")
@@ -411,7 +413,8 @@ class Workload:
         # the G-buffer and the GI records, so they can run on a side stream while frame f is resolved and denoised on the
         # main stream; the two meet at neb_gi_resolve (the reference's separate nrc Resolve step, DeferredRenderer.cpp:586).
         # Measured on MI355X: +1 % (the GI kernels already occupy every wave slot), so it is off by default.
-        self.overlap = do_gi and args.overlap
+        own_px = (self.own[1] - self.own[0]) * GW
+        self.overlap = do_gi and (args.overlap == "on" or (args.overlap == "auto" and world > 1 and own_px <= 600_000))
         self.side = rt.new_stream() if self.overlap else None
         self.resolved = None
         if self.overlap:
@@ -436,6 +439,10 @@ class Workload:
         if self.do_gi:
             if pipelined and self.resolved is not None:
                 self.side.wait_event(self.resolved)  # the previous frame's resolve has consumed the GI records
+            if pipelined and regen_gbuffer:  # the G-buffer of this frame was just rendered on the main stream
+                drawn = self.rt.event(timing=False)
+                drawn.record(stream)
+                self.side.wait_event(drawn)
             r.submit_commands_gi_pathtrace(stream=self.rt.stream_handle(gi_stream))
         if timed_events is not None:
             timed_events["gi1"].record(stream)
@@ -501,7 +508,8 @@ class Workload:
             return "single GPU"
         return (f"row-strips x{self.world} of {p.H // p.N} rows + halo exchange over RCCL: scheme '{p.scheme}' ({p.scheme_reason}; "
                 f"{ {'once': 'one exchange per frame', 'per_level': 'one exchange per a-trous level', 'overlap': 'two exchanges per frame, GI recomputed on the overlap rows'}[p.scheme]}, {p.exchanged_bytes_per_frame() / 1e6:.1f} MB sent "
-                f"per rank and frame), transport '{self.r.exchange}' ({'neb_strips_exchange: grouped ncclSend / ncclRecv' if self.r.exchange == 'rccl' else 'torch.distributed batch_isend_irecv on the planes'})")
+                f"per rank and frame), transport '{self.r.exchange}' ({'neb_strips_exchange: grouped ncclSend / ncclRecv' if self.r.exchange == 'rccl' else 'torch.distributed batch_isend_irecv on the planes'})"
+                + ("; two frames in flight: the GI stages of frame f+1 on a side stream beside the SVGF passes of frame f, meeting at neb_gi_resolve" if self.overlap else ""))
 
     def destroy(self):
         self.r.destroy()
@@ -596,6 +604,7 @@ def main(argv=None, rt=None, emit=None):
     # ---- the primary workload: ONE width x height frame (BASELINE.json configs[2]) on `world` GPUs = `world` row strips ----
     GW, GH = args.width, args.height
     w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme, link=link)
+    frames_in_flight = 2 if w.overlap else 1  # (2: the GI stages of frame f + 1 run on a side stream beside the SVGF passes of frame f)
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
     bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth(), "build_ms": round(r.build_ms(), 2)} if do_gi else None
@@ -728,7 +737,7 @@ def main(argv=None, rt=None, emit=None):
             "config": {"workload": workload_label(GW, GH, args.spp, L, do_gi),
                        "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
                        "parallelism": parallelism, "link": (link.label() if link is not None else None), "halo_rows": halo_rows, "rows_per_strip": GH // world,
-                       "frames_in_flight": 2 if (do_gi and args.overlap) else 1,
+                       "frames_in_flight": frames_in_flight,
                        "scene_device_bytes": scene_bytes, "bvh": bvh, "library_build_id": library_build_id()},
             "frames_per_s_with_final_gather": fps_with_gather,
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,

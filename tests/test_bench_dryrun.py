@@ -111,13 +111,28 @@ class DryRuntime:
                 cur = self.svgf.get_current_resource_index()
                 self.svgf.plane_tensor(PLANE_RADIANCE, cur).copy_(torch.from_numpy(synth.synth_radiance(self._g["base"][r0:r1], 1)))
 
+            def set_defer_resolve(self, on=True):  # (bench.py --overlap: the indirect term stays in the GI records until neb_gi_resolve)
+                self._defer, self._pending = bool(on), None
+
             def submit_commands_gi_pathtrace(self, rows=None, stream=None):
                 own = self.part.gi_rows(self.rank) if rows is None else rows
-                r0, _ = self._rows()
-                cur = self.svgf.get_current_resource_index()
-                t = self.svgf.plane_tensor(PLANE_RADIANCE, cur)
-                t[own[0] - r0:own[1] - r0, :, :3] += 0.01 * float(self.info.frame_index % 7)  # "adds into radiance[cur]"
                 self._rays += 2 * (own[1] - own[0]) * self.part.W * int(self.gi_ui.gi_samples_per_pixel)
+                add = (own, 0.01 * float(self.info.frame_index % 7))
+                if getattr(self, "_defer", False):
+                    self._pending = add
+                else:
+                    self._add(add)
+
+            def submit_commands_gi_resolve(self, stream=None):
+                assert self._defer and self._pending is not None, "neb_gi_resolve: nothing pending"
+                self._add(self._pending)
+                self._pending = None
+
+            def _add(self, add):
+                own, v = add
+                r0, _ = self._rows()
+                t = self.svgf.plane_tensor(PLANE_RADIANCE, self.svgf.get_current_resource_index())
+                t[own[0] - r0:own[1] - r0, :, :3] += v  # "adds into radiance[cur]"
 
             def ray_count(self, reset=False):
                 v = self._rays
@@ -174,6 +189,8 @@ def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     assert cfg["link"].startswith("link measured: ") and "20 exchanges of 4096 B" in cfg["link"] and "of 2097152 B" in cfg["link"]
     if scheme == "auto":
         assert "cost table: once +" in cfg["parallelism"] and "link measured" in cfg["parallelism"]
+    # strips this small run two frames in flight (--overlap auto): GI of frame f + 1 on a side stream, deferred resolve
+    assert cfg["frames_in_flight"] == 2 and "two frames in flight" in cfg["parallelism"]
 
 
 _ARGV = ["--steps", "2", "--warmup", "1", "--width", "64", "--height", "256", "--cpu-frames", "0", "--triangles", "2000", "--tex-size", "16",

@@ -76,7 +76,7 @@ def test_two_rank_rehearsal(scheme):
     launcher = [] if scheme == "once" else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                             "--master-port", str(29650 + (os.getpid() % 200))]
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--cpu-frames", "0", "--gather", "--tex-size", "256"] + (["--config5", "--config5-frames", "4"] if scheme == "once" else [])
+           "--cpu-frames", "0", "--gather", "--tex-size", "256"] + (["--config5", "--config5-frames", "4"] if scheme == "once" else ["--overlap", "on"])
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -86,6 +86,9 @@ def test_two_rank_rehearsal(scheme):
     assert ("one exchange per frame" if scheme == "once" else "one exchange per a-trous level") in d["config"]["parallelism"]
     assert f"scheme '{scheme}'" in d["config"]["parallelism"] and "transport 'torch'" in d["config"]["parallelism"]
     assert d["frames_per_s_with_final_gather"] > 0
+    # 540-row strips keep one frame in flight under --overlap auto; "per_level" forces two: GI of frame f + 1 on a side stream, deferred resolve
+    assert d["config"]["frames_in_flight"] == (1 if scheme == "once" else 2)
+    assert ("two frames in flight" in d["config"]["parallelism"]) == (scheme != "once")
     assert d["config"]["link"].startswith("link measured: ") and d["value_settled"] > 0 and d["warmup_run"] == 2
     assert d["weak_scaling"]["global_height"] == 2160 and d["weak_scaling"]["rows_per_strip"] == 1080 and d["weak_scaling"]["frames_per_s_1080p_equivalents"] > 0
     if scheme == "once":

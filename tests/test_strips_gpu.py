@@ -45,6 +45,55 @@ def test_strips_equal_full_image_gi_plus_svgf(scheme, W, H, N):
     ls.destroy()
 
 
+@pytest.mark.parametrize("W,H,N", [(256, 192, 2), (1920, 1080, 8)])
+def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N):
+    """bench.py --overlap (auto for strips of at most 0.6 M pixels): every strip traces with "gi_defer_resolve" on a side stream and
+    adds its indirect term with neb_gi_resolve on the main stream, after the direct term was written there -- the strips must still
+    equal the full image (fused dispatch, one stream) bit for bit."""
+    L = 5
+    sc = S.atrium_standin(target_triangles=20000, n_submeshes=40, tex_size=32)
+    cam = S.sponza_camera()
+    full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
+    ls = LockstepStrips(W, H, N, L, "once")
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    resolved = None
+    for f in range(1, 5):
+        info = RenderInfo(scene=sc, camera=cam, frame_index=f)
+        full.begin_frame(info)
+        full.submit_commands_gbuffer()
+        full.svgf.plane_tensor(PLANE_RADIANCE, full.svgf.get_current_resource_index()).fill_(0.125)
+        full.submit_commands_gi_pathtrace()
+        for r in ls.rs:
+            r.begin_frame(info)
+            if f == 1:
+                r.set_defer_resolve(True)  # (an option of the GI state: it exists once the first frame has set the scene)
+            r.submit_commands_gbuffer()
+        drawn = torch.cuda.Event()
+        drawn.record(main)
+        side.wait_event(drawn)
+        if resolved is not None:
+            side.wait_event(resolved)  # last frame's resolve has consumed the GI records
+        for r in ls.rs:
+            r.submit_commands_gi_pathtrace(stream=side.cuda_stream)
+            r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).fill_(0.125)  # the direct term, on the main stream
+        traced = torch.cuda.Event()
+        traced.record(side)
+        main.wait_event(traced)
+        for r in ls.rs:
+            r.submit_commands_gi_resolve()
+        resolved = torch.cuda.Event()
+        resolved.record(main)
+        ran_full = full.submit_commands_svgf_denoising()
+        assert all(x == ran_full for x in ls.denoise())
+    torch.cuda.synchronize()
+    want = full.svgf.download(PLANE_RADIANCE)
+    got = ls.image()
+    assert np.isfinite(want).all() and float(np.abs(want[..., :3]).max()) > 0.2
+    assert np.array_equal(got, want)
+    full.destroy()
+    ls.destroy()
+
+
 def test_c_entry_point_exchanges_rows_over_rccl():
     """neb_strips_exchange: grouped ncclSend / ncclRecv straight out of / into the planes, on the caller's stream, through an
     RCCL communicator the library creates itself (librccl resolved at run time).  One GPU: a communicator of one rank that
