@@ -415,10 +415,13 @@ class Workload:
         # Measured on MI355X: +1 % (the GI kernels already occupy every wave slot), so it is off by default.
         own_px = (self.own[1] - self.own[0]) * GW
         self.overlap = do_gi and (args.overlap == "on" or (args.overlap == "auto" and world > 1 and own_px <= 600_000))
-        self.side = rt.new_stream() if self.overlap else None
-        self.resolved = None
+        # ... and on strips of at most 0.3 M pixels (N = 8) on TWO side streams and the library's two record sets ("gi_defer_resolve" = 2): the GI
+        # stages of frame f + 1 also run beside those of frame f (a 135-row strip 183 -> 149 us per frame; 270 rows and more: no further gain)
+        self.depth = (2 if (own_px <= 300_000 or args.overlap == "on") else 1) if self.overlap else 0
+        self.sides = [rt.new_stream() for _ in range(self.depth)]
+        self.resolved = [None] * max(self.depth, 1)
         if self.overlap:
-            r.set_defer_resolve(True)
+            r.set_defer_resolve(self.depth)
 
     def step(self, timed_events=None, cam=None, regen_gbuffer=False):
         torch, r, stream = self.torch, self.r, self.stream
@@ -431,18 +434,20 @@ class Workload:
             r.submit_commands_pbr_lighting()
             self.direct.copy_(self.rad_view[cur], non_blocking=True)  # (kept for the still frames that follow)
         pipelined = self.overlap and timed_events is None
-        gi_stream = self.side if pipelined else stream
+        slot = f % self.depth if self.overlap else 0
+        side = self.sides[slot] if self.overlap else None
+        gi_stream = side if pipelined else stream
         if not self.overlap and not regen_gbuffer:  # PBR pass stand-in (overwrites radiance[cur]); the GI dispatch then adds into it
             self.rad_view[cur].copy_(self.direct if self.do_gi else self.noisy_dev[f % 4], non_blocking=True)
         if timed_events is not None:
             timed_events["gi0"].record(stream)
         if self.do_gi:
-            if pipelined and self.resolved is not None:
-                self.side.wait_event(self.resolved)  # the previous frame's resolve has consumed the GI records
+            if pipelined and self.resolved[slot] is not None:
+                side.wait_event(self.resolved[slot])  # the resolve that consumed this record set
             if pipelined and regen_gbuffer:  # the G-buffer of this frame was just rendered on the main stream
                 drawn = self.rt.event(timing=False)
                 drawn.record(stream)
-                self.side.wait_event(drawn)
+                side.wait_event(drawn)
             r.submit_commands_gi_pathtrace(stream=self.rt.stream_handle(gi_stream))
         if timed_events is not None:
             timed_events["gi1"].record(stream)
@@ -450,12 +455,11 @@ class Workload:
             self.rad_view[cur].copy_(self.direct, non_blocking=True)
             if pipelined:
                 done = self.rt.event(timing=False)
-                done.record(self.side)
+                done.record(side)
                 stream.wait_event(done)
             r.submit_commands_gi_resolve()
-            if pipelined:
-                self.resolved = self.rt.event(timing=False)
-                self.resolved.record(stream)
+            self.resolved[slot] = self.rt.event(timing=False)  # (recorded on the serial, event-timed frames too: the next pipelined frame of this
+            self.resolved[slot].record(stream)                 # parity must not start tracing into the set before this resolve has read it)
         self.ran_svgf.append(r.submit_commands_svgf_denoising(timed_events))
         r.end_frame()
 
@@ -509,7 +513,8 @@ class Workload:
         return (f"row-strips x{self.world} of {p.H // p.N} rows + halo exchange over RCCL: scheme '{p.scheme}' ({p.scheme_reason}; "
                 f"{ {'once': 'one exchange per frame', 'per_level': 'one exchange per a-trous level', 'overlap': 'two exchanges per frame, GI recomputed on the overlap rows'}[p.scheme]}, {p.exchanged_bytes_per_frame() / 1e6:.1f} MB sent "
                 f"per rank and frame), transport '{self.r.exchange}' ({'neb_strips_exchange: grouped ncclSend / ncclRecv' if self.r.exchange == 'rccl' else 'torch.distributed batch_isend_irecv on the planes'})"
-                + ("; two frames in flight: the GI stages of frame f+1 on a side stream beside the SVGF passes of frame f, meeting at neb_gi_resolve" if self.overlap else ""))
+                + (f"; {1 + self.depth} frames in flight: the GI stages of frame f+1 on a side stream beside the SVGF passes of frame f, meeting at neb_gi_resolve"
+                   + (" (two record sets: also beside the GI stages of frame f+2)" if self.depth == 2 else "") if self.overlap else ""))
 
     def destroy(self):
         self.r.destroy()
@@ -604,7 +609,7 @@ def main(argv=None, rt=None, emit=None):
     # ---- the primary workload: ONE width x height frame (BASELINE.json configs[2]) on `world` GPUs = `world` row strips ----
     GW, GH = args.width, args.height
     w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme, link=link)
-    frames_in_flight = 2 if w.overlap else 1  # (2: the GI stages of frame f + 1 run on a side stream beside the SVGF passes of frame f)
+    frames_in_flight = 1 + w.depth  # (2: the GI stages of frame f + 1 run on a side stream beside the SVGF passes of frame f; 3: and beside those of frame f + 2)
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
     bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth(), "build_ms": round(r.build_ms(), 2)} if do_gi else None

@@ -114,6 +114,10 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *                     on for dispatches of 1.5 M pixels and more, off for smaller ones, where the sort costs more than it saves),
  *                     bit 1 = sort the bounce rays by direction octant + origin (default off);
  *   "gi_defer_resolve": 1 = neb_gi_trace leaves the frame's indirect term in its records; neb_gi_resolve adds it;
+ *                       2 = the same on TWO sets of records, used alternately: a second neb_gi_trace (the next frame's, on another stream)
+ *                       may be issued and run before the first one's neb_gi_resolve has executed; neb_gi_resolve retires the dispatches in
+ *                       the order they were traced.  The caller orders the streams: a trace must not start before the resolve that read
+ *                       its set (two traces earlier) has finished, a resolve not before its own trace has;
  *   "gi_exact_shade":   1 = hit shading in the C arithmetic of the CPU oracle (IEEE division, sqrt, powf, sinf / cosf) instead of
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;

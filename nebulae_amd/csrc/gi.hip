@@ -923,6 +923,10 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     GI_GUARD(ctx);
     ScopedRange range("GI: Query Pass"); // "GI: NRC Query Pass", DeferredRenderer.cpp:434 (the NRC calls are stubbed here)
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
+    // the set of per-dispatch buffers: with "gi_defer_resolve" = 2 two deferred dispatches may be in flight (on two streams), on alternating sets
+    if (g->defer_resolve == 2 && g->traces - g->resolves >= 2u)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: both record sets hold a dispatch that neb_gi_resolve has not retired yet");
+    GiState::DispatchSet& ds = g->sets[g->defer_resolve == 2 ? (g->traces & 1u) : 0u];
     if (g->debug_hits && !g->d_hits) {
         void* p = nullptr;
         GI_HIP(ctx, hipMalloc(&p, npx * sizeof(neb_gi_hit)));
@@ -930,21 +934,21 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         g->allocs.push_back(p);
         g->d_hits = (neb_gi_hit*)p;
     }
-    if (!g->d_records) {
+    if (!ds.d_records) {
         void* p = nullptr;
         GI_HIP(ctx, hipMalloc(&p, npx * sizeof(float4) * 9));
         g->allocs.push_back(p);
-        g->d_records = (float4*)p;
+        ds.d_records = (float4*)p;
     }
     GiArgs a;
     a.S = g->view;
     a.c = *c;
-    a.R.ray_o = g->d_records;
-    a.R.ray_d = g->d_records + npx;
-    a.R.hit = g->d_records + 2 * npx;
-    a.R.path = g->d_records + 3 * npx;
-    a.R.state = g->d_records + 4 * npx;
-    a.R.srec = g->d_records + 5 * npx;
+    a.R.ray_o = ds.d_records;
+    a.R.ray_d = ds.d_records + npx;
+    a.R.hit = ds.d_records + 2 * npx;
+    a.R.path = ds.d_records + 3 * npx;
+    a.R.state = ds.d_records + 4 * npx;
+    a.R.srec = ds.d_records + 5 * npx;
     a.albedo = (const uint32_t*)ctx->planes[NEB_PLANE_ALBEDO][0];
     a.rough_metal = (const uint32_t*)ctx->planes[NEB_PLANE_ROUGH_METAL][0];
     a.world_pos = (const uint2*)ctx->planes[NEB_PLANE_WORLDPOS][0];
@@ -980,61 +984,63 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     const bool compact = a.sun_table && g->compact_shadow;
     const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
     if (sort_shadow || g->sort_bounce) {
-        if (!g->d_sort) {
+        if (!ds.d_sort) {
             void* p = nullptr;
             GI_HIP(ctx, hipMalloc(&p, 8 * npx * sizeof(uint32_t))); // {keys, vals, keys_out, vals_out} x {shadow, bounce}
             g->allocs.push_back(p);
-            g->d_sort = (uint32_t*)p;
+            ds.d_sort = (uint32_t*)p;
             const size_t bytes = ray_sort_scratch_bytes(npx);
             GI_HIP(ctx, hipMalloc(&p, bytes));
             g->allocs.push_back(p);
-            g->d_sort_temp = p;
+            ds.d_sort_temp = p;
             g->sort_temp_bytes = bytes;
         }
         if (sort_shadow) {
-            a.sort_keys = g->d_sort;
-            a.sort_vals = g->d_sort + npx;
+            a.sort_keys = ds.d_sort;
+            a.sort_vals = ds.d_sort + npx;
         }
         if (g->sort_bounce) {
-            a.bsort_keys = g->d_sort + 4 * npx;
-            a.bsort_vals = g->d_sort + 5 * npx;
+            a.bsort_keys = ds.d_sort + 4 * npx;
+            a.bsort_vals = ds.d_sort + 5 * npx;
             a.raygen_only = 1;
         }
     }
     a.defer_resolve = g->defer_resolve ? 1u : 0u;
-    g->pending_spp = c->samplesPerPixel;
-    g->pending_row0 = row0;
-    g->pending_row1 = row1;
+    ds.pending_spp = c->samplesPerPixel;
+    ds.pending_row0 = row0;
+    ds.pending_row1 = row1;
+    if (g->defer_resolve == 2)
+        g->traces++;
     const uint32_t tiles_y = (row1 - row0 + 7) / 8;
     const dim3 grid(a.tiles_x * tiles_y), block(64);
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
-    if (!g->d_block_counts) {
+    if (!ds.d_block_counts) {
         void* p = nullptr;
         GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow answered by the sun table} rays per workgroup
         GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
-        g->d_block_counts = (uint32_t*)p;
+        ds.d_block_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
-    a.bounce_counts = g->d_block_counts;
-    a.shadow_counts = g->d_block_counts + g->n_block_counts;
-    a.table_counts = g->d_block_counts + 2 * g->n_block_counts;
+    a.bounce_counts = ds.d_block_counts;
+    a.shadow_counts = ds.d_block_counts + g->n_block_counts;
+    a.table_counts = ds.d_block_counts + 2 * g->n_block_counts;
     a.list = nullptr;
     a.list_counts = nullptr;
     a.list_cap = a.list_set = 0;
     uint32_t list_waves = 0;
     if (compact) {
         const uint32_t wg_per_list = (uint32_t)((g->n_block_counts + kListSegments - 1) / kListSegments);
-        if (!g->d_list) {
+        if (!ds.d_list) {
             void* p = nullptr;
             // (64 bytes per slot, a slot per pixel: what the per-pixel shadow-record plane takes; the two counter sets sit in front)
             GI_HIP(ctx, hipMalloc(&p, (size_t)kListSegments * wg_per_list * 64u * 64u + 4096u));
             GI_HIP(ctx, hipMemset(p, 0, 4096u));
             g->allocs.push_back(p);
-            g->d_list = (uint32_t*)p;
+            ds.d_list = (uint32_t*)p;
         }
-        a.list_counts = g->d_list;
-        a.list = (float4*)((char*)g->d_list + 4096);
+        a.list_counts = ds.d_list;
+        a.list = (float4*)((char*)ds.d_list + 4096);
         a.list_cap = wg_per_list * 64u;
         list_waves = kListSegments * (wg_per_list < kListChunks ? wg_per_list : kListChunks);
     }
@@ -1047,16 +1053,16 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
                 hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
             }
             if (g->sort_bounce) {
-                uint32_t* bs = g->d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
+                uint32_t* bs = ds.d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
                 GI_HIP(ctx, ray_sort_pairs(bs + a.first_px, bs + npx + a.first_px, bs + 2 * npx + a.first_px, bs + 3 * npx + a.first_px,
-                                           bs + npx + a.first_px, a.n_px, kSortBits, g->d_sort_temp, (hipStream_t)stream));
+                                           bs + npx + a.first_px, a.n_px, kSortBits, ds.d_sort_temp, (hipStream_t)stream));
                 GiArgs b1 = a;
                 b1.sort_order = bs + npx + a.first_px;
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, dim3((a.n_px + 63) / 64), block, 0, (hipStream_t)stream, b1);
             } else if (b > 1) {
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             }
-            a.list_set = g->list_epoch & 1u;
+            a.list_set = ds.list_epoch & 1u;
             if (kFastShade && !g->exact_shade)
                 hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
             else
@@ -1066,15 +1072,15 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
                     hipLaunchKernelGGL(gi_shadow_list_kernel<true>, dim3(list_waves), block, 0, (hipStream_t)stream, a);
                 else
                     hipLaunchKernelGGL(gi_shadow_list_kernel<false>, dim3(list_waves), block, 0, (hipStream_t)stream, a);
-                g->list_epoch++;
+                ds.list_epoch++;
             } else if (sort_shadow) {
                 // {keys, vals} are the shade kernel's output and the sort's ping; {keys_tmp, vals_tmp} its pong; the
                 // sorted pixel indices land back in vals
-                GI_HIP(ctx, ray_sort_pairs(g->d_sort + a.first_px, g->d_sort + npx + a.first_px, g->d_sort + 2 * npx + a.first_px,
-                                           g->d_sort + 3 * npx + a.first_px, g->d_sort + npx + a.first_px, a.n_px, kSortBits, g->d_sort_temp,
+                GI_HIP(ctx, ray_sort_pairs(ds.d_sort + a.first_px, ds.d_sort + npx + a.first_px, ds.d_sort + 2 * npx + a.first_px,
+                                           ds.d_sort + 3 * npx + a.first_px, ds.d_sort + npx + a.first_px, a.n_px, kSortBits, ds.d_sort_temp,
                                            (hipStream_t)stream));
                 GiArgs b2 = a;
-                b2.sort_order = g->d_sort + npx + a.first_px;
+                b2.sort_order = ds.d_sort + npx + a.first_px;
                 hipLaunchKernelGGL(gi_shadow_trace_kernel, dim3((a.n_px + 63) / 64), block, 0, (hipStream_t)stream, b2);
             } else {
                 hipLaunchKernelGGL(gi_shadow_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
@@ -1092,16 +1098,21 @@ int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
     if (int rc = neb::svgf_flush_pending(ctx))
         return rc;
     GiState* g = ctx->gi;
-    if (!g || !g->d_records || !g->defer_resolve)
+    if (!g || !g->defer_resolve || (g->defer_resolve == 2 && g->resolves == g->traces))
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
-    if (g->pending_row1 <= g->pending_row0)
+    GiState::DispatchSet& ds = g->sets[g->defer_resolve == 2 ? (g->resolves & 1u) : 0u]; // (two sets: the oldest dispatch first)
+    if (!ds.d_records)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
+    if (g->defer_resolve == 2)
+        g->resolves++;
+    if (ds.pending_row1 <= ds.pending_row0)
         return NEB_OK;
     GI_GUARD(ctx);
     ScopedRange range("GI: Resolve query data"); // "GI: Resolve NRC query data", DeferredRenderer.cpp:567
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);
-    const size_t first = (size_t)(g->pending_row0 - ctx->row_begin) * ctx->W, n = (size_t)(g->pending_row1 - g->pending_row0) * ctx->W;
+    const size_t first = (size_t)(ds.pending_row0 - ctx->row_begin) * ctx->W, n = (size_t)(ds.pending_row1 - ds.pending_row0) * ctx->W;
     hipLaunchKernelGGL(gi_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], g->d_records + 5 * npx, first, n, 1.0f / (float)g->pending_spp);
+                       (float4*)ctx->planes[NEB_PLANE_RADIANCE][ctx->cur], ds.d_records + 5 * npx, first, n, 1.0f / (float)ds.pending_spp);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
 }
@@ -1132,17 +1143,17 @@ int neb_pbr_direct(neb_ctx* ctx, const neb_gi_constants* c, neb_stream stream)
     a.tiles_x = (ctx->W + 7) / 8; // Dispatch((W+7)/8, (H+7)/8): DeferredRenderer.cpp:382
     const uint32_t tiles_y = (a.row1 - a.row0 + 7) / 8;
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
-    if (!g->d_block_counts) {
+    if (!g->d_direct_counts) {
         void* p = nullptr;
         GI_HIP(ctx, hipMalloc(&p, 3 * n_blocks * sizeof(uint32_t))); // {bounce, shadow, shadow answered by the sun table} rays per workgroup
         GI_HIP(ctx, hipMemset(p, 0, 3 * n_blocks * sizeof(uint32_t)));
         g->allocs.push_back(p);
-        g->d_block_counts = (uint32_t*)p;
+        g->d_direct_counts = (uint32_t*)p;
         g->n_block_counts = n_blocks;
     }
-    a.bounce_counts = g->d_block_counts;
-    a.shadow_counts = g->d_block_counts + g->n_block_counts;
-    a.table_counts = g->d_block_counts + 2 * g->n_block_counts;
+    a.bounce_counts = g->d_direct_counts;
+    a.shadow_counts = g->d_direct_counts + g->n_block_counts;
+    a.table_counts = g->d_direct_counts + 2 * g->n_block_counts;
     hipLaunchKernelGGL(pbr_direct_kernel, dim3(a.tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream, a);
     GI_HIP(ctx, hipGetLastError());
     return NEB_OK;
@@ -1178,22 +1189,27 @@ int neb_gi_ray_count(neb_ctx* ctx, uint64_t* rays, int reset, neb_stream stream)
     GiState* g = ctx->gi;
     GI_GUARD(ctx);
     unsigned long long v[16] = {};
-    std::vector<uint32_t> counts(3 * g->n_block_counts);
+    uint32_t* arrays[3] = {g->sets[0].d_block_counts, g->sets[1].d_block_counts, g->d_direct_counts}; // (every dispatch set, and the direct pass)
+    const size_t n3 = 3 * g->n_block_counts;
+    std::vector<uint32_t> counts(3 * n3);
     GI_HIP(ctx, hipMemcpyAsync(v, g->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    if (g->d_block_counts)
-        GI_HIP(ctx, hipMemcpyAsync(counts.data(), g->d_block_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                   (hipStream_t)stream));
+    for (int q = 0; q < 3; ++q)
+        if (arrays[q])
+            GI_HIP(ctx, hipMemcpyAsync(counts.data() + q * n3, arrays[q], n3 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GI_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     if (reset) {
         GI_HIP(ctx, hipMemsetAsync(g->d_ray_counter, 0, sizeof(v), (hipStream_t)stream));
-        if (g->d_block_counts)
-            GI_HIP(ctx, hipMemsetAsync(g->d_block_counts, 0, counts.size() * sizeof(uint32_t), (hipStream_t)stream));
+        for (int q = 0; q < 3; ++q)
+            if (arrays[q])
+                GI_HIP(ctx, hipMemsetAsync(arrays[q], 0, n3 * sizeof(uint32_t), (hipStream_t)stream));
     }
     unsigned long long total = 0, table = 0;
-    for (size_t k = 0; k < 2 * g->n_block_counts; ++k)
-        total += counts[k];
-    for (size_t k = 2 * g->n_block_counts; k < counts.size(); ++k)
-        table += counts[k];
+    for (int q = 0; q < 3; ++q) {
+        for (size_t k = 0; k < 2 * g->n_block_counts; ++k)
+            total += counts[q * n3 + k];
+        for (size_t k = 2 * g->n_block_counts; k < n3; ++k)
+            table += counts[q * n3 + k];
+    }
     g->table_rays = table;
     v[0] = total;
     if (rays)
@@ -1331,7 +1347,13 @@ int gi_set_defer_resolve(neb_ctx* ctx, int on)
 {
     if (!ctx->gi)
         return NEB_ERR_STATE;
-    ctx->gi->defer_resolve = on != 0;
+    if (on < 0 || on > 2)
+        return NEB_ERR_STATE;
+    GiState* g = ctx->gi;
+    if (g->defer_resolve == 2 && g->traces != g->resolves)
+        return NEB_ERR_STATE; // (a traced dispatch still waits for its neb_gi_resolve)
+    g->defer_resolve = on;
+    g->traces = g->resolves = 0;
     return NEB_OK;
 }
 int gi_set_sun_table(neb_ctx* ctx, int on)

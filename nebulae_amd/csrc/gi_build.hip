@@ -20,7 +20,13 @@ void gi_on_resize(GiState* g)
 {
     if (!g)
         return;
-    void* stale[] = {g->d_records, g->d_hits, g->d_block_counts, g->d_sort, g->d_sort_temp, g->d_list};
+    std::vector<void*> stale = {g->d_hits, g->d_direct_counts};
+    for (GiState::DispatchSet& ds : g->sets) {
+        for (void* p : {(void*)ds.d_records, (void*)ds.d_block_counts, (void*)ds.d_sort, ds.d_sort_temp, (void*)ds.d_list})
+            stale.push_back(p);
+        ds = GiState::DispatchSet{};
+    }
+    g->traces = g->resolves = 0;
     for (void* p : stale) {
         if (!p)
             continue;
@@ -31,13 +37,9 @@ void gi_on_resize(GiState* g)
             }
         (void)hipFree(p);
     }
-    g->d_records = nullptr;
     g->d_hits = nullptr;
-    g->d_block_counts = nullptr;
+    g->d_direct_counts = nullptr;
     g->n_block_counts = 0;
-    g->d_sort = nullptr;
-    g->d_sort_temp = nullptr;
-    g->d_list = nullptr;
 }
 
 void gi_destroy(GiState* g)

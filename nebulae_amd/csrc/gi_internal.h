@@ -159,18 +159,26 @@ struct GiState {
     unsigned long long* d_ray_counter = nullptr;
     neb_gi_hit* d_hits = nullptr;
     bool debug_hits = false;
-    float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
+    // What ONE dispatch of neb_gi_trace writes besides radiance[cur].  Two sets ("gi_defer_resolve" = 2): the GI stages of two frames may be in flight
+    // on two streams, each on its own set; neb_gi_resolve retires them in the order they were traced.
+    struct DispatchSet {
+        float4* d_records = nullptr; // 5 float4 planes + one 4 x float4 record plane over the resident pixels (GiRecords)
+        uint32_t* d_sort = nullptr;  // 4 x npx uint32: keys, vals, keys_out, vals_out
+        void* d_sort_temp = nullptr;
+        uint32_t* d_block_counts = nullptr; // [3][n_block_counts]: bounce rays / shadow rays / shadow rays answered by the sun table, per workgroup
+        uint32_t* d_list = nullptr;  // [2][kListSegments] counters, then [kListSegments][cap] ray records
+        uint32_t list_epoch = 0;     // shade launches so far: picks the counter set
+        uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
+    } sets[2];
+    uint32_t traces = 0, resolves = 0; // deferred dispatches issued / retired (set = count & 1 with two sets)
+    uint32_t* d_direct_counts = nullptr; // neb_pbr_direct's own per-workgroup ray counts (it may run beside a GI dispatch)
     unsigned long long last_stats[16] = {};
-    bool defer_resolve = false;
+    int defer_resolve = 0; // "gi_defer_resolve": 0 fused; 1 the indirect term waits in the records for neb_gi_resolve; 2 the same on two record sets
     bool exact_shade = false; // "gi_exact_shade": gi_shade_kernel<false>, the oracle's C arithmetic
     bool sort_shadow = true;  // "gi_sort_rays" bit 0
     bool sort_shadow_auto = true; // until "gi_sort_rays" is set: sort the shadow rays of dispatches of 1.5 M pixels and more only
     bool sort_bounce = false; // "gi_sort_rays" bit 1
-    uint32_t* d_sort = nullptr;      // 4 x npx uint32: keys, vals, keys_out, vals_out
-    void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
-    uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
-    uint32_t* d_block_counts = nullptr; // [3][n_block_counts]: bounce rays / shadow rays / shadow rays answered by the sun table, per workgroup
     size_t n_block_counts = 0;
     // the sun-visibility table in the shading records (gi_sun_table.hip)
     bool sun_table = true;            // option "gi_sun_table"
@@ -181,8 +189,6 @@ struct GiState {
     uint32_t sun_table_builds = 0;
     unsigned long long table_rays = 0; // shadow rays answered by the table as of the last neb_gi_ray_count
     bool compact_shadow = true;       // with the table on: the rays it leaves are compacted into lists by the shade pass ("gi_sun_table" = 2: off)
-    uint32_t* d_list = nullptr;       // [2][kListSegments] counters, then [kListSegments][cap] pixel indices
-    uint32_t list_epoch = 0;          // shade launches so far: picks the counter set
 };
 hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream);
 

@@ -234,8 +234,13 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         return hipSuccess;
     const float key[4] = {c.sunLightDirection[0], c.sunLightDirection[1], c.sunLightDirection[2], c.sunTanHalfAngle};
     const bool want = g->sun_table;
+    // The flags live in the shading records every dispatch reads.  With two dispatches in flight ("gi_defer_resolve" = 2) the other one may still
+    // be running on another stream: whatever rewrites the flags first waits for the device (a change of sun or of the option -- never a steady frame).
+    auto quiesce = [&]() { return g->defer_resolve == 2 ? hipDeviceSynchronize() : hipSuccess; };
     if (!want) {
         if (g->sun_table_state != 0) {
+            if (hipError_t e = quiesce(); e != hipSuccess)
+                return e;
             hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->view.n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->view.n_tris);
             g->sun_table_state = 0;
         }
@@ -256,8 +261,11 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     }
     const float dd = key[0] * key[0] + key[1] * key[1] + key[2] * key[2];
     if (!(dd > 0.0f) || !(dd < 1e30f) || !(key[3] >= 0.0f) || !(key[3] < 1.0f)) { // no usable sun: no certificate, every ray is traced
-        if (g->sun_table_state != 0)
+        if (g->sun_table_state != 0) {
+            if (hipError_t e = quiesce(); e != hipSuccess)
+                return e;
             hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->view.n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->view.n_tris);
+        }
         g->sun_table_state = 0;
         return hipGetLastError();
     }
@@ -269,7 +277,10 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         g->allocs.push_back(p);
         g->d_sun_counts = (unsigned long long*)p;
     }
-    hipError_t e = hipMemsetAsync(g->d_sun_counts, 0, 4 * sizeof(unsigned long long), stream);
+    hipError_t e = quiesce();
+    if (e != hipSuccess)
+        return e;
+    e = hipMemsetAsync(g->d_sun_counts, 0, 4 * sizeof(unsigned long long), stream);
     if (e != hipSuccess)
         return e;
     SunTableArgs a;

@@ -112,6 +112,7 @@ class DryRuntime:
                 self.svgf.plane_tensor(PLANE_RADIANCE, cur).copy_(torch.from_numpy(synth.synth_radiance(self._g["base"][r0:r1], 1)))
 
             def set_defer_resolve(self, on=True):  # (bench.py --overlap: the indirect term stays in the GI records until neb_gi_resolve)
+                assert int(on) in (0, 1, 2)
                 self._defer, self._pending = bool(on), None
 
             def submit_commands_gi_pathtrace(self, rows=None, stream=None):
@@ -190,7 +191,7 @@ def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     if scheme == "auto":
         assert "cost table: once +" in cfg["parallelism"] and "link measured" in cfg["parallelism"]
     # strips this small run two frames in flight (--overlap auto): GI of frame f + 1 on a side stream, deferred resolve
-    assert cfg["frames_in_flight"] == 2 and "two frames in flight" in cfg["parallelism"]
+    assert cfg["frames_in_flight"] == 3 and "3 frames in flight" in cfg["parallelism"] and "two record sets" in cfg["parallelism"]
 
 
 _ARGV = ["--steps", "2", "--warmup", "1", "--width", "64", "--height", "256", "--cpu-frames", "0", "--triangles", "2000", "--tex-size", "16",

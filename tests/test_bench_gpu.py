@@ -86,9 +86,9 @@ def test_two_rank_rehearsal(scheme):
     assert ("one exchange per frame" if scheme == "once" else "one exchange per a-trous level") in d["config"]["parallelism"]
     assert f"scheme '{scheme}'" in d["config"]["parallelism"] and "transport 'torch'" in d["config"]["parallelism"]
     assert d["frames_per_s_with_final_gather"] > 0
-    # 540-row strips keep one frame in flight under --overlap auto; "per_level" forces two: GI of frame f + 1 on a side stream, deferred resolve
-    assert d["config"]["frames_in_flight"] == (1 if scheme == "once" else 2)
-    assert ("two frames in flight" in d["config"]["parallelism"]) == (scheme != "once")
+    # 540-row strips keep one frame in flight under --overlap auto; "per_level" forces the pipelined form: GI of frames f + 1 and f + 2 on two side streams and two record sets, deferred resolve
+    assert d["config"]["frames_in_flight"] == (1 if scheme == "once" else 3)
+    assert ("3 frames in flight" in d["config"]["parallelism"]) == (scheme != "once")
     assert d["config"]["link"].startswith("link measured: ") and d["value_settled"] > 0 and d["warmup_run"] == 2
     assert d["weak_scaling"]["global_height"] == 2160 and d["weak_scaling"]["rows_per_strip"] == 1080 and d["weak_scaling"]["frames_per_s_1080p_equivalents"] > 0
     if scheme == "once":

@@ -7,6 +7,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch
 
 from nebulae_amd import scene as S
 from nebulae_amd.renderer import DeferredRenderer, RenderInfo
@@ -238,9 +239,11 @@ def test_multi_bounce_matches_oracle(max_vertices, spp, sort_rays):
     r.destroy()
 
 
-def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact(depth):
     """neb_gi_trace with "gi_defer_resolve" + neb_gi_resolve == the fused dispatch, and running the GI stages of frame
-    f+1 on a side stream while frame f is denoised gives the same frames bit for bit."""
+    f+1 on a side stream while frame f is denoised gives the same frames bit for bit -- with one record set and one side stream, and with
+    two of each ("gi_defer_resolve" = 2: the GI stages of frames f+1 and f+2 may both be in flight)."""
     import torch
     make, cam, W, H = scenes()["atrium_small"]
     sc = make()
@@ -249,7 +252,7 @@ def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact():
         r = DeferredRenderer()
         r.init(W, H, atrous_levels=4)
         main = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        sides = [torch.cuda.Stream() for _ in range(depth)]
         r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=main.cuda_stream))
         r.submit_commands_gbuffer()
         torch.cuda.synchronize()
@@ -259,22 +262,23 @@ def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact():
         rad = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
         direct = torch.full_like(rad[0], 0.125)
         if mode == "pipelined":
-            r.set_defer_resolve(True)
-        resolved = None
-        for f in range(2, 9):
+            r.set_defer_resolve(depth)
+        resolved = [None] * depth
+        for f in range(2, 11):
+            side, slot = sides[f % depth], f % depth
             r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=main.cuda_stream))
             cur = r.svgf.get_current_resource_index()
             if mode == "pipelined":
-                if resolved is not None:
-                    side.wait_event(resolved)
+                if resolved[slot] is not None:
+                    side.wait_event(resolved[slot])
                 r.submit_commands_gi_pathtrace(stream=side.cuda_stream)
                 rad[cur].copy_(direct, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(side)
                 main.wait_event(done)
                 r.submit_commands_gi_resolve()
-                resolved = torch.cuda.Event()
-                resolved.record(main)
+                resolved[slot] = torch.cuda.Event()
+                resolved[slot].record(main)
             else:
                 rad[cur].copy_(direct, non_blocking=True)
                 r.submit_commands_gi_pathtrace()
@@ -285,6 +289,44 @@ def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact():
         r.destroy()
     assert float(np.abs(outs[0][..., :3]).max()) > 0.2
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_two_record_sets_hold_two_dispatches_and_refuse_a_third():
+    """"gi_defer_resolve" = 2: two traced dispatches may wait for their neb_gi_resolve at once (each on its own set of records, retired in the
+    order they were traced); a third is refused, and so is a resolve with nothing pending or a change of the option in between."""
+    from nebulae_amd.svgf import NebError
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    outs = []
+    for mode in ("fused", "two sets"):
+        r = DeferredRenderer()
+        r.init(W, H, atrous_levels=2)
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=3))
+        r.submit_commands_gbuffer()
+        rad = r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index())
+        rad.zero_()
+        if mode == "fused":
+            r.submit_commands_gi_pathtrace()
+        else:
+            r.set_defer_resolve(2)
+            r.submit_commands_gi_pathtrace()
+            r.submit_commands_gi_pathtrace()  # (the same frame again: the same indirect term, in the other set)
+            with pytest.raises(NebError):
+                r.submit_commands_gi_pathtrace()
+            with pytest.raises(NebError):
+                r.set_defer_resolve(1)
+            torch.cuda.synchronize()
+            assert float(rad.abs().max()) == 0.0  # nothing has touched radiance[cur] yet
+            r.submit_commands_gi_resolve()
+            r.submit_commands_gi_resolve()
+            with pytest.raises(NebError):
+                r.submit_commands_gi_resolve()
+            r.set_defer_resolve(0)
+        torch.cuda.synchronize()
+        outs.append(rad.cpu().numpy().copy())
+        r.destroy()
+    assert float(np.abs(outs[0][..., :3]).max()) > 0.05
+    assert np.array_equal(outs[1][..., :3], 2.0 * outs[0][..., :3])  # s + s, exactly
 
 
 def test_resize_recreates_planes_and_gi_buffers():

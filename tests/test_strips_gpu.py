@@ -45,8 +45,8 @@ def test_strips_equal_full_image_gi_plus_svgf(scheme, W, H, N):
     ls.destroy()
 
 
-@pytest.mark.parametrize("W,H,N", [(256, 192, 2), (1920, 1080, 8)])
-def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N):
+@pytest.mark.parametrize("W,H,N,depth", [(256, 192, 2, 1), (256, 192, 2, 2), (1920, 1080, 8, 2)])
+def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N, depth):
     """bench.py --overlap (auto for strips of at most 0.6 M pixels): every strip traces with "gi_defer_resolve" on a side stream and
     adds its indirect term with neb_gi_resolve on the main stream, after the direct term was written there -- the strips must still
     equal the full image (fused dispatch, one stream) bit for bit."""
@@ -55,9 +55,10 @@ def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N):
     cam = S.sponza_camera()
     full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
     ls = LockstepStrips(W, H, N, L, "once")
-    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
-    resolved = None
-    for f in range(1, 5):
+    main, sides = torch.cuda.current_stream(), [torch.cuda.Stream() for _ in range(depth)]
+    resolved = [None] * depth  # depth 2: "gi_defer_resolve" = 2, two record sets used alternately, the GI stages of two frames in flight
+    for f in range(1, 7):
+        side, slot = sides[f % depth], f % depth
         info = RenderInfo(scene=sc, camera=cam, frame_index=f)
         full.begin_frame(info)
         full.submit_commands_gbuffer()
@@ -66,13 +67,13 @@ def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N):
         for r in ls.rs:
             r.begin_frame(info)
             if f == 1:
-                r.set_defer_resolve(True)  # (an option of the GI state: it exists once the first frame has set the scene)
+                r.set_defer_resolve(depth)  # (an option of the GI state: it exists once the first frame has set the scene)
             r.submit_commands_gbuffer()
         drawn = torch.cuda.Event()
         drawn.record(main)
         side.wait_event(drawn)
-        if resolved is not None:
-            side.wait_event(resolved)  # last frame's resolve has consumed the GI records
+        if resolved[slot] is not None:
+            side.wait_event(resolved[slot])  # the resolve that consumed this record set
         for r in ls.rs:
             r.submit_commands_gi_pathtrace(stream=side.cuda_stream)
             r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).fill_(0.125)  # the direct term, on the main stream
@@ -81,8 +82,8 @@ def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N):
         main.wait_event(traced)
         for r in ls.rs:
             r.submit_commands_gi_resolve()
-        resolved = torch.cuda.Event()
-        resolved.record(main)
+        resolved[slot] = torch.cuda.Event()
+        resolved[slot].record(main)
         ran_full = full.submit_commands_svgf_denoising()
         assert all(x == ran_full for x in ls.denoise())
     torch.cuda.synchronize()

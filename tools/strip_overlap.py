@@ -42,20 +42,24 @@ def frame(r, direct, stream, f):
         r.end_frame()
 
 
-def frame_pipelined(r, direct, main, side, f, state):
-    """the GI stages of frame f on the side stream (deferred resolve), beside the SVGF passes of frame f - 1 on the main stream (bench.py --overlap)"""
+def frame_pipelined(r, direct, main, sides, f, state):
+    """the GI stages of frame f on a side stream (deferred resolve), beside the SVGF passes of frame f - 1 on the main stream (bench.py --overlap);
+    with two side streams (and the library's two record sets, "gi_defer_resolve" = 2) also beside the GI stages of frame f - 1"""
+    side = sides[f % len(sides)]
     with torch.cuda.stream(main):
         r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=main.cuda_stream))
-        if state.get("resolved") is not None:
-            side.wait_event(state["resolved"])
+        ev = state.get(("resolved", f % len(sides)))
+        if ev is not None:
+            side.wait_event(ev)  # the resolve that consumed this record set
         r.submit_commands_gi_pathtrace(stream=side.cuda_stream)
         r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).copy_(direct, non_blocking=True)
         done = torch.cuda.Event()
         done.record(side)
         main.wait_event(done)
         r.submit_commands_gi_resolve()
-        state["resolved"] = torch.cuda.Event()
-        state["resolved"].record(main)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        state[("resolved", f % len(sides))] = ev
         r.submit_commands_svgf_denoising()
         r.end_frame()
 
@@ -79,18 +83,22 @@ for N in (8, 4, 2, 1):
         print(f"N = {N}: {K} strip renderer(s) in flight: host {(t1 - t0) / (n * K) * 1e6:.0f} us per frame; wall {(t2 - t0) / (n * K) * 1e6:.0f} us per frame "
               f"({(t2 - t0) / n * 1e6:.0f} us per round of {K})", flush=True)
     r, direct = rs[0]
-    r.set_defer_resolve(True)
-    main, side, state = streams[0], streams[1], {}
-    for f in range(200, 260):
-        frame_pipelined(r, direct, main, side, f, state)
-    torch.cuda.synchronize()
-    n = 100
-    t0 = time.perf_counter()
-    for f in range(260, 260 + n):
-        frame_pipelined(r, direct, main, side, f, state)
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print(f"N = {N}: ONE renderer, GI of frame f + 1 on a side stream beside the SVGF passes of frame f: host {(t1 - t0) / n * 1e6:.0f} us per frame; wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
+    extra = torch.cuda.Stream()
+    for depth in (1, 2):
+        torch.cuda.synchronize()
+        r.set_defer_resolve(depth)
+        main, sides, state = streams[0], [streams[1], extra][:depth], {}
+        for f in range(200, 260):
+            frame_pipelined(r, direct, main, sides, f, state)
+        torch.cuda.synchronize()
+        n = 100
+        t0 = time.perf_counter()
+        for f in range(260, 260 + n):
+            frame_pipelined(r, direct, main, sides, f, state)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"N = {N}: ONE renderer, GI of frame f + 1 on a side stream beside the SVGF passes of frame f, {depth} record set(s) / side stream(s): "
+              f"host {(t1 - t0) / n * 1e6:.0f} us per frame; wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
     for r, _ in rs:
         r.destroy()
