@@ -412,7 +412,8 @@ class Workload:
         # Optional frames in flight (the reference keeps 3, src/nri/Swapchain.h:15): the GI stages of frame f+1 touch only
         # the G-buffer and the GI records, so they can run on a side stream while frame f is resolved and denoised on the
         # main stream; the two meet at neb_gi_resolve (the reference's separate nrc Resolve step, DeferredRenderer.cpp:586).
-        # Measured on MI355X: +1 % (the GI kernels already occupy every wave slot), so it is off by default.
+        # Measured on MI355X: a whole 1080p frame gains nothing (the GI kernels already occupy every wave slot: 643 -> 669 us), a strip does --
+        # its short launches leave the chip idle (tools/strip_overlap.py); hence `--overlap auto`:
         own_px = (self.own[1] - self.own[0]) * GW
         self.overlap = do_gi and (args.overlap == "on" or (args.overlap == "auto" and world > 1 and own_px <= 600_000))
         # ... and on strips of at most 0.3 M pixels (N = 8) on TWO side streams and the library's two record sets ("gi_defer_resolve" = 2): the GI
