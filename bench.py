@@ -356,6 +356,10 @@ class GpuRuntime:
     def event(self, timing=True):
         return self.torch.cuda.Event(enable_timing=timing)
 
+    def event_handle(self, event):
+        """the raw hipEvent_t of a torch event that has been recorded at least once"""
+        return event.cuda_event
+
     def to_device(self, t):
         return t.cuda()
 
@@ -409,20 +413,33 @@ class Workload:
             self.noisy_dev = [rt.to_device(torch.from_numpy(synth.synth_radiance(g["base"][self.res[0]:self.res[1]], f + 1))) for f in range(4)]
         self.frame = 1
         self.ran_svgf = []
-        # Optional frames in flight (the reference keeps 3, src/nri/Swapchain.h:15): the GI stages of frame f+1 touch only
-        # the G-buffer and the GI records, so they can run on a side stream while frame f is resolved and denoised on the
-        # main stream; the two meet at neb_gi_resolve (the reference's separate nrc Resolve step, DeferredRenderer.cpp:586).
-        # Measured on MI355X: a whole 1080p frame gains nothing (the GI kernels already occupy every wave slot: 643 -> 669 us), a strip does --
-        # its short launches leave the chip idle (tools/strip_overlap.py); hence `--overlap auto`:
+        # Frames in flight (the reference keeps 3, src/nri/Swapchain.h:15).  Kernels that are bound by their own dependent chains leave the chip idle;
+        # work of the NEXT frame that depends on nothing of this one can run beside them on a side stream.  Two forms, same frames bit for bit
+        # (tools/strip_overlap.py, tools/frame_split.py; --overlap off = one frame in flight, reported beside as value_one_frame_in_flight):
+        #  "split":  neb_gi_trace_begin (ray generation + closest-hit walk) of frame f+1 starts when frame f's shade pass has finished and runs beside
+        #            frame f's short, latency-bound shadow pass, its SVGF chain and the direct-term copy; neb_gi_trace_finish (shade + shadow passes)
+        #            follows on the main stream.  Whole 1080p frame 649 -> 614-622 us, 540-row strip 402 -> 373, 270 rows 271 -> 235.
+        #  "defer":  the whole GI dispatch of frames f+1 and f+2 on two side streams and two record sets ("gi_defer_resolve" = 2), meeting the SVGF
+        #            passes at neb_gi_resolve: best on the smallest strips (135 rows: 208 -> 149 us, split: 166), no gain on big ones.
         own_px = (self.own[1] - self.own[0]) * GW
-        self.overlap = do_gi and (args.overlap == "on" or (args.overlap == "auto" and world > 1 and own_px <= 600_000))
-        # ... and on strips of at most 0.3 M pixels (N = 8) on TWO side streams and the library's two record sets ("gi_defer_resolve" = 2): the GI
-        # stages of frame f + 1 also run beside those of frame f (a 135-row strip 183 -> 149 us per frame; 270 rows and more: no further gain)
-        self.depth = (2 if (own_px <= 300_000 or args.overlap == "on") else 1) if self.overlap else 0
-        self.sides = [rt.new_stream() for _ in range(self.depth)]
-        self.resolved = [None] * max(self.depth, 1)
-        if self.overlap:
-            r.set_defer_resolve(self.depth)
+        splittable = do_gi and spp == 1 and int(r.gi_ui.max_path_vertices) <= 2  # (one sample, one bounce per pixel: what neb_gi_trace_begin / _finish take)
+        forced = os.environ.get("NEB_BENCH_PIPELINE")  # experiments: "split" | "defer"
+        self.mode = None
+        if do_gi and args.overlap != "off":
+            self.mode = (forced if forced != "split" or splittable else None) or ("defer" if (world > 1 and own_px <= 300_000) or not splittable else "split")
+            if self.mode == "defer" and not forced and args.overlap == "auto" and not (world > 1 and own_px <= 300_000):
+                self.mode = None  # (several samples per pixel on a big strip: nothing to gain)
+        self.overlap = self.mode is not None
+        self.depth = 2 if self.mode == "defer" else 0
+        self.sides = [rt.new_stream() for _ in range(2 if self.mode == "defer" else 1 if self.mode == "split" else 0)]
+        self.resolved = [None, None]
+        self.shaded = None
+        self.force_serial = False
+        if self.mode == "defer":
+            r.set_defer_resolve(2)
+
+    def frames_in_flight(self):
+        return {None: 1, "split": 2, "defer": 3}[self.mode]
 
     def step(self, timed_events=None, cam=None, regen_gbuffer=False):
         torch, r, stream = self.torch, self.r, self.stream
@@ -434,25 +451,46 @@ class Workload:
             r.submit_commands_gbuffer()
             r.submit_commands_pbr_lighting()
             self.direct.copy_(self.rad_view[cur], non_blocking=True)  # (kept for the still frames that follow)
-        pipelined = self.overlap and timed_events is None
-        slot = f % self.depth if self.overlap else 0
-        side = self.sides[slot] if self.overlap else None
-        gi_stream = side if pipelined else stream
-        if not self.overlap and not regen_gbuffer:  # PBR pass stand-in (overwrites radiance[cur]); the GI dispatch then adds into it
+        pipelined = self.overlap and timed_events is None and not self.force_serial
+        defer = self.mode == "defer"
+        slot = f % 2
+        side = self.sides[slot if defer else 0] if self.overlap else None
+        if not defer and not regen_gbuffer and not (self.mode == "split" and pipelined):
+            # PBR pass stand-in (overwrites radiance[cur]); the GI dispatch then adds into it
             self.rad_view[cur].copy_(self.direct if self.do_gi else self.noisy_dev[f % 4], non_blocking=True)
         if timed_events is not None:
             timed_events["gi0"].record(stream)
-        if self.do_gi:
-            if pipelined and self.resolved[slot] is not None:
+        if self.do_gi and self.mode == "split" and pipelined:
+            if self.shaded is not None:
+                side.wait_event(self.shaded)  # the previous frame's shade pass is over (what read this record set finished a frame before that)
+            if regen_gbuffer:  # the G-buffer of this frame was just rendered on the main stream
+                drawn = self.rt.event(timing=False)
+                drawn.record(stream)
+                side.wait_event(drawn)
+            r.submit_commands_gi_pathtrace_begin(rows=self.part.gi_rows(self.rank), stream=self.rt.stream_handle(side))
+            walked = self.rt.event(timing=False)
+            walked.record(side)
+            if not regen_gbuffer:
+                self.rad_view[cur].copy_(self.direct, non_blocking=True)
+            stream.wait_event(walked)
+            self.shaded = self.rt.event(timing=False)
+            self.shaded.record(stream)  # (creates the underlying event; the library records it again between its shade and shadow passes)
+            r.submit_commands_gi_pathtrace_finish(after_shade_event=self.rt.event_handle(self.shaded))
+        elif self.do_gi:
+            gi_stream = side if (pipelined and defer) else stream
+            if pipelined and defer and self.resolved[slot] is not None:
                 side.wait_event(self.resolved[slot])  # the resolve that consumed this record set
-            if pipelined and regen_gbuffer:  # the G-buffer of this frame was just rendered on the main stream
+            if pipelined and defer and regen_gbuffer:
                 drawn = self.rt.event(timing=False)
                 drawn.record(stream)
                 side.wait_event(drawn)
             r.submit_commands_gi_pathtrace(stream=self.rt.stream_handle(gi_stream))
+        if self.mode == "split" and not pipelined and self.do_gi:
+            self.shaded = self.rt.event(timing=False)  # (a serial frame in between: the next split frame's walk waits for all of its GI)
+            self.shaded.record(stream)
         if timed_events is not None:
             timed_events["gi1"].record(stream)
-        if self.overlap:
+        if defer:
             self.rad_view[cur].copy_(self.direct, non_blocking=True)
             if pipelined:
                 done = self.rt.event(timing=False)
@@ -510,12 +548,20 @@ class Workload:
     def parallelism_label(self):
         p = self.part
         if self.world == 1:
-            return "single GPU"
+            return "single GPU" + self.pipeline_label()
         return (f"row-strips x{self.world} of {p.H // p.N} rows + halo exchange over RCCL: scheme '{p.scheme}' ({p.scheme_reason}; "
                 f"{ {'once': 'one exchange per frame', 'per_level': 'one exchange per a-trous level', 'overlap': 'two exchanges per frame, GI recomputed on the overlap rows'}[p.scheme]}, {p.exchanged_bytes_per_frame() / 1e6:.1f} MB sent "
                 f"per rank and frame), transport '{self.r.exchange}' ({'neb_strips_exchange: grouped ncclSend / ncclRecv' if self.r.exchange == 'rccl' else 'torch.distributed batch_isend_irecv on the planes'})"
-                + (f"; {1 + self.depth} frames in flight: the GI stages of frame f+1 on a side stream beside the SVGF passes of frame f, meeting at neb_gi_resolve"
-                   + (" (two record sets: also beside the GI stages of frame f+2)" if self.depth == 2 else "") if self.overlap else ""))
+                + self.pipeline_label())
+
+    def pipeline_label(self):
+        if self.mode == "split":
+            return ("; 2 frames in flight: ray generation + closest-hit walk of frame f+1 (neb_gi_trace_begin) on a side stream from the end of frame f's "
+                    "shade pass, beside its shadow pass, SVGF chain and the direct-term copy")
+        if self.mode == "defer":
+            return ("; 3 frames in flight: the GI stages of frames f+1 and f+2 on two side streams and two record sets beside the SVGF passes of frame f, "
+                    "meeting at neb_gi_resolve")
+        return ""
 
     def destroy(self):
         self.r.destroy()
@@ -610,7 +656,7 @@ def main(argv=None, rt=None, emit=None):
     # ---- the primary workload: ONE width x height frame (BASELINE.json configs[2]) on `world` GPUs = `world` row strips ----
     GW, GH = args.width, args.height
     w = Workload(rt, args, GW, GH, L, args.spp, sc, cam, rank, world, local_rank, group, do_gi=do_gi, scheme=scheme, link=link)
-    frames_in_flight = 1 + w.depth  # (2: the GI stages of frame f + 1 run on a side stream beside the SVGF passes of frame f; 3: and beside those of frame f + 2)
+    frames_in_flight = w.frames_in_flight()
     r, part = w.r, w.part
     scene_bytes = r.scene_bytes() if do_gi else None
     bvh = {"triangles": r.scene_info()[0], "bvh4_nodes": r.scene_info()[1], "bvh4_depth": r.bvh_depth(), "build_ms": round(r.build_ms(), 2)} if do_gi else None
@@ -625,6 +671,11 @@ def main(argv=None, rt=None, emit=None):
     # the settled rate: the same K steps, timed the same way, once the context has run SETTLE_FRAMES frames in all
     settle_run = max(Workload.SETTLE_FRAMES - warmup_run - args.steps, 0)
     dt_settled, _ = w.timed(args.steps, settle_run)
+    dt_serial = None
+    if w.overlap:  # the same K steps with ONE frame in flight (every stage of a frame on the main stream, in order)
+        w.force_serial = True
+        dt_serial, _ = w.timed(args.steps, 2)
+        w.force_serial = False
 
     # ---- optional: the same loop with SURVEY.md 8e's final gather of the strips to rank 0 after every frame ----
     fps_with_gather = None
@@ -713,7 +764,7 @@ def main(argv=None, rt=None, emit=None):
         dtw, rays_w = ww.timed(args.steps, max(args.warmup, 1))
         weak = {"frames_per_s_1080p_equivalents": args.steps / dtw * world, "global_frames_per_s": args.steps / dtw, "ms_per_frame": dtw / args.steps * 1e3,
                 "mrays_per_s": rays_w / dtw / 1e6, "global_width": args.width * a, "global_height": args.height * b,
-                "rows_per_strip": args.height * b // world, "parallelism": ww.parallelism_label()}
+                "rows_per_strip": args.height * b // world, "parallelism": ww.parallelism_label(), "frames_in_flight": ww.frames_in_flight()}
         ww.destroy()
     config5 = None
     if do_gi and (args.config5 or world == 8):
@@ -737,6 +788,8 @@ def main(argv=None, rt=None, emit=None):
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_run": warmup_run,
             # a second timed region of the same K steps after `settled_after_frames` frames of this context (value: after W only)
             "value_settled": args.steps / dt_settled, "ms_per_step_settled": dt_settled / args.steps * 1e3,
+            # ... and with one frame in flight (None when `value` already is that): value's frames overlap the next frame's closest-hit walk
+            "value_one_frame_in_flight": (args.steps / dt_serial) if dt_serial else None,
             "settled_after_frames": warmup_run + args.steps + settle_run,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not args.scene else f"scene file {os.path.basename(args.scene)}; synthetic camera",

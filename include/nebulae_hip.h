@@ -307,6 +307,16 @@ int neb_gi_build_ms(const neb_ctx* ctx, float* ms);
  * normal[cur].  _rows: image rows [row0,row1) only (multi-GPU strips). */
 int neb_gi_trace(neb_ctx* ctx, const neb_gi_constants* constants, neb_stream stream);
 int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* constants, uint32_t row0, uint32_t row1, neb_stream stream);
+/* The same dispatch in two calls, for a host that keeps two frames in flight (the reference's swapchain keeps three, src/nri/Swapchain.h:15):
+ * _begin enqueues ray generation + the closest-hit walk -- they read the G-buffer and write only GI records --, _finish the shading and shadow
+ * passes of the dispatch begun longest ago, which add into the radiance[cur] of the frame current AT THE _finish CALL.  Two sets of GI records:
+ * the _begin of frame f+1 may be enqueued (on another stream) while the _finish of frame f is still executing -- the short, latency-bound
+ * shadow pass of frame f then runs beside the closest-hit walk of frame f+1 instead of alone on the chip.  `after_shade_event`: NULL, or a
+ * hipEvent_t that _finish records between its two passes (what the next _begin's stream may wait for).  The caller orders the streams: a
+ * _finish must not start before its own _begin has completed, a _begin not before the _finish that read its set (two dispatches earlier).
+ * One sample and one bounce per pixel only (samplesPerPixel == 1, maxPathVertices <= 2); not together with "gi_defer_resolve". */
+int neb_gi_trace_begin(neb_ctx* ctx, const neb_gi_constants* constants, uint32_t row0, uint32_t row1, neb_stream stream);
+int neb_gi_trace_finish(neb_ctx* ctx, neb_stream stream, void* after_shade_event);
 /* The reference's separate resolve step (nrc Resolve(commandList, GetRadianceOutput()), DeferredRenderer.cpp:586):
  * radiance[cur].rgb += the indirect term of the last neb_gi_trace that ran with "gi_defer_resolve" = 1.  Lets the GI
  * stages of frame f+1 overlap the SVGF passes of frame f on another stream (they share no plane until this call). */

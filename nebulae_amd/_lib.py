@@ -90,6 +90,8 @@ def _gi_sigs():
         "neb_gi_trace": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_void_p]),
         "neb_gi_trace_rows": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_uint32, C.c_uint32, C.c_void_p]),
         "neb_gi_resolve": (C.c_int, [C.c_void_p, C.c_void_p]),
+        "neb_gi_trace_begin": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_uint32, C.c_uint32, C.c_void_p]),
+        "neb_gi_trace_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
         "neb_gi_ray_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_void_p]),
         "neb_gi_traversal_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
         "neb_gi_wave_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -905,7 +905,9 @@ using namespace neb;
 
 extern "C" {
 
-int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, uint32_t row1, neb_stream stream)
+// phase 0: the whole dispatch (neb_gi_trace).  1: ray generation + closest-hit walk only (neb_gi_trace_begin); 2: the shading and shadow passes of
+// the dispatch begun longest ago (neb_gi_trace_finish; `after_shade`: an event to record between the two).
+static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, uint32_t row1, neb_stream stream, int phase, hipEvent_t after_shade)
 {
     if (!ctx || !c)
         return ctx ? gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: null constants") : NEB_ERR_INVALID_ARG;
@@ -926,7 +928,17 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     // the set of per-dispatch buffers: with "gi_defer_resolve" = 2 two deferred dispatches may be in flight (on two streams), on alternating sets
     if (g->defer_resolve == 2 && g->traces - g->resolves >= 2u)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: both record sets hold a dispatch that neb_gi_resolve has not retired yet");
-    GiState::DispatchSet& ds = g->sets[g->defer_resolve == 2 ? (g->traces & 1u) : 0u];
+    if (phase == 0 && g->begun != g->finished)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: a dispatch begun with neb_gi_trace_begin still waits for its neb_gi_trace_finish");
+    if (phase != 0) {
+        if (g->defer_resolve)
+            return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_begin / _finish: not together with gi_defer_resolve (the finish call adds into radiance[cur] itself)");
+        if (c->samplesPerPixel != 1 || c->maxPathVertices > 2 || g->sort_bounce)
+            return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_begin / _finish: one sample and one bounce per pixel only, bounce-ray sorting off (use neb_gi_trace)");
+        if (phase == 1 && g->begun - g->finished >= 2u)
+            return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_begin: both record sets hold a dispatch that neb_gi_trace_finish has not completed yet");
+    }
+    GiState::DispatchSet& ds = g->sets[phase == 1 ? (g->begun & 1u) : phase == 2 ? (g->finished & 1u) : g->defer_resolve == 2 ? (g->traces & 1u) : 0u];
     if (g->debug_hits && !g->d_hits) {
         void* p = nullptr;
         GI_HIP(ctx, hipMalloc(&p, npx * sizeof(neb_gi_hit)));
@@ -979,7 +991,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
     // unsorted (the sort's six launches cost more than coherence is worth to the ~14 % that are left).
     // the sun-visibility table: brought up to date with this frame's sun (a rebuild only when the sun or the scene changed -- and
     // then only once the new sun has held for a second frame: a sun that is being dragged is traced the plain way meanwhile)
-    GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
+    if (phase != 1) // (the flags are read by the shade pass)
+        GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
     a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
     const bool compact = a.sun_table && g->compact_shadow;
     const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
@@ -1049,9 +1062,11 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         a.sample = s;
         for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
             a.bounce = b;
-            if (b == 1) {
+            if (b == 1 && phase != 2) {
                 hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
             }
+            if (phase == 1)
+                continue;
             if (g->sort_bounce) {
                 uint32_t* bs = ds.d_sort + 4 * npx; // {keys, vals, keys_tmp, order}
                 GI_HIP(ctx, ray_sort_pairs(bs + a.first_px, bs + npx + a.first_px, bs + 2 * npx + a.first_px, bs + 3 * npx + a.first_px,
@@ -1067,6 +1082,8 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
                 hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
             else
                 hipLaunchKernelGGL(gi_shade_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+            if (after_shade)
+                GI_HIP(ctx, hipEventRecord(after_shade, (hipStream_t)stream));
             if (a.list) {
                 if (a.n_px < NEB_LIST_QUAD_BELOW)
                     hipLaunchKernelGGL(gi_shadow_list_kernel<true>, dim3(list_waves), block, 0, (hipStream_t)stream, a);
@@ -1088,7 +1105,37 @@ int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, ui
         }
     }
     GI_HIP(ctx, hipGetLastError());
+    if (phase == 1) {
+        ds.split_c = *c;
+        ds.split_row0 = row0;
+        ds.split_row1 = row1;
+        g->begun++;
+    } else if (phase == 2) {
+        g->finished++;
+    }
     return NEB_OK;
+}
+
+int neb_gi_trace_rows(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, uint32_t row1, neb_stream stream)
+{
+    return gi_dispatch(ctx, c, row0, row1, stream, 0, nullptr);
+}
+
+int neb_gi_trace_begin(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, uint32_t row1, neb_stream stream)
+{
+    return gi_dispatch(ctx, c, row0, row1, stream, 1, nullptr);
+}
+
+int neb_gi_trace_finish(neb_ctx* ctx, neb_stream stream, void* after_shade_event)
+{
+    if (!ctx || !ctx->gi)
+        return ctx ? gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_finish: no scene") : NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (g->begun == g->finished)
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_finish: nothing begun (neb_gi_trace_begin first)");
+    const GiState::DispatchSet& ds = g->sets[g->finished & 1u];
+    const neb_gi_constants c = ds.split_c;
+    return gi_dispatch(ctx, &c, ds.split_row0, ds.split_row1, stream, 2, (hipEvent_t)after_shade_event);
 }
 
 int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)

@@ -27,6 +27,7 @@ void gi_on_resize(GiState* g)
         ds = GiState::DispatchSet{};
     }
     g->traces = g->resolves = 0;
+    g->begun = g->finished = 0;
     for (void* p : stale) {
         if (!p)
             continue;

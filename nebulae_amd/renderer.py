@@ -169,6 +169,20 @@ class DeferredRenderer:
             rc = self._lib.neb_gi_trace_rows(self._ctx, C.byref(c), rows[0], rows[1], st)
         self._check(rc, "neb_gi_trace")
 
+    def submit_commands_gi_pathtrace_begin(self, rows=None, stream=None):
+        """The first half of SubmitCommandsGIPathtrace -- ray generation + the closest-hit walk (neb_gi_trace_begin): touches only the
+        G-buffer and GI records, so the next frame's may run beside this frame's shadow pass and SVGF on another stream."""
+        c = self.global_constants()
+        st = C.c_void_p(self.info.stream if stream is None else stream)
+        r0, r1 = (self.svgf.row_begin, self.svgf.row_end) if rows is None else rows
+        self._check(self._lib.neb_gi_trace_begin(self._ctx, C.byref(c), r0, r1, st), "neb_gi_trace_begin")
+
+    def submit_commands_gi_pathtrace_finish(self, stream=None, after_shade_event=None):
+        """The second half: shading + shadow passes of the dispatch begun longest ago, adding into radiance[cur] (neb_gi_trace_finish).
+        after_shade_event: a raw hipEvent_t (e.g. torch.cuda.Event(...).cuda_event) recorded between the two passes."""
+        self._check(self._lib.neb_gi_trace_finish(self._ctx, C.c_void_p(self.info.stream if stream is None else stream),
+                                                  C.c_void_p(after_shade_event or 0)), "neb_gi_trace_finish")
+
     def set_defer_resolve(self, on=True):
         """Split the GI dispatch as the reference does (QueryAndTrain ... then Resolve, DeferredRenderer.cpp:560,586)."""
         self.svgf.set_option("gi_defer_resolve", int(on))

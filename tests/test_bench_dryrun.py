@@ -60,6 +60,9 @@ class DryRuntime:
     def event(self, timing=True):
         return _Event()
 
+    def event_handle(self, event):
+        return 0
+
     def to_device(self, t):
         return t
 
@@ -124,6 +127,17 @@ class DryRuntime:
                 else:
                     self._add(add)
 
+            def submit_commands_gi_pathtrace_begin(self, rows=None, stream=None):  # (bench.py's "split" form: the walk now, shading + adding later)
+                assert getattr(self, "_begun", None) is None, "neb_gi_trace_begin: the dry run keeps one dispatch begun"
+                own = self.part.gi_rows(self.rank) if rows is None else rows
+                self._rays += 2 * (own[1] - own[0]) * self.part.W * int(self.gi_ui.gi_samples_per_pixel)
+                self._begun = (own, 0.01 * float(self.info.frame_index % 7))
+
+            def submit_commands_gi_pathtrace_finish(self, stream=None, after_shade_event=None):
+                assert self._begun is not None, "neb_gi_trace_finish: nothing begun"
+                self._add(self._begun)
+                self._begun = None
+
             def submit_commands_gi_resolve(self, stream=None):
                 assert self._defer and self._pending is not None, "neb_gi_resolve: nothing pending"
                 self._add(self._pending)
@@ -166,7 +180,14 @@ def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     argv = ["--gpus", str(world), "--steps", "2", "--warmup", "2", "--width", "64", "--height", "512", "--cpu-frames", "0", "--triangles", "2000",
             "--tex-size", "16", "--gather", "--scheme", scheme, "--config5", "--config5-frames", "4", "--config5-size", "64", "512"]
     port = 29900 + (os.getpid() % 1500) + world
-    mp.spawn(_rank_main, args=(world, port, argv, str(out)), nprocs=world, join=True)
+    # strips this small take the "defer" form of frames in flight (three: two record sets); world 2 is made to take the "split" form a
+    # whole frame or a big strip takes (two: neb_gi_trace_begin of the next frame on a side stream)
+    form = "split" if world == 2 else "defer"
+    os.environ["NEB_BENCH_PIPELINE"] = form
+    try:
+        mp.spawn(_rank_main, args=(world, port, argv, str(out)), nprocs=world, join=True)
+    finally:
+        del os.environ["NEB_BENCH_PIPELINE"]
     d = json.loads(out.read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "weak_scaling", "config5", "kernel_us", "svgf_roofline", "frame_roofline"):
@@ -191,7 +212,12 @@ def test_multi_gpu_control_flow_on_cpu(tmp_path, world, scheme):
     if scheme == "auto":
         assert "cost table: once +" in cfg["parallelism"] and "link measured" in cfg["parallelism"]
     # strips this small run two frames in flight (--overlap auto): GI of frame f + 1 on a side stream, deferred resolve
-    assert cfg["frames_in_flight"] == 3 and "3 frames in flight" in cfg["parallelism"] and "two record sets" in cfg["parallelism"]
+    if form == "defer":
+        assert cfg["frames_in_flight"] == 3 and "3 frames in flight" in cfg["parallelism"] and "two record sets" in cfg["parallelism"]
+    else:
+        assert cfg["frames_in_flight"] == 2 and "neb_gi_trace_begin" in cfg["parallelism"]
+    assert d["value_one_frame_in_flight"] > 0
+    assert d["weak_scaling"]["frames_in_flight"] == cfg["frames_in_flight"]
 
 
 _ARGV = ["--steps", "2", "--warmup", "1", "--width", "64", "--height", "256", "--cpu-frames", "0", "--triangles", "2000", "--tex-size", "16",

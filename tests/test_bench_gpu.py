@@ -26,6 +26,9 @@ def test_single_gpu_line():
               "dtype", "data", "config", "roofline", "cpu_baseline", "svgf_roofline", "svgf_fused_model", "frame_roofline", "kernel_us"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    # two frames in flight by default: the next frame's closest-hit walk (neb_gi_trace_begin) beside this frame's shadow pass and SVGF chain;
+    # the rate with one frame in flight rides beside
+    assert d["config"]["frames_in_flight"] == 2 and "neb_gi_trace_begin" in d["config"]["parallelism"] and d["value_one_frame_in_flight"] > 0
     assert d["warmup"] == 2 and d["warmup_run"] == 2 and d["value_settled"] > 0 and d["settled_after_frames"] >= 48
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
     # one GPU: temporal + level 0 ran as one launch, the pure levels are timed by the library's own events
@@ -71,12 +74,14 @@ def test_scene_file_replaces_the_stand_in():
 @pytest.mark.parametrize("scheme", ["once", "per_level"])
 def test_two_rank_rehearsal(scheme):
     env = dict(os.environ, NEB_BENCH_SHARE_DEVICE="1", NEB_BENCH_BACKEND="gloo", NEB_STRIPS_SCHEME=scheme)
+    if scheme == "per_level":
+        env["NEB_BENCH_PIPELINE"] = "defer"  # (the form 135-row strips take; 540-row strips take "split" by themselves)
     # "once": the driver's own form, `python bench.py --gpus 2 ...` with no launcher around it (bench.py starts its ranks itself);
     # "per_level": under torch.distributed.run, as the contract also allows
     launcher = [] if scheme == "once" else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                             "--master-port", str(29650 + (os.getpid() % 200))]
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--cpu-frames", "0", "--gather", "--tex-size", "256"] + (["--config5", "--config5-frames", "4"] if scheme == "once" else ["--overlap", "on"])
+           "--cpu-frames", "0", "--gather", "--tex-size", "256"] + (["--config5", "--config5-frames", "4"] if scheme == "once" else [])
     env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -86,9 +91,9 @@ def test_two_rank_rehearsal(scheme):
     assert ("one exchange per frame" if scheme == "once" else "one exchange per a-trous level") in d["config"]["parallelism"]
     assert f"scheme '{scheme}'" in d["config"]["parallelism"] and "transport 'torch'" in d["config"]["parallelism"]
     assert d["frames_per_s_with_final_gather"] > 0
-    # 540-row strips keep one frame in flight under --overlap auto; "per_level" forces the pipelined form: GI of frames f + 1 and f + 2 on two side streams and two record sets, deferred resolve
-    assert d["config"]["frames_in_flight"] == (1 if scheme == "once" else 3)
-    assert ("3 frames in flight" in d["config"]["parallelism"]) == (scheme != "once")
+    # 540-row strips take the "split" form of two frames in flight; "per_level" is made to take the "defer" form of the smallest strips
+    assert d["config"]["frames_in_flight"] == (2 if scheme == "once" else 3)
+    assert ("neb_gi_trace_begin" if scheme == "once" else "two record sets") in d["config"]["parallelism"]
     assert d["config"]["link"].startswith("link measured: ") and d["value_settled"] > 0 and d["warmup_run"] == 2
     assert d["weak_scaling"]["global_height"] == 2160 and d["weak_scaling"]["rows_per_strip"] == 1080 and d["weak_scaling"]["frames_per_s_1080p_equivalents"] > 0
     if scheme == "once":

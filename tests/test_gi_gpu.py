@@ -291,6 +291,67 @@ def test_deferred_resolve_and_two_stream_pipelining_are_bit_exact(depth):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_dispatch_in_two_calls_with_the_next_walk_beside_this_frames_shadow_pass_is_bit_exact():
+    """neb_gi_trace_begin (ray generation + closest-hit walk) + neb_gi_trace_finish (shade + shadow passes) == neb_gi_trace, also when the walk of
+    frame f + 1 runs on a side stream from the end of frame f's shade pass, beside its shadow pass and SVGF chain (bench.py's default form)."""
+    from nebulae_amd.svgf import NebError
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    outs = []
+    for mode in ("one call", "two calls"):
+        r = DeferredRenderer()
+        r.init(W, H, atrous_levels=4)
+        main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=main.cuda_stream))
+        r.submit_commands_gbuffer()
+        torch.cuda.synchronize()
+        for pl in (PLANE_NORMAL, PLANE_DEPTH):
+            r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
+        rad = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
+        direct = torch.full_like(rad[0], 0.125)
+        shaded = None
+        for f in range(2, 11):
+            r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=main.cuda_stream))
+            cur = r.svgf.get_current_resource_index()
+            if mode == "two calls":
+                if shaded is not None:
+                    side.wait_event(shaded)
+                r.submit_commands_gi_pathtrace_begin(stream=side.cuda_stream)
+                walked = torch.cuda.Event()
+                walked.record(side)
+                rad[cur].copy_(direct, non_blocking=True)
+                main.wait_event(walked)
+                shaded = torch.cuda.Event()
+                shaded.record(main)
+                r.submit_commands_gi_pathtrace_finish(after_shade_event=shaded.cuda_event)
+            else:
+                rad[cur].copy_(direct, non_blocking=True)
+                r.submit_commands_gi_pathtrace()
+            r.submit_commands_svgf_denoising()
+            r.end_frame()
+        torch.cuda.synchronize()
+        outs.append(r.svgf.download(PLANE_RADIANCE))
+        if mode == "two calls":  # misuse is refused, not guessed at
+            r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=11, stream=main.cuda_stream))
+            with pytest.raises(NebError):
+                r.submit_commands_gi_pathtrace_finish()  # nothing begun
+            r.submit_commands_gi_pathtrace_begin()
+            r.submit_commands_gi_pathtrace_begin()
+            with pytest.raises(NebError):
+                r.submit_commands_gi_pathtrace_begin()  # both record sets taken
+            with pytest.raises(NebError):
+                r.submit_commands_gi_pathtrace()  # the one-call form while a dispatch is begun
+            r.submit_commands_gi_pathtrace_finish()
+            r.submit_commands_gi_pathtrace_finish()
+            r.gi_ui.gi_samples_per_pixel = 2
+            with pytest.raises(NebError):
+                r.submit_commands_gi_pathtrace_begin()  # one sample per pixel only
+            torch.cuda.synchronize()
+        r.destroy()
+    assert float(np.abs(outs[0][..., :3]).max()) > 0.2
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_two_record_sets_hold_two_dispatches_and_refuse_a_third():
     """"gi_defer_resolve" = 2: two traced dispatches may wait for their neb_gi_resolve at once (each on its own set of records, retired in the
     order they were traced); a third is refused, and so is a resolve with nothing pending or a change of the option in between."""

@@ -95,6 +95,52 @@ def test_strips_with_the_gi_stages_on_a_side_stream_equal_full_image(W, H, N, de
     ls.destroy()
 
 
+@pytest.mark.parametrize("W,H,N", [(256, 192, 2), (1920, 1080, 4)])
+def test_strips_with_the_dispatch_in_two_calls_equal_full_image(W, H, N):
+    """bench.py's "split" form on strips: every strip walks its rows with neb_gi_trace_begin on a side stream and shades them with
+    neb_gi_trace_finish on the main stream once the direct term is there -- still the full image (one call, one stream) bit for bit."""
+    L = 5
+    sc = S.atrium_standin(target_triangles=20000, n_submeshes=40, tex_size=32)
+    cam = S.sponza_camera()
+    full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
+    ls = LockstepStrips(W, H, N, L, "once")
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    shaded = None
+    for f in range(1, 6):
+        info = RenderInfo(scene=sc, camera=cam, frame_index=f)
+        full.begin_frame(info)
+        full.submit_commands_gbuffer()
+        full.svgf.plane_tensor(PLANE_RADIANCE, full.svgf.get_current_resource_index()).fill_(0.125)
+        full.submit_commands_gi_pathtrace()
+        for r in ls.rs:
+            r.begin_frame(info)
+            r.submit_commands_gbuffer()
+        drawn = torch.cuda.Event()
+        drawn.record(main)
+        side.wait_event(drawn)
+        if shaded is not None:
+            side.wait_event(shaded)
+        for r in ls.rs:
+            r.submit_commands_gi_pathtrace_begin(rows=r.part.gi_rows(r.rank), stream=side.cuda_stream)
+            r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).fill_(0.125)  # the direct term, on the main stream
+        walked = torch.cuda.Event()
+        walked.record(side)
+        main.wait_event(walked)
+        for r in ls.rs:
+            r.submit_commands_gi_pathtrace_finish()
+        shaded = torch.cuda.Event()
+        shaded.record(main)
+        ran_full = full.submit_commands_svgf_denoising()
+        assert all(x == ran_full for x in ls.denoise())
+    torch.cuda.synchronize()
+    want = full.svgf.download(PLANE_RADIANCE)
+    got = ls.image()
+    assert np.isfinite(want).all() and float(np.abs(want[..., :3]).max()) > 0.2
+    assert np.array_equal(got, want)
+    full.destroy()
+    ls.destroy()
+
+
 def test_c_entry_point_exchanges_rows_over_rccl():
     """neb_strips_exchange: grouped ncclSend / ncclRecv straight out of / into the planes, on the caller's stream, through an
     RCCL communicator the library creates itself (librccl resolved at run time).  One GPU: a communicator of one rank that

@@ -64,6 +64,25 @@ def frame_pipelined(r, direct, main, sides, f, state):
         r.end_frame()
 
 
+def frame_split(r, direct, main, side, f, state):
+    """neb_gi_trace_begin / _finish (tools/frame_split.py): the closest-hit walk of frame f on the side stream from the end of frame f - 1's shade pass"""
+    with torch.cuda.stream(main):
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=main.cuda_stream))
+        if state.get("shaded") is not None:
+            side.wait_event(state["shaded"])
+        r.submit_commands_gi_pathtrace_begin(rows=r.part.gi_rows(r.rank), stream=side.cuda_stream)
+        walked = torch.cuda.Event()
+        walked.record(side)
+        r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).copy_(direct, non_blocking=True)
+        main.wait_event(walked)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        r.submit_commands_gi_pathtrace_finish(after_shade_event=ev.cuda_event)
+        state["shaded"] = ev
+        r.submit_commands_svgf_denoising()
+        r.end_frame()
+
+
 for N in (8, 4, 2, 1):
     streams = [torch.cuda.Stream() for _ in range(3)]
     rs = [make(N, s) for s in streams]
@@ -100,5 +119,18 @@ for N in (8, 4, 2, 1):
         t2 = time.perf_counter()
         print(f"N = {N}: ONE renderer, GI of frame f + 1 on a side stream beside the SVGF passes of frame f, {depth} record set(s) / side stream(s): "
               f"host {(t1 - t0) / n * 1e6:.0f} us per frame; wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
+    torch.cuda.synchronize()
+    r.set_defer_resolve(0)
+    main, side, state = streams[0], streams[1], {}
+    for f in range(500, 560):
+        frame_split(r, direct, main, side, f, state)
+    torch.cuda.synchronize()
+    n = 100
+    t0 = time.perf_counter()
+    for f in range(560, 560 + n):
+        frame_split(r, direct, main, side, f, state)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"N = {N}: ONE renderer, neb_gi_trace_begin of frame f + 1 on a side stream from the end of frame f's shade pass: wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
     for r, _ in rs:
         r.destroy()
