@@ -9,7 +9,7 @@ for setting in "$@"; do
   d=gpurun_out/abenv_$k
   rm -rf "$d"
   ( for kv in $setting; do export "$kv"; done
-    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python bench.py --steps 24 --warmup 8 --cpu-frames 0 $AB_BENCH_FLAGS > "$d.log" 2>&1 ) || { tail -5 "$d.log"; exit 1; }
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python bench.py --steps 24 --warmup 8 --cpu-frames 0 --overlap off $AB_BENCH_FLAGS > "$d.log" 2>&1 ) || { tail -5 "$d.log"; exit 1; }
   python - "$setting" "$d" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[2] + "/*/*kernel_stats.csv")[0]

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   export NEB_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/lib_$v.so
   rm -rf gpurun_out/abk_$v
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abk_$v -- python bench.py --steps 24 --warmup 8 --cpu-frames 0 > gpurun_out/abk_$v.log 2>&1 || exit 1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abk_$v -- python bench.py --steps 24 --warmup 8 --cpu-frames 0 --overlap off > gpurun_out/abk_$v.log 2>&1 || exit 1
   python - "$v" <<'PY'
 import csv, glob, sys
 f = glob.glob(f"gpurun_out/abk_{sys.argv[1]}/*/*kernel_stats.csv")[0]

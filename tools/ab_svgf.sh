@@ -12,7 +12,7 @@ for v in "$@"; do
     timeout -k 10 400 python -m pytest tests/test_svgf_gpu.py -x -q > gpurun_out/absvgf_$v.test.log 2>&1; echo "$v tests: $(tail -1 gpurun_out/absvgf_$v.test.log)"
   fi
   rm -rf gpurun_out/absvgf_$v
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/absvgf_$v -- python bench.py $mode --steps 24 --warmup 8 --cpu-frames 0 $AB_BENCH_FLAGS > gpurun_out/absvgf_$v.log 2>&1 || { tail -5 gpurun_out/absvgf_$v.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/absvgf_$v -- python bench.py $mode --steps 24 --warmup 8 --cpu-frames 0 --overlap off $AB_BENCH_FLAGS > gpurun_out/absvgf_$v.log 2>&1 || { tail -5 gpurun_out/absvgf_$v.log; exit 1; }
   python - "$v" <<'PY'
 import csv, glob, re, sys
 f = glob.glob(f"gpurun_out/absvgf_{sys.argv[1]}/*/*kernel_stats.csv")[0]
