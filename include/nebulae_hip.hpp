@@ -124,6 +124,18 @@ namespace Neb
             ThrowIfFailed(m_svgf.Context(), neb_gi_trace(m_svgf.Context(), &globalConstants, commandList), "neb_gi_trace");
         }
 
+        // The same dispatch in two command lists, for a renderer that keeps frames in flight (src/nri/Swapchain.h:15): the first half (ray
+        // generation + closest-hit walk) touches only the G-buffer and GI records and may be recorded for frame f + 1 on another stream while
+        // the second half of frame f (shade + shadow passes, adds into the radiance target) and its SVGF passes still execute.
+        void SubmitCommandsGIPathtraceBegin(const neb_gi_constants& globalConstants, uint32_t row0, uint32_t row1, neb_stream commandList)
+        {
+            ThrowIfFailed(m_svgf.Context(), neb_gi_trace_begin(m_svgf.Context(), &globalConstants, row0, row1, commandList), "neb_gi_trace_begin");
+        }
+        void SubmitCommandsGIPathtraceFinish(neb_stream commandList, void* afterShadeEvent = nullptr)
+        {
+            ThrowIfFailed(m_svgf.Context(), neb_gi_trace_finish(m_svgf.Context(), commandList, afterShadeEvent), "neb_gi_trace_finish");
+        }
+
         // the acceleration structure is built on the device; these report what came out of it
         uint32_t BvhDepth() const
         {
