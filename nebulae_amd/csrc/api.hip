@@ -446,13 +446,14 @@ static hipError_t geometry_ensure(neb_ctx* ctx, uint32_t row0, uint32_t row1, hi
         ctx->geom_hi = row1;
         return e;
     }
-    if (row0 < ctx->geom_lo) {
-        e = decode(row0, ctx->geom_lo);
-        ctx->geom_lo = row0;
-    }
-    if (e == hipSuccess && row1 > ctx->geom_hi) {
-        e = decode(ctx->geom_hi, row1);
-        ctx->geom_hi = row1;
+    if (row0 < ctx->geom_lo || row1 > ctx->geom_hi) {
+        // rows beside the valid run are missing: a strip's halo rows, which every level from here on taps.  ALL resident rows that are not
+        // valid yet are decoded now, both sides in one launch (a 135-row strip's frame: two 4.6-us launches less than decoding per request)
+        e = launch_decode_geometry2(ctx->W, ctx->row_begin, ctx->row_begin, ctx->geom_lo, ctx->geom_hi, ctx->row_end,
+                                    (const uint32_t*)ctx->planes[NEB_PLANE_DEPTH][ctx->cur], (const uint2*)ctx->planes[NEB_PLANE_NORMAL][ctx->cur],
+                                    (float4*)ctx->planes[NEB_PLANE_GEOMETRY][0], stream);
+        ctx->geom_lo = ctx->row_begin;
+        ctx->geom_hi = ctx->row_end;
     }
     return e;
 }

@@ -920,8 +920,17 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
         return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_gi_trace: rows not resident");
     if (c->samplesPerPixel == 0 || c->maxPathVertices > 8)
         return gi_fail(ctx, NEB_ERR_INVALID_ARG, "neb_gi_trace: samplesPerPixel must be >= 1 and maxPathVertices <= 8 (MaxPathtracingRecursionDepth)");
-    if (row0 == row1)
+    if (row0 == row1) { // nothing to trace; a begun dispatch still pairs with its finish
+        if (phase == 1 && g->begun - g->finished < 2u) {
+            GiState::DispatchSet& e = g->sets[g->begun & 1u];
+            e.split_c = *c;
+            e.split_row0 = e.split_row1 = row0;
+            g->begun++;
+        } else if (phase == 2) {
+            g->finished++;
+        }
         return NEB_OK;
+    }
     GI_GUARD(ctx);
     ScopedRange range("GI: Query Pass"); // "GI: NRC Query Pass", DeferredRenderer.cpp:434 (the NRC calls are stubbed here)
     const size_t npx = (size_t)ctx->W * (ctx->row_end - ctx->row_begin);

@@ -83,6 +83,8 @@ hipError_t launch_atrous_fused_temporal(const SvgfLaunch& L, bool only_level, co
 // decodes depth / normal rows [row0, row1) (all W columns) into the geometry plane
 hipError_t launch_decode_geometry(uint32_t W, uint32_t row_begin, uint32_t row0, uint32_t row1, const uint32_t* depth, const uint2* normal,
                                   float4* geometry, hipStream_t s);
+hipError_t launch_decode_geometry2(uint32_t W, uint32_t row_begin, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const uint32_t* depth,
+                                   const uint2* normal, float4* geometry, hipStream_t s);
 
 // raysort.hip: stable LSD radix sort of (key, value) pairs on key bits [0, bits), bits <= 16 (enqueue only)
 size_t ray_sort_scratch_bytes(size_t n);

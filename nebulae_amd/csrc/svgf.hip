@@ -211,6 +211,30 @@ __global__ __launch_bounds__(256) void svgf_decode_geometry_kernel(const uint32_
     geometry[i] = make_float4(N.x, N.y, N.z, depth_unorm24(depth[i]));
 }
 
+// ... of two row ranges in one launch (the halo rows above and below a strip's own: one launch where two tiny ones cost their latency twice)
+__global__ __launch_bounds__(256) void svgf_decode_geometry2_kernel(const uint32_t* __restrict__ depth, const uint32_t* __restrict__ normal32,
+                                                                    float4* __restrict__ geometry, size_t first_a, size_t n_a, size_t first_b, size_t n_b)
+{
+    const size_t k = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_a + n_b)
+        return;
+    const size_t i = k < n_a ? first_a + k : first_b + (k - n_a);
+    const float3 N = oct16_unpack_zw(normal32[2 * i + 1]);
+    geometry[i] = make_float4(N.x, N.y, N.z, depth_unorm24(depth[i]));
+}
+
+hipError_t launch_decode_geometry2(uint32_t W, uint32_t row_begin, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, const uint32_t* depth,
+                                   const uint2* normal, float4* geometry, hipStream_t s)
+{
+    const size_t n_a = a0 < a1 ? (size_t)(a1 - a0) * W : 0, n_b = b0 < b1 ? (size_t)(b1 - b0) * W : 0;
+    if (n_a + n_b == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(svgf_decode_geometry2_kernel, dim3((unsigned)((n_a + n_b + 255) / 256)), dim3(256), 0, s, depth,
+                       reinterpret_cast<const uint32_t*>(normal), geometry, n_a ? (size_t)(a0 - row_begin) * W : 0, n_a,
+                       n_b ? (size_t)(b0 - row_begin) * W : 0, n_b);
+    return hipGetLastError();
+}
+
 hipError_t launch_decode_geometry(uint32_t W, uint32_t row_begin, uint32_t row0, uint32_t row1, const uint32_t* depth, const uint2* normal,
                                   float4* geometry, hipStream_t s)
 {
