@@ -421,7 +421,7 @@ class Workload:
         #            follows on the main stream.  Whole 1080p frame 649 -> 614-622 us, 540-row strip 402 -> 373, 270 rows 271 -> 235.
         #  "defer":  the whole GI dispatch of frames f+1 and f+2 on two side streams and two record sets ("gi_defer_resolve" = 2), meeting the SVGF
         #            passes at neb_gi_resolve: best on the smallest strips (135 rows: 208 -> 149 us, split: 166), no gain on big ones.
-        own_px = (self.own[1] - self.own[0]) * GW
+        own_px = ((GH + world - 1) // world) * GW  # (the largest strip's: every rank must take the same form -- the timed regions hold collectives)
         splittable = do_gi and spp == 1 and int(r.gi_ui.max_path_vertices) <= 2  # (one sample, one bounce per pixel: what neb_gi_trace_begin / _finish take)
         forced = os.environ.get("NEB_BENCH_PIPELINE")  # experiments: "split" | "defer"
         self.mode = None
