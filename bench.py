@@ -20,6 +20,12 @@ the same JSON line for N > 1:
                   orbiting for half the frames and still for the rest -- the reference's policy (SVGF
                   skipped while moving, history reset on the first still frame) and "always-on".
 
+Frames in flight (`--overlap auto`, the default; `off` = every stage of a frame on one stream): the K timed steps are K whole frames between two
+barriers + device synchronisations, with the next frame's ray generation + closest-hit walk running on a side stream beside this frame's shadow pass
+and SVGF chain (neb_gi_trace_begin / _finish; strips of at most 0.3 M pixels: the whole GI dispatch of the next two frames on two record sets).  Same
+frames bit for bit; `config.frames_in_flight` says which, `value_one_frame_in_flight` is the rate of the same K steps run serially.
+(NEB_BENCH_PIPELINE=split|defer forces a form: experiments.)
+
 Prints ONE JSON line (rank 0) with "roofline" (dominant SVGF kernel = a-trous level, HBM bound,
 algorithmic 46 B/px/level) and "cpu_baseline" (the scalar C/C++ oracle on the host cores).
 """
