@@ -408,6 +408,8 @@ class Workload:
             r.svgf.set_option("gi_sort_rays", args.sort_rays)
         if args.sun_table >= 0:
             r.svgf.set_option("gi_sun_table", args.sun_table)
+        if os.environ.get("NEB_BENCH_SUN_HINTS"):  # tuning: occluder hints tried per hit in the shade pass (0, 2, 4)
+            r.svgf.set_option("gi_sun_hints", int(os.environ["NEB_BENCH_SUN_HINTS"]))
         r.submit_commands_pbr_lighting()     # direct sun term of the static view (row f1), computed once, outside the timed region
         rt.synchronize()
         self.direct = self.rad_view[r.svgf.get_current_resource_index()].clone()
@@ -549,6 +551,9 @@ class Workload:
         self.barrier()
         dt = time.perf_counter() - t0
         rays = self.r.ray_count(reset=True) if self.do_gi else 0
+        # of those, the sun-visibility queries the table answered inside the shade pass (no walk): `rays` counts QUERIES, SURVEY 8d's formula
+        answered = self.r.sun_table_stats()["rays_answered"] if self.do_gi else 0
+        _, self.last_answered = self.reduce_max_sum(dt, answered)
         return self.reduce_max_sum(dt, rays)
 
     def parallelism_label(self):
@@ -671,6 +676,7 @@ def main(argv=None, rt=None, emit=None):
     # that every timed frame is a steady-state denoised frame; `warmup_run` on the line says what ran)
     warmup_run = max(args.warmup, 1)
     dt, rays_total = w.timed(args.steps, warmup_run)
+    answered_total = w.last_answered
     assert all(w.ran_svgf), "SVGF was skipped inside the timed region"
     if do_gi:  # (as of the ray count that ended the timed region: sides proven lit, shadow rays the table answered in those K frames)
         bvh["sun_table"] = r.sun_table_stats()
@@ -726,6 +732,7 @@ def main(argv=None, rt=None, emit=None):
         r.svgf.set_option("svgf_profile", 0)
     rt.synchronize()
     rays_ev = (r.ray_count(reset=True) if do_gi else 0) // (3 if world == 1 else 2)  # (batches of NPROF frames)
+    answered_ev = (r.sun_table_stats()["rays_answered"] if do_gi else 0) // (3 if world == 1 else 2)
     t_gi = avg([e["gi0"].elapsed_time(e["gi1"]) for e in ev]) * 1e-3
     fused = bracketed = False
     atrous_samples = None
@@ -805,8 +812,15 @@ def main(argv=None, rt=None, emit=None):
                        "frames_in_flight": frames_in_flight,
                        "scene_device_bytes": scene_bytes, "bvh": bvh, "library_build_id": library_build_id()},
             "frames_per_s_with_final_gather": fps_with_gather,
+            # rays = W H spp (1 + hit fraction) per frame: one bounce ray per pixel + one sun-visibility QUERY per hit.  Most of the
+            # queries are answered by the sun table inside the shade pass; `traced_*` counts only the rays a traverser walked (bounce rays + the
+            # shadow rays left in the lists) -- the figure to read as traverser throughput
             "mrays_per_s": (rays_total / dt / 1e6) if do_gi else None,
+            "traced_mrays_per_s": ((rays_total - answered_total) / dt / 1e6) if do_gi else None,
             "gi_kernel_mrays_per_s": (rays_ev / NPROF / t_gi / 1e6) if do_gi else None,
+            "gi_kernel_traced_mrays_per_s": ((rays_ev - answered_ev) / NPROF / t_gi / 1e6) if do_gi else None,
+            "rays_per_frame": {"queries": rays_total / args.steps, "traced": (rays_total - answered_total) / args.steps,
+                               "answered_by_sun_table": answered_total / args.steps} if do_gi else None,
             "weak_scaling": weak,
             "config5": config5,
             "kernel_us": {"gi_trace": t_gi * 1e6, "temporal": None if fused else t_temporal * 1e6,

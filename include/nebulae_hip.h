@@ -125,6 +125,8 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *                       (neb_gi_sun_table_stats) instead of tracing the shadow ray, and trace the rest from compacted ray lists;
  *                       2 = the table answers but the remaining rays keep the sorted / tiled pass (A/B arm); results are bit-identical
  *                       in all three;
+ *   "gi_sun_hints":     4 (default), 2 or 0: how many of a triangle's occluder hints the shade pass tries (with the traverser's own
+ *                       triangle test) before it leaves the shadow ray to the list pass; results are bit-identical in all three;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);
  *   "svgf_fuse":        0 (default) / 1 (opt-in), see neb_svgf_atrous;   "svgf_profile": 0 (default) / 1 / 2, see neb_svgf_level_times. */
 int neb_set_option(neb_ctx* ctx, const char* key, int value);
@@ -337,6 +339,10 @@ int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream);
  * their loop iterations -- {waves, loop iterations, iterations that ran a node phase, lanes live in those, iterations that ran a leaf
  * phase, lanes live in those}; a wave executes every phase some lane needs, so lanes / (64 x iterations) is the lane utilisation. */
 int neb_gi_wave_stats(neb_ctx* ctx, uint64_t out[6]);
+/* Diagnostics (same collection): where in the breadth-first node array the closest-hit pass's node visits fall -- {visits of nodes with
+ * an index below 64, below 256, below 1024, below 4096, node phases that ended with more than 12 entries on the ray's stack}; the
+ * total is neb_gi_traversal_stats' bounce node visits.  (What a copy of the top of the tree in LDS would serve.) */
+int neb_gi_node_index_stats(neb_ctx* ctx, uint64_t out[5]);
 /* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);
 /* Diagnostics / tests: runs the library's ray-reordering sort (raysort.hip: stable LSD radix sort on key bits

@@ -310,6 +310,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_table needs a scene (neb_gi_set_scene) and 0, 1 or 2");
         return NEB_OK;
     }
+    if (!strcmp(key, "gi_sun_hints")) {
+        if (gi_set_sun_hints(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_hints needs a scene (neb_gi_set_scene) and 0, 2 or 4");
+        return NEB_OK;
+    }
     if (!strcmp(key, "gi_max_bvh_depth")) {
         if (gi_set_max_bvh_depth(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_max_bvh_depth needs a scene and a depth in 1..21");

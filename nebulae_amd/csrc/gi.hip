@@ -70,6 +70,7 @@ struct GiArgs {
     uint32_t* shadow_counts;     // per-workgroup shadow-ray counts (every sun-visibility query, traced or answered by the table)
     uint32_t* table_counts;      // per-workgroup count of the shadow rays the sun table answered
     uint32_t sun_table;          // 1: the shading records carry the sun-visibility table of THIS frame's sun (gi_sun_table.hip)
+    uint32_t hint_pairs;         // pairs of occluder hints the shade pass tries per hit (option "gi_sun_hints" / 2: 0, 1 or 2)
     uint32_t W, row_begin, row0, row1, tiles_x;
     uint32_t sample;             // index of the sample this launch handles
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
@@ -133,28 +134,63 @@ __device__ __forceinline__ bool gi_pixel(const GiArgs& a, uint32_t& x, uint32_t&
 
 // Ray accounting without same-address atomics (one hot word saturates at ~90 atomics/us on MI355X, which cost
 // more than the traversal itself): every workgroup owns one slot of a per-kernel count array; the host sums them.
-__device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine)
+__device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine, uint32_t slot)
 {
     uint32_t total = mine;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         total += __shfl_down(total, off);
-    if (threadIdx.x == 0 && total)
-        block_counts[blockIdx.x] += total; // slot owned by this workgroup; launches on one stream are ordered
+    if ((threadIdx.x & 63u) == 0 && total)
+        block_counts[slot] += total; // slot owned by this wave; launches on one stream are ordered
 }
+__device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine) { count_rays(block_counts, mine, blockIdx.x); }
 
 #ifndef NEB_FAST_RAYGEN
 #define NEB_FAST_RAYGEN 0 // A/B arm: 1 = 1-ulp hardware rcp / rsq / sqrt / x^5 in ray generation, 2 = also v_sin / v_cos.  Measured: the
                           // kernel takes 380 us either way (377 us exact) although ray generation is ~15 % of its instructions, and
                           // six parity tests leave their 2e-5 band (a direction that moves by an ulp lands on another texel footprint)
 #endif
+// Workgroups of kRgWaves waves, one 8x8 pixel tile per wave (tile = workgroup * kRgWaves + wave): the waves of a workgroup share one copy of
+// the top of the tree in LDS (TreeletT: kRgTreelet nodes), staged when the workgroup starts; their stacks keep kRgStack entries in LDS.
+// LDS per CU at 8 waves per SIMD: 32 x kRgStack x 256 B of stacks + (32 / kRgWaves) x kRgTreelet x 64 B of treelets <= 160 KB.
+#ifndef NEB_RG_WAVES
+#define NEB_RG_WAVES 1
+#endif
+#ifndef NEB_RG_STACK
+#define NEB_RG_STACK 12 // (no bounce ray of the bench frame ever holds more than 12 entries: tools/gi_wave_stamps.py; deeper ones go to the private array)
+#endif
+#ifndef NEB_RG_TREELET
+#define NEB_RG_TREELET 0
+#endif
+#ifndef NEB_RG_LANE_FREE
+#define NEB_RG_LANE_FREE 0
+#endif
+constexpr int kRgWaves = NEB_RG_WAVES, kRgStack = NEB_RG_STACK, kRgTreelet = NEB_RG_TREELET;
+constexpr bool kRgLaneFree = NEB_RG_LANE_FREE != 0;
+#ifndef NEB_RG_MODE
+#define NEB_RG_MODE 3 // bit 0: address-as-stack-pointer (TravStackA), bit 1: child codes selected through LDS slots, bit 2: ... all four read up front, bit 3: ... and the three pushes without branches (with bit 0)
+#endif
+constexpr int kRgMode = NEB_RG_MODE;
+static_assert(32 * ((kRgStack + ((kRgMode & 8) ? 1 : 0)) * 256 + ((kRgMode & 46) ? 1024 : 0)) + (32 / kRgWaves) * kRgTreelet * 64 <= 160 * 1024 || NEB_TRACE_WAVES < 8,
+              "LDS budget of the closest-hit pass: 32 waves per CU of stacks and child slots (+ treelets) in 160 KB");
 template <bool FAST, bool FAST_TRIG>
-__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
+__global__ __launch_bounds__(64 * kRgWaves, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
 {
-    __shared__ int stack_mem[kLdsStack * 64];
-    uint32_t x, y;
-    size_t i;
-    const bool active = gi_pixel<kRaygenRuns>(a, x, y, i);
+    __shared__ int stack_all[kRgWaves][(kRgStack + ((kRgMode & 8) ? 1 : 0)) * 64]; // (+ the spare row of TravStackA::push3)
+    __shared__ f32x4 treelet_mem[kRgTreelet > 0 ? 4 * kRgTreelet : 1];
+    __shared__ int child_slot_mem[(kRgMode & 46) ? kRgWaves * 256 : 4];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u; // (wave: a scalar, and so is all tile arithmetic)
+    int* stack_mem = stack_all[wave];
+    [[maybe_unused]] TreeletT<(kRgTreelet > 0 ? kRgTreelet : 1)> tl{};
+    if constexpr (kRgTreelet > 0) {
+        tl = stage_treelet<(kRgTreelet > 0 ? kRgTreelet : 1)>(a.S, treelet_mem, threadIdx.x, 64u * kRgWaves);
+        __syncthreads();
+    }
+    const uint32_t tile = gi_block<kRaygenRuns>() * kRgWaves + wave;
+    const uint32_t tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+    const uint32_t x = tile_x * 8 + (lane & 7), y = a.row0 + tile_y * 8 + (lane >> 3);
+    const uint32_t i = (y - a.row_begin) * a.W + x; // (32 bits: one register across the walk)
+    const bool active = x < a.W && y < a.row1; // (a tile past the last one has y >= row1)
     uint32_t rays = 0;
     uint32_t wave_stamp[5] = {0u, 0u, 0u, 0u, 0u}; // diagnostics (a.stats): the closest-hit loop's wave stamps, see Hit
     if (active) {
@@ -198,7 +234,18 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         }
         if (bounce && !a.raygen_only && a.S.n_tris) {
             Hit hit;
-            const bool found = traverse(a.S, org, dir, 0.01f, kTraceMax, false, stack_mem + threadIdx.x, hit, a.stats != 0u);
+            bool found;
+            [[maybe_unused]] int* slots = (kRgMode & 46) ? child_slot_mem + wave * 256u + 4u * lane : nullptr;
+            if constexpr (kRgMode != 0) {
+                static_assert(kRgMode == 0 || (kRgTreelet == 0 && !kRgLaneFree), "the round-5 stack / select forms are built without the treelet arms");
+                found = a.stats ? traverse_t<false, true, kRgStack, NoTreelet, false, kRgMode>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, NoTreelet{}, stack_mem, slots)
+                                : traverse_t<false, false, kRgStack, NoTreelet, false, kRgMode>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, NoTreelet{}, stack_mem, slots);
+            } else if constexpr (kRgTreelet > 0)
+                found = a.stats ? traverse_t<false, true, kRgStack, decltype(tl), kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit, tl)
+                                : traverse_t<false, false, kRgStack, decltype(tl), kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit, tl);
+            else
+                found = a.stats ? traverse_t<false, true, kRgStack, NoTreelet, kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit)
+                                : traverse_t<false, false, kRgStack, NoTreelet, kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit);
             if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only
@@ -206,12 +253,18 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
                 wave_stamp[4] = hit.w_leaf_lanes;
                 atomicAdd(a.ray_counter + 1, (unsigned long long)hit.node_visits);
                 atomicAdd(a.ray_counter + 2, (unsigned long long)hit.tri_tests);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    atomicAdd(a.ray_counter + 11 + k, (unsigned long long)hit.top_visits[k]);
+                atomicAdd(a.ray_counter + 15, (unsigned long long)hit.deep_sp);
                 a.R.srec[4 * i + kSrContrib].w = __uint_as_float(hit.node_visits + ((hit.tri_tests + 3u) >> 2)); // loop iterations of this ray
             }
         }
         a.R.hit[i] = h;
     }
-    count_rays(a.bounce_counts, rays);
+    if (tile >= a.tiles_x * ((a.row1 - a.row0 + 7u) / 8u))
+        return; // (a wave past the last tile: nothing to count)
+    count_rays(a.bounce_counts, rays, tile);
     if (a.stats) { // the stamps are wave-uniform among the lanes that walked longest: the wave's totals are the maxima over its lanes
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -219,10 +272,10 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
                 v = max(v, (uint32_t)__shfl_xor((int)v, off));
-            if (threadIdx.x == 0)
+            if (lane == 0)
                 atomicAdd(a.ray_counter + 6 + k, (unsigned long long)v);
         }
-        if (threadIdx.x == 0)
+        if (lane == 0)
             atomicAdd(a.ray_counter + 5, 1ull);
     }
 }
@@ -337,7 +390,7 @@ __device__ __forceinline__ void shade_pixel(const GiArgs& a, size_t i, const flo
 #pragma unroll
                 for (int pair = 0; pair < kHints && !hinted_hit; pair += 2) {
                     const uint32_t h0 = ts.hint[pair];
-                    if (h0 == kNoHint)
+                    if (h0 == kNoHint || (uint32_t)pair >= 2u * a.hint_pairs)
                         break;
                     const uint32_t h1 = ts.hint[pair + 1] != kNoHint ? ts.hint[pair + 1] : h0;
                     const float4 a0 = a.S.tris[3 * h0], b0 = a.S.tris[3 * h0 + 1], c0 = a.S.tris[3 * h0 + 2];
@@ -1000,9 +1053,14 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
     // unsorted (the sort's six launches cost more than coherence is worth to the ~14 % that are left).
     // the sun-visibility table: brought up to date with this frame's sun (a rebuild only when the sun or the scene changed -- and
     // then only once the new sun has held for a second frame: a sun that is being dragged is traced the plain way meanwhile)
-    if (phase != 1) // (the flags are read by the shade pass)
+    if (phase != 1) { // (the flags are read by the shade pass)
         GI_HIP(ctx, gi_sun_table_update(g, *c, (hipStream_t)stream));
+        GI_HIP(ctx, gi_sun_table_order(g, (hipStream_t)stream)); // a rewrite of the flags enqueued on another stream comes first
+        g->last_dispatch_stream = (hipStream_t)stream;
+        g->last_dispatch_stream_set = true;
+    }
     a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
+    a.hint_pairs = (uint32_t)g->sun_hints / 2u;
     const bool compact = a.sun_table && g->compact_shadow;
     const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
     if (sort_shadow || g->sort_bounce) {
@@ -1072,7 +1130,8 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
         for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
             a.bounce = b;
             if (b == 1 && phase != 2) {
-                hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), dim3((grid.x + kRgWaves - 1) / kRgWaves),
+                                   dim3(64 * kRgWaves), 0, (hipStream_t)stream, a);
             }
             if (phase == 1)
                 continue;
@@ -1292,6 +1351,15 @@ int neb_gi_wave_stats(neb_ctx* ctx, uint64_t out[6])
     return NEB_OK;
 }
 
+int neb_gi_node_index_stats(neb_ctx* ctx, uint64_t out[5])
+{
+    if (!ctx || !ctx->gi || !out)
+        return NEB_ERR_INVALID_ARG;
+    for (int k = 0; k < 5; ++k)
+        out[k] = ctx->gi->last_stats[11 + k];
+    return NEB_OK;
+}
+
 int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream)
 {
     if (!ctx || !ctx->gi || !out)
@@ -1418,6 +1486,13 @@ int gi_set_sun_table(neb_ctx* ctx, int on)
         return NEB_ERR_STATE;
     ctx->gi->sun_table = on != 0;
     ctx->gi->compact_shadow = on != 2; // 2 (A/B arm): the table answers, but the remaining rays keep the sorted / tiled shadow pass
+    return NEB_OK;
+}
+int gi_set_sun_hints(neb_ctx* ctx, int n)
+{
+    if (!ctx->gi || (n != 0 && n != 2 && n != 4))
+        return NEB_ERR_STATE;
+    ctx->gi->sun_hints = n;
     return NEB_OK;
 }
 int gi_set_debug_hits(neb_ctx* ctx, int on)

@@ -49,6 +49,8 @@ void gi_destroy(GiState* g)
         return;
     for (void* p : g->allocs)
         (void)hipFree(p);
+    if (g->sun_table_event)
+        (void)hipEventDestroy(g->sun_table_event);
     delete g;
 }
 
@@ -1887,6 +1889,7 @@ int neb_gi_build_bvh(neb_ctx* ctx, neb_stream stream_)
     g->view.shade = d_shade;
     g->view.nodes = d_wide;
     g->view.qnodes = d_wide_q;
+    g->view.n_qnodes = n_wide;
     g->view.root = root_code;
     g->n_nodes = n_wide;
     g->bvh_depth = (uint32_t)max_depth;

@@ -143,6 +143,7 @@ struct SceneView {
     const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
     uint32_t n_tris;
     int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
+    uint32_t n_qnodes;       // nodes in qnodes (breadth-first: the first ones are the top of the tree, see TreeletT)
 };
 
 struct GiState {
@@ -190,10 +191,21 @@ struct GiState {
     float sun_table_key[4] = {0, 0, 0, 0}; // {sunLightDirection, sunTanHalfAngle} the flags were built for
     unsigned long long* d_sun_counts = nullptr; // sides proven lit {+, -} by the last build
     uint32_t sun_table_builds = 0;
+    // The flags are rewritten IN PLACE in the shading records, on the stream of the dispatch that noticed the new sun, while the host
+    // state says "table valid" from the moment of the enqueue: a dispatch on ANOTHER stream ("gi_defer_resolve" = 2, or a host that
+    // alternates streams) waits for this event first, or its shade pass could read the previous sun's lit bits of records the
+    // 15-ms build has not reached yet.
+    hipEvent_t sun_table_event = nullptr;   // recorded behind every launch that rewrites the flags
+    hipStream_t sun_table_stream = nullptr; // ... on this stream
+    bool sun_table_event_pending = false;   // not yet seen complete
+    hipStream_t last_dispatch_stream = nullptr; // stream of the last dispatch that read the flags (a rewrite on another stream waits for the device)
+    bool last_dispatch_stream_set = false;
     unsigned long long table_rays = 0; // shadow rays answered by the table as of the last neb_gi_ray_count
+    int sun_hints = 4;                // option "gi_sun_hints": occluder hints the shade pass tries per hit (0, 2 or 4)
     bool compact_shadow = true;       // with the table on: the rays it leaves are compacted into lists by the shade pass ("gi_sun_table" = 2: off)
 };
 hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream);
+hipError_t gi_sun_table_order(GiState* g, hipStream_t stream);
 
 void gi_on_resize(GiState* g);
 void gi_destroy(GiState* g);

@@ -32,6 +32,7 @@ struct SunTableArgs {
     SceneView S;
     lit::Frame F;
     double scene_hmax; // highest point of the scene along L
+    double box_pad;    // padding of the node boxes (floats) in the double-precision cull: an ulp of the scene's largest coordinate, at least 1e-5
     float4* shade;     // the shading records (writable view of S.shade)
     unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint
 };
@@ -100,10 +101,10 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
             double qa[2] = {1e300, -1e300}, qb[2] = {1e300, -1e300}, qh = 1e300;
             for (int s = 0; s < 2; ++s)
                 if (R[s].valid) {
-                    const double reach = (a.scene_hmax - R[s].h_min + lit::kMarginH) * a.F.tau + lit::kMarginR;
+                    const double reach = (a.scene_hmax - R[s].h_min + a.F.margin) * a.F.tau + a.F.margin;
                     qa[0] = fmin(qa[0], R[s].bb_a[0] - reach), qa[1] = fmax(qa[1], R[s].bb_a[1] + reach);
                     qb[0] = fmin(qb[0], R[s].bb_b[0] - reach), qb[1] = fmax(qb[1], R[s].bb_b[1] + reach);
-                    qh = fmin(qh, R[s].h_min - lit::kMarginH);
+                    qh = fmin(qh, R[s].h_min - a.F.margin);
                 }
             int stack[64];
             int sp = 0;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                         continue;
                     // sun-space bounds of the world box: centre +- |axis| . half extent (padded: the boxes are floats)
                     const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-                    const double e[3] = {0.5 * (hi[0] - lo[0]) + 1e-5, 0.5 * (hi[1] - lo[1]) + 1e-5, 0.5 * (hi[2] - lo[2]) + 1e-5};
+                    const double e[3] = {0.5 * (hi[0] - lo[0]) + a.box_pad, 0.5 * (hi[1] - lo[1]) + a.box_pad, 0.5 * (hi[2] - lo[2]) + a.box_pad};
                     const double ca = c[0] * a.F.A[0] + c[1] * a.F.A[1] + c[2] * a.F.A[2];
                     const double ea = e[0] * fabs(a.F.A[0]) + e[1] * fabs(a.F.A[1]) + e[2] * fabs(a.F.A[2]);
                     if (ca + ea < qa[0] || ca - ea > qa[1])
@@ -227,6 +228,32 @@ __global__ void sun_table_clear_kernel(float4* shade, uint32_t n)
     }
 }
 
+// behind a launch that rewrites the flags: dispatches on other streams order themselves after it (gi_sun_table_order)
+static hipError_t mark_rewrite(GiState* g, hipStream_t stream)
+{
+    if (!g->sun_table_event)
+        if (hipError_t e = hipEventCreateWithFlags(&g->sun_table_event, hipEventDisableTiming); e != hipSuccess)
+            return e;
+    g->sun_table_stream = stream;
+    g->sun_table_event_pending = true;
+    return hipEventRecord(g->sun_table_event, stream);
+}
+
+// Every dispatch calls this after gi_sun_table_update: work on `stream` that reads the shading records runs after the last rewrite of
+// their flags, whichever stream that was enqueued on.
+hipError_t gi_sun_table_order(GiState* g, hipStream_t stream)
+{
+    if (!g->sun_table_event_pending || stream == g->sun_table_stream)
+        return hipSuccess; // (same stream: ordered by the stream itself)
+    const hipError_t q = hipEventQuery(g->sun_table_event);
+    if (q == hipSuccess) {
+        g->sun_table_event_pending = false;
+        return hipSuccess;
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
+    return hipStreamWaitEvent(stream, g->sun_table_event, 0);
+}
+
 // Brings the table in the shading records up to date with (scene, sun) -- or clears it when the option is off.  Enqueue only.
 hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream)
 {
@@ -236,12 +263,15 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     const bool want = g->sun_table;
     // The flags live in the shading records every dispatch reads.  With two dispatches in flight ("gi_defer_resolve" = 2) the other one may still
     // be running on another stream: whatever rewrites the flags first waits for the device (a change of sun or of the option -- never a steady frame).
-    auto quiesce = [&]() { return g->defer_resolve == 2 ? hipDeviceSynchronize() : hipSuccess; };
+    // The same for a host that moved to another stream since its last dispatch: that one's shade pass may still be reading the flags.
+    auto quiesce = [&]() { return (g->defer_resolve == 2 || (g->last_dispatch_stream_set && g->last_dispatch_stream != stream)) ? hipDeviceSynchronize() : hipSuccess; };
     if (!want) {
         if (g->sun_table_state != 0) {
             if (hipError_t e = quiesce(); e != hipSuccess)
                 return e;
             hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->view.n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->view.n_tris);
+            if (hipError_t em = mark_rewrite(g, stream); em != hipSuccess)
+                return em;
             g->sun_table_state = 0;
         }
         return hipGetLastError();
@@ -260,11 +290,20 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         return hipSuccess;
     }
     const float dd = key[0] * key[0] + key[1] * key[1] + key[2] * key[2];
-    if (!(dd > 0.0f) || !(dd < 1e30f) || !(key[3] >= 0.0f) || !(key[3] < 1.0f)) { // no usable sun: no certificate, every ray is traced
+    // The certificate's slack grows with the scene's coordinates (lit_predicate.h: an ulp there is what fp32 hit points and triangle tests
+    // can be off by) while the ray offset stays 1e-2: past +-218 units the slack would eat a quarter of the offset and nothing could be proven
+    // with a margin worth the name -- such a scene gets no table (and no 16-ms build), every shadow ray is traced.
+    double scene_abs_max = 0.0;
+    for (int k = 0; k < 3; ++k)
+        scene_abs_max = fmax(scene_abs_max, fmax(fabs((double)g->scene_min[k]), fabs((double)g->scene_max[k])));
+    const bool too_large = !lit::margin_usable(lit::margin_for(scene_abs_max));
+    if (too_large || !(dd > 0.0f) || !(dd < 1e30f) || !(key[3] >= 0.0f) || !(key[3] < 1.0f)) { // no usable sun / scale: no certificate, every ray is traced
         if (g->sun_table_state != 0) {
             if (hipError_t e = quiesce(); e != hipSuccess)
                 return e;
             hipLaunchKernelGGL(sun_table_clear_kernel, dim3((g->view.n_tris + 255) / 256), dim3(256), 0, stream, const_cast<float4*>(g->view.shade), g->view.n_tris);
+            if (hipError_t em = mark_rewrite(g, stream); em != hipSuccess)
+                return em;
         }
         g->sun_table_state = 0;
         return hipGetLastError();
@@ -285,17 +324,20 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         return e;
     SunTableArgs a;
     a.S = g->view;
-    lit::make_frame(key, key[3], a.F);
+    lit::make_frame(key, key[3], scene_abs_max, a.F);
+    a.box_pad = fmax(1e-5, 1.1920928955078125e-7 * scene_abs_max);
     double hmax = -1e300;
     for (int k = 0; k < 8; ++k) {
         const double p[3] = {(k & 1) ? g->scene_max[0] : g->scene_min[0], (k & 2) ? g->scene_max[1] : g->scene_min[1],
                              (k & 4) ? g->scene_max[2] : g->scene_min[2]};
         hmax = fmax(hmax, p[0] * a.F.L[0] + p[1] * a.F.L[1] + p[2] * a.F.L[2]);
     }
-    a.scene_hmax = hmax + 1e-3;
+    a.scene_hmax = hmax + fmax(1e-3, a.F.margin);
     a.shade = const_cast<float4*>(g->view.shade);
     a.counts = g->d_sun_counts;
     hipLaunchKernelGGL(sun_table_kernel, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
+    if (hipError_t em = mark_rewrite(g, stream); em != hipSuccess)
+        return em;
     memcpy(g->sun_table_key, key, sizeof(key));
     g->sun_table_state = 1;
     g->sun_table_builds++;

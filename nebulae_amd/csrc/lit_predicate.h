@@ -23,18 +23,37 @@ namespace neb {
 namespace lit {
 
 constexpr double kOffset = 1e-2;      // the shadow ray leaves the surface by GN * 1e-2 (pathtracer.hlsl:560)
-constexpr double kMarginH = 2e-4;     // slack on heights: float rounding of hit points, directions and the traverser's triangle test
-constexpr double kMarginR = 2e-4;     // slack on lateral reach
+// Slack on heights and on lateral reach (Frame::margin): what fp32 rounding can move between the exact geometry this header reasons
+// about and what the device computes -- the hit point hitP = org + dir * t of a bounce ray that may have started anywhere in the scene
+// (three roundings at the magnitude of the scene's coordinates and of the ray's length), the ray origin hitP +- GN * 1e-2 (one more),
+// and the traverser's triangle test on (origin - v0, e1, e2), a dozen operations on differences of scene coordinates.  Every one of
+// them is an ulp of a number no larger than the scene: the slack is kMarginUlps ulps of the largest coordinate magnitude of the
+// scene box, never below the 2e-4 world units rounds 1-4 validated on scenes of +-15 units (there: 109 ulps).  (Round 4 had the
+// absolute 2e-4 alone: at |coordinate| ~ 2000 that is under two ulps.)  The ray offset is 1e-2 whatever the scene's size
+// (pathtracer.hlsl:560), so the certificate has a scale beyond which it cannot hold: where the slack exceeds kMaxMarginShare of the
+// offset, gi_sun_table_update does not build a table at all (margin_usable) -- every shadow ray of such a scene is traced.
+constexpr double kMarginFloor = 2e-4;
+constexpr double kMarginUlps = 96.0;
+constexpr double kMaxMarginShare = 0.25;
+NEB_LIT_HD double margin_for(double scene_abs_max)
+{
+    const double m = kMarginUlps * 1.1920928955078125e-7 * scene_abs_max; // FLT_EPSILON = the ulp of 1
+    return m > kMarginFloor ? m : kMarginFloor;
+}
+NEB_LIT_HD bool margin_usable(double margin) { return margin <= kMaxMarginShare * kOffset; }
 constexpr double kMinFacing = 0.05;   // |n . L| below this: the receiver is (nearly) edge-on to the sun, no certificate
 constexpr double kMinNormalDot = 0.25; // vertex normals further apart than this: the interpolated normal is not bounded well enough
 
 struct Frame {
     double A[3], B[3], L[3]; // orthonormal, L towards the sun
     double tau;              // tan(half angle of the sun disk), padded
+    double margin;           // slack on heights and lateral reach, from the scene's size (margin_for)
 };
 
-NEB_LIT_HD void make_frame(const float sun_direction[3], float tan_half_angle, Frame& F)
+// scene_abs_max: the largest |coordinate| of the scene's bounding box (every ray origin, hit point and triangle lies inside it)
+NEB_LIT_HD void make_frame(const float sun_direction[3], float tan_half_angle, double scene_abs_max, Frame& F)
 {
+    F.margin = margin_for(scene_abs_max);
     double l[3] = {-(double)sun_direction[0], -(double)sun_direction[1], -(double)sun_direction[2]};
     const double n = std::sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
     for (int k = 0; k < 3; ++k)
@@ -183,10 +202,10 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
 {
     double hmax = O.h[0] > O.h[1] ? O.h[0] : O.h[1];
     hmax = O.h[2] > hmax ? O.h[2] : hmax;
-    const double smax = hmax - R.h_min + kMarginH; // the most a ray can have climbed when it meets O
+    const double smax = hmax - R.h_min + F.margin; // the most a ray can have climbed when it meets O
     if (smax <= 0.0)
         return false;
-    const double rho = smax * F.tau + kMarginR;    // ... and drifted sideways
+    const double rho = smax * F.tau + F.margin;    // ... and drifted sideways
     // clip O (as a 3-D polygon) by the three vertical planes through R's edges, pushed out by the drift and the offset box
     double pa[8], pb[8], ph[8], qa[8], qb[8], qh[8];
     int n = 3;
@@ -218,10 +237,10 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
     if (n == 0)
         return false;
     // s = h_q - h_o <= [h_q - plane_R(q_ab)] + grad1 * rho - c_lo; linear over the clipped polygon: the maximum is at a vertex
-    const double bound = R.c_lo - R.grad1 * rho - kMarginH;
+    const double bound = R.c_lo - R.grad1 * rho - F.margin;
     for (int i = 0; i < n; ++i) {
         const double f = ph[i] - (R.h0 + R.ga * pa[i] + R.gb * pb[i]);
-        // (an intersection point is computed with rounding of ~1e-16 relative: covered by kMarginH)
+        // (an intersection point is computed with rounding of ~1e-16 relative: covered by the margin)
         if (!(f <= bound))
             return true;
     }

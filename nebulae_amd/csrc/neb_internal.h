@@ -105,6 +105,7 @@ int gi_set_sort_rays(neb_ctx* ctx, int mask);
 int gi_set_max_bvh_depth(neb_ctx* ctx, int depth);
 int gi_set_exact_shade(neb_ctx* ctx, int on);
 int gi_set_sun_table(neb_ctx* ctx, int on);
+int gi_set_sun_hints(neb_ctx* ctx, int n);
 
 } // namespace neb
 

@@ -224,6 +224,12 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_wave_stats(self._ctx, v), "neb_gi_wave_stats")
         return dict(zip(("waves", "iterations", "node_iterations", "node_lanes", "leaf_iterations", "leaf_lanes"), [int(x) for x in v]))
 
+    def node_index_stats(self):
+        """closest-hit pass, same collection: node visits by position in the breadth-first node array, and deep stacks"""
+        v = (C.c_uint64 * 5)()
+        self._check(self._lib.neb_gi_node_index_stats(self._ctx, v), "neb_gi_node_index_stats")
+        return dict(zip(("below_64", "below_256", "below_1024", "below_4096", "deep_stack_phases"), [int(x) for x in v]))
+
     def sun_table_stats(self):
         """{sides proven lit (+normal side / -normal side), shadow rays the table answered as of the last ray_count(), builds}"""
         v = (C.c_uint64 * 4)()

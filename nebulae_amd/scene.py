@@ -712,6 +712,32 @@ def atrium_standin(target_triangles=262267, n_submeshes=103, n_materials=25, tex
     return sc
 
 
+def moved_scene(sc, scale=1.0, shift=(0.0, 0.0, 0.0)):
+    """The same scene scaled about the origin and then translated (world' = world * scale + shift): a copy that shares the vertex
+    streams and differs in the per-geometry surfaceToWorld matrices (row-vector convention, as GIProcessedScene.cpp:47-93 uploads
+    them).  For the tests that put a scene far from the origin or blow it up."""
+    out = Scene(f"{sc.name}-x{scale:g}+{tuple(float(v) for v in shift)}")
+    out.materials, out.textures = sc.materials, sc.textures
+    for g in sc.geometries:
+        h = dict(g)
+        M = g["M"].astype(np.float64).copy()
+        M[:, :3] *= scale
+        M[3, :3] += np.asarray(shift, np.float64)
+        h["M"] = np.ascontiguousarray(M, F)
+        out.geometries.append(h)
+    return out
+
+
+def moved_camera(cam, scale=1.0, shift=(0.0, 0.0, 0.0)):
+    """the camera that sees moved_scene(sc, scale, shift) as `cam` saw sc (near / far planes scale along)"""
+    out = CameraDesc()
+    out.eye[:] = [float(cam.eye[k] * scale + shift[k]) for k in range(3)]
+    out.target[:] = [float(cam.target[k] * scale + shift[k]) for k in range(3)]
+    out.up[:] = list(cam.up)
+    out.vfov_deg, out.znear, out.zfar = cam.vfov_deg, cam.znear * scale, cam.zfar * scale
+    return out
+
+
 def framing_camera(sc):
     """A view of a whole scene from outside its box (bench.py --scene with a file that is not Sponza): the reference's orbit
     camera (InspectCamera.h:31-42) about the box centre, far enough for the vertical field of view to hold the box."""

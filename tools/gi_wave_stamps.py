@@ -32,6 +32,10 @@ for long_thin in (False, True):
     print(f"  loop iterations per wave {I / ws['waves']:.1f} (a ray needs {it.mean():.1f} on average, p99 {np.percentile(it, 99):.0f}, max {it.max()})")
     print(f"  node phase: ran in {ws['node_iterations'] / I:.3f} of the iterations with {ws['node_lanes'] / max(ws['node_iterations'], 1):.1f} of 64 lanes live")
     print(f"  leaf phase: ran in {ws['leaf_iterations'] / I:.3f} of the iterations with {ws['leaf_lanes'] / max(ws['leaf_iterations'], 1):.1f} of 64 lanes live")
+    ni = r.node_index_stats()
+    nv = max(st["bounce_nodes"], 1)
+    print("  node visits by index in the breadth-first array: " + ", ".join(f"< {k}: {ni[f'below_{k}'] / nv:.3f}" for k in (64, 256, 1024, 4096))
+          + f"; node phases that ended with > 12 stack entries: {ni['deep_stack_phases'] / nv:.4f}")
     node_cost, leaf_cost = 130.0, 110.0  # wave-instructions of one node phase / one leaf phase (two triangles), from the ISA
     total = ws["node_iterations"] * node_cost + ws["leaf_iterations"] * leaf_cost
     useful = ws["node_lanes"] / 64.0 * node_cost + ws["leaf_lanes"] / 64.0 * leaf_cost

@@ -9,6 +9,15 @@
 
 using namespace neb::lit;
 
+// the largest |coordinate| of the scene (what the device takes from the scene box): sets the certificate's slack
+static double scene_abs_max(int n, const float* verts)
+{
+    double m = 0.0;
+    for (long i = 0; i < 9L * n; ++i)
+        m = std::max(m, std::fabs((double)verts[i]));
+    return m;
+}
+
 // area of polygon O (projected) clipped to the projected triangle R (no dilation): how much of R's footprint O covers
 static double covered_area(const Receiver& R, const Tri& O, double shrink)
 {
@@ -42,7 +51,7 @@ static double covered_area(const Receiver& R, const Tri& O, double shrink)
 extern "C" void lit_proto_hints(int n, const float* verts, const float* normals, const float* sun_dir, float tan_half, float* cover /* n x 2 x 2 */)
 {
     Frame F;
-    make_frame(sun_dir, tan_half, F);
+    make_frame(sun_dir, tan_half, scene_abs_max(n, verts), F);
     std::vector<Tri> T(n);
     double amin = 1e30, amax = -1e30, bmin = 1e30, bmax = -1e30;
     for (int i = 0; i < n; ++i)
@@ -102,7 +111,13 @@ extern "C" void lit_proto_flags(int n, const float* verts, const float* normals,
                                 double* stats)
 {
     Frame F;
-    make_frame(sun_dir, tan_half, F);
+    make_frame(sun_dir, tan_half, scene_abs_max(n, verts), F);
+    if (!margin_usable(F.margin)) { // the device builds no table for a scene this large (gi_sun_table_update): nothing is called lit
+        std::fill(flags, flags + n, (unsigned char)0);
+        if (stats)
+            stats[0] = stats[1] = 0;
+        return;
+    }
     std::vector<Tri> T(n);
     double amin = 1e30, amax = -1e30, bmin = 1e30, bmax = -1e30, hmax = -1e30;
     for (int i = 0; i < n; ++i)
@@ -140,7 +155,7 @@ extern "C" void lit_proto_flags(int n, const float* verts, const float* normals,
                 invalid += 1;
                 continue;
             }
-            const double reach = (hmax - R.h_min + kMarginH) * F.tau + kMarginR;
+            const double reach = (hmax - R.h_min + F.margin) * F.tau + F.margin;
             bool lit = true;
             for (int y = cy(R.bb_b[0] - reach); y <= cy(R.bb_b[1] + reach) && lit; ++y)
                 for (int x = cx(R.bb_a[0] - reach); x <= cx(R.bb_a[1] + reach) && lit; ++x)
