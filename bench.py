@@ -810,6 +810,9 @@ def main(argv=None, rt=None, emit=None):
                        "global_width": GW, "global_height": GH, "atrous_levels": L, "spp": args.spp,
                        "parallelism": parallelism, "link": (link.label() if link is not None else None), "halo_rows": halo_rows, "rows_per_strip": GH // world,
                        "frames_in_flight": frames_in_flight,
+                       # what the metric's own strong-scaling curve cannot exceed at N strips, before a byte is exchanged: one strip's frame alone on
+                       # a GPU (measured with the exchange stubbed, strips.STRIP_FRAME_US_1080P) -- to read a SCALE_rNN.json against
+                       "strong_scaling_ceiling": (strips.strong_scaling_ceilings() if (GW, GH) == (1920, 1080) else None),
                        "scene_device_bytes": scene_bytes, "bvh": bvh, "library_build_id": library_build_id()},
             "frames_per_s_with_final_gather": fps_with_gather,
             # rays = W H spp (1 + hit fraction) per frame: one bounce ray per pixel + one sun-visibility QUERY per hit.  Most of the

@@ -221,6 +221,42 @@ int neb_strips_exchange(neb_ctx* ctx, void* comm, const neb_halo_plane* planes, 
                         neb_stream stream);
 const char* neb_strips_last_error(void); /* message of the last failed neb_strips_* call that had no context */
 
+/* ONE call per strip frame (round 5): everything a strip context does between "radiance[cur] holds the direct term" and "radiance[cur]
+ * holds this strip's rows of the denoised frame" -- the GI dispatch on its rows, the temporal pass, the halo exchange(s) and the a-trous
+ * levels on the row ranges the exchange scheme prescribes -- enqueued by the library in the order and on the streams nebulae_amd/strips.py
+ * used to spell out call by call (105 us of host time per 135-row strip frame from Python against 150 us of device time).  The partition
+ * arithmetic is the library's (the same as strips.StripPartition: strips of H / n_strips rows; resident rows = strip +- halo, which the
+ * context must have been created with: row_begin / row_end of neb_create_info).
+ *   scheme NEB_STRIPS_ONCE:      one exchange per frame -- the h = sum_l 2 * 2^l boundary rows of the temporally accumulated radiance and of the
+ *                                variance plane, beside the interior rows of level 0 (side stream); level l filters strip +- sum_{m>l} 2 * 2^m rows;
+ *   scheme NEB_STRIPS_PER_LEVEL: an exchange of 2 * 2^l rows of the level's source plane in front of every level;
+ *   scheme NEB_STRIPS_OVERLAP:   SURVEY 8e's: GI, temporal pass and levels 0 .. L-2 also on the band beyond the strip, one exchange in front
+ *                                of the widest level, one of the final image's band rows (next frame's history) after it.
+ * Transports: `comm` = an RCCL communicator (neb_strips_comm_create; one process or thread per GPU: every rank makes the matching call),
+ * or `peers` = the neighbouring strips' contexts of a host that drives all strips from ONE thread (any devices: rows are pushed with
+ * hipMemcpyPeerAsync; scheme ONCE only).  Such a host calls neb_strip_frame_begin for every strip, then neb_strip_frame_finish for every
+ * strip, frame after frame; a host with a communicator calls neb_strip_frame (= begin + finish).
+ * flags: NEB_STRIP_RESET_HISTORY = neb_svgf_reset_history first (the frame policy's reset, src/DeferredRenderer.cpp:601-609).
+ * constants == NULL: no GI dispatch (radiance[cur] is complete as it is). */
+enum { NEB_STRIPS_ONCE = 0, NEB_STRIPS_PER_LEVEL = 1, NEB_STRIPS_OVERLAP = 2 };
+enum { NEB_STRIP_RESET_HISTORY = 1 };
+typedef struct neb_strip_plan {
+    uint32_t n_strips, strip; /* this context holds strip `strip` of `n_strips` */
+    uint32_t scheme;          /* NEB_STRIPS_* */
+    uint32_t flags;           /* NEB_STRIP_* */
+} neb_strip_plan;
+typedef struct neb_strip_peers {
+    neb_ctx* up;   /* the context of strip - 1 (NULL for the first strip) */
+    neb_ctx* down; /* the context of strip + 1 (NULL for the last) */
+} neb_strip_peers;
+struct neb_gi_constants; /* (defined below) */
+int neb_strip_frame(neb_ctx* ctx, const struct neb_gi_constants* constants, void* comm, const neb_strip_plan* plan, neb_stream stream);
+int neb_strip_frame_begin(neb_ctx* ctx, const struct neb_gi_constants* constants, const neb_strip_plan* plan, const neb_strip_peers* peers, neb_stream stream);
+int neb_strip_frame_finish(neb_ctx* ctx, void* comm, const neb_strip_plan* plan, const neb_strip_peers* peers, neb_stream stream);
+/* The row ranges the plan implies for this strip (what strips.StripPartition computes; for hosts and tests):
+ * out = {owned row0, row1, resident row0, row1, GI / temporal row0, row1, halo rows, band rows}; levels = the context's a-trous levels. */
+int neb_strip_rows(const neb_ctx* ctx, const neb_strip_plan* plan, uint32_t out[8]);
+
 /* ======================= GI: one-bounce indirect diffuse =========================================
  * Replaces DeferredRenderer::SubmitCommandsGIPathtrace (src/DeferredRenderer.cpp:396-591) driving
  * assets/shaders/pathtracer.hlsl with the NRC calls stubbed (rtxgi/Nrc.hlsli:579-621), and the DXR

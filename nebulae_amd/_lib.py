@@ -76,6 +76,20 @@ _SIGS = {
 
 
 
+class StripPlan(C.Structure):
+    """neb_strip_plan"""
+    _fields_ = [("n_strips", C.c_uint32), ("strip", C.c_uint32), ("scheme", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class StripPeers(C.Structure):
+    """neb_strip_peers"""
+    _fields_ = [("up", C.c_void_p), ("down", C.c_void_p)]
+
+
+STRIP_SCHEMES = {"once": 0, "per_level": 1, "overlap": 2}
+STRIP_RESET_HISTORY = 1
+
+
 def _gi_sigs():
     from . import scene as S
     return {
@@ -102,6 +116,10 @@ def _gi_sigs():
         "neb_pbr_direct": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_void_p]),
         "neb_tonemap": (C.c_int, [C.c_void_p, C.c_void_p]),
         "neb_gbuffer_raycast": (C.c_int, [C.c_void_p, C.POINTER(S.CameraDesc), C.c_void_p]),
+        "neb_strip_frame": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.c_void_p, C.POINTER(StripPlan), C.c_void_p]),
+        "neb_strip_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(S.GIConstants), C.POINTER(StripPlan), C.POINTER(StripPeers), C.c_void_p]),
+        "neb_strip_frame_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StripPlan), C.POINTER(StripPeers), C.c_void_p]),
+        "neb_strip_rows": (C.c_int, [C.c_void_p, C.POINTER(StripPlan), C.POINTER(C.c_uint32)]),
     }
 
 

@@ -196,6 +196,11 @@ int neb_destroy(neb_ctx* ctx)
     free_planes(ctx);
     for (hipEvent_t e : ctx->prof_events)
         (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ctx->strip.ready, ctx->strip.done, ctx->strip.pushed, ctx->strip.frame_done})
+        if (e)
+            (void)hipEventDestroy(e);
+    if (ctx->strip.xstream)
+        (void)hipStreamDestroy(ctx->strip.xstream);
     gi_destroy(ctx->gi);
     delete ctx;
     return NEB_OK;

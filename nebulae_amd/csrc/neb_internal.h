@@ -125,5 +125,13 @@ struct neb_ctx {
     std::vector<hipEvent_t> prof_events; // levels + 1 of them once profiling has run
     uint32_t prof_recorded = 0;
     neb::GiState* gi = nullptr;
+    // neb_strip_frame* (strips.hip): a side stream for the halo exchange beside level 0, and the events that order it -- created on first use
+    struct StripSync {
+        hipStream_t xstream = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr; // launch stream -> side stream, side stream -> launch stream
+        hipEvent_t pushed = nullptr;                // local transport: this strip's boundary rows are in its neighbours' halos
+        hipEvent_t frame_done = nullptr;            // ... this strip's frame has been enqueued to its end (its halo rows may be overwritten after it)
+        bool frame_done_recorded = false;
+    } strip;
     std::string last_error;
 };

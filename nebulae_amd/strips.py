@@ -53,8 +53,19 @@ def frame_factors(n):
 # (EXCHANGE_LATENCY_US, LINK_GBPS) are GUESSES until a run with N > 1 ranks measures them: `measure_link` does that in a few
 # milliseconds at start-up (bench.py calls it), and only a measured link lets "auto" leave the default scheme.
 # Override with NEB_STRIPS_EXCHANGE_LATENCY_US / NEB_STRIPS_LINK_GBPS.
-ATROUS_US_PER_MPX_LEVEL = 14.0   # one a-trous level over a megapixel (28 us per 2.07 Mpx level at 1080p, profiles/r03m*)
-GI_TEMPORAL_US_PER_MPX = 290.0   # the GI dispatch + the temporal pass over a megapixel (571 + 30 us per 2.07 Mpx)
+ATROUS_US_PER_MPX_LEVEL = 12.8   # one a-trous level over a megapixel (26.6 us per 2.07 Mpx level at 1080p, profiles/r04g_kernel_stats.csv)
+GI_TEMPORAL_US_PER_MPX = 250.0   # the GI dispatch + the temporal pass over a megapixel (486 + 32 us per 2.07 Mpx, profiles/r05*_kernel_stats.csv)
+# What ONE strip of a 1920x1080 frame takes alone on a GPU, frames in flight as bench.py runs them (profiles/r04_strip_overlap.txt, one MI355X,
+# exchange stubbed): the ceiling of the metric's strong-scaling curve before a byte is exchanged -- N strips finish a frame in this time.
+STRIP_FRAME_US_1080P = {1: 645.0, 2: 379.0, 4: 237.0, 8: 150.0}
+
+
+def strong_scaling_ceilings(frame_us_one_gpu=None):
+    """{N: (frames/s, speed-up over one GPU)} a 1920x1080 frame in N row strips cannot exceed: a strip's own frame time on one MI355X with the
+    exchange stubbed (STRIP_FRAME_US_1080P) -- a 135-row strip is a latency-bound launch sequence, not an eighth of the work.  bench.py prints it in
+    `config` so that a SCALE_rNN.json can be read against it."""
+    t1 = float(frame_us_one_gpu or STRIP_FRAME_US_1080P[1])
+    return {n: {"frames_per_s": round(1e6 / (t if n > 1 else t1), 1), "speedup": round(t1 / (t if n > 1 else t1), 2)} for n, t in STRIP_FRAME_US_1080P.items()}
 EXCHANGE_LATENCY_US = 12.0       # GUESS: one grouped send + receive with a neighbour, launch to completion, message size aside
 LINK_GBPS = 60.0                 # GUESS: sustained one-direction rate of one xGMI link for row blocks of a few hundred KB
 
@@ -257,35 +268,106 @@ class StripRenderer(DeferredRenderer):
         import os
         self._staging = os.environ.get("NEB_STRIPS_STAGING") or None  # None | "host" | "device"
         self._staging_decided = False
-        self.exchange = exchange or os.environ.get("NEB_STRIPS_EXCHANGE") or "torch"
-        if self.exchange not in ("torch", "rccl"):
-            raise ValueError(f"unknown halo exchange backend {self.exchange!r}")
+        requested = exchange or os.environ.get("NEB_STRIPS_EXCHANGE")
+        if requested not in (None, "torch", "rccl"):
+            raise ValueError(f"unknown halo exchange backend {requested!r}")
         self._comm = None
         self._xstream = None
         self._device = device
-        if self.exchange == "rccl" and part.N > 1:
-            self._comm = self._create_comm()
+        self.exchange = requested or "torch"
+        if part.N > 1 and self._rccl_wanted(requested):
+            # round 5: the library's own transport is the default wherever it can run (ONE transport to debug on a multi-GPU node); when the
+            # caller did not ask for it, a librccl that cannot be loaded sends every rank back to torch's P2P together
+            self._comm = self._create_comm(required=requested == "rccl")
+            self.exchange = "rccl" if self._comm is not None else "torch"
+        self._plan = None  # neb_strip_plan of this strip (the one-call frame of the C ABI), made on first use
 
-    def _create_comm(self):
-        """ncclCommInitRank through the library: rank 0 draws the unique id, the torch group (any backend) carries it."""
+    def _rccl_wanted(self, requested):
+        if requested is not None:
+            return requested == "rccl"
+        try:  # default: the HIP denoiser on a GPU, ranks talking over RCCL already (not the gloo stand-ins of the CPU tests)
+            import torch
+            import torch.distributed as dist
+            return (isinstance(self.svgf, SVGFDenoiser) and torch.cuda.is_available() and dist.is_initialized()
+                    and dist.get_backend(self.group) == "nccl")
+        except Exception:
+            return False
+
+    def _create_comm(self, required=True):
+        """ncclCommInitRank through the library: rank 0 draws the unique id, the torch group (any backend) carries it -- with a flag that
+        says whether rank 0 could (librccl present): without it every rank falls back together (or raises, when RCCL was asked for)."""
         import ctypes as C
 
         import torch
         import torch.distributed as dist
         lib = self._lib
         buf = (C.c_char * 128)()
+        ok = 1
         if self.rank == 0:
-            self._check(lib.neb_strips_unique_id(buf), "neb_strips_unique_id")
+            ok = 1 if lib.neb_strips_unique_id(buf) == 0 else 0
         on_cuda = dist.get_backend(self.group) != "gloo"
-        t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        t = torch.frombuffer(bytearray(bytes(buf) + bytes([ok])), dtype=torch.uint8).clone()
         t = t.cuda() if on_cuda else t
         dist.broadcast(t, src=0, group=self.group)
-        ident = bytes(t.cpu().numpy().tobytes())
+        raw = bytes(t.cpu().numpy().tobytes())
+        if not raw[128]:
+            if required:
+                raise NebError(f"neb_strips_unique_id failed on rank 0: {lib.neb_strips_last_error().decode() if self.rank == 0 else 'see rank 0'}")
+            return None
         comm = C.c_void_p()
-        rc = lib.neb_strips_comm_create(self._device, self.part.N, self.rank, ident, C.byref(comm))
+        rc = lib.neb_strips_comm_create(self._device, self.part.N, self.rank, raw[:128], C.byref(comm))
         if rc != 0:
             raise NebError(f"neb_strips_comm_create failed ({rc}): {lib.neb_strips_last_error().decode()}")
         return comm
+
+    # ---- the one-call strip frame of the C ABI (neb_strip_frame*, strips.hip): the partition arithmetic and the enqueue order below, in C ----
+    def strip_plan(self, reset_history=False):
+        from . import _lib
+        return _lib.StripPlan(self.part.N, self.rank, _lib.STRIP_SCHEMES[self.part.scheme], _lib.STRIP_RESET_HISTORY if reset_history else 0)
+
+    def has_c_frame(self):
+        """the library call can serve this strip: one strip (the whole frame), or the RCCL transport (a torch.distributed exchange is Python's)"""
+        return isinstance(self.svgf, SVGFDenoiser) and (self.part.N == 1 or self._comm is not None)
+
+    def submit_strip_frame_local(self, phase, up, down, with_gi=True, stream=None):
+        """The same frame for a host that drives ALL strips from one thread (several contexts, any devices): `phase` "begin" for every strip,
+        then "finish" for every strip; up / down = the neighbouring StripRenderers (None at the image's edges).  Rows travel by
+        hipMemcpyPeerAsync between the contexts (scheme "once").  -> whether SVGF runs this frame."""
+        import ctypes as C
+
+        from . import _lib
+        st = C.c_void_p(self.info.stream if stream is None else stream)
+        skip = self.dynamic_scene_this_frame and not self.denoise_while_moving
+        if skip:
+            if phase == "begin" and with_gi:
+                self.submit_commands_gi_pathtrace(stream=stream)
+            return False
+        peers = _lib.StripPeers(up._ctx if up is not None else None, down._ctx if down is not None else None)
+        if phase == "begin":
+            self._plan = self.strip_plan(self.reset_history)
+            self.reset_history = False
+            c = self.global_constants() if with_gi else None
+            self._check(self._lib.neb_strip_frame_begin(self._ctx, C.byref(c) if c is not None else None, C.byref(self._plan), C.byref(peers), st),
+                        "neb_strip_frame_begin")
+        else:
+            self._check(self._lib.neb_strip_frame_finish(self._ctx, None, C.byref(self._plan), C.byref(peers), st), "neb_strip_frame_finish")
+        return True
+
+    def submit_strip_frame(self, with_gi=True, stream=None):
+        """GI rows -> temporal rows -> exchange(s) -> levels as ONE library call (neb_strip_frame); the frame policy stays here.
+        -> whether SVGF ran (src/DeferredRenderer.cpp:595)."""
+        import ctypes as C
+        st = C.c_void_p(self.info.stream if stream is None else stream)
+        skip = self.dynamic_scene_this_frame and not self.denoise_while_moving
+        if skip:
+            if with_gi:
+                self.submit_commands_gi_pathtrace(stream=stream)
+            return False
+        plan = self.strip_plan(self.reset_history)
+        self.reset_history = False
+        c = self.global_constants() if with_gi else None
+        self._check(self._lib.neb_strip_frame(self._ctx, C.byref(c) if c is not None else None, self._comm, C.byref(plan), st), "neb_strip_frame")
+        return True
 
     def _swap_rows_rccl_begin(self, planes, plan):
         """The same exchange through neb_strips_exchange, on a side stream so that work enqueued on the launch stream between
@@ -437,6 +519,9 @@ class StripRenderer(DeferredRenderer):
             return False
         st = self.info.stream
         own = self.part.owned(self.rank)
+        if events is None and self.part.N > 1 and self._comm is not None:
+            # the steady-state frame over RCCL: one library call for temporal rows -> exchange(s) -> levels (the sequence below, in C)
+            return self.submit_strip_frame(with_gi=False)
         if self.reset_history:
             self.reset_history = False
             self.svgf.reset_history(st)

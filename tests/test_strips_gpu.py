@@ -182,3 +182,64 @@ def test_c_entry_point_exchanges_rows_over_rccl():
     assert lib.neb_strips_exchange(d._ctx, comm, planes, 2, bad, 1, C.c_void_p(stream)) == -5
     assert lib.neb_strips_comm_destroy(comm) == 0
     d.destroy()
+
+
+@pytest.mark.parametrize("scheme", ["once", "per_level", "overlap"])
+@pytest.mark.parametrize("H,N,L", [(192, 2, 5), (1080, 8, 5), (2160, 4, 5), (240, 2, 3), (96, 1, 4)])
+def test_the_librarys_strip_rows_are_the_partitions(scheme, H, N, L):
+    """neb_strip_rows (the partition arithmetic of the one-call strip frame, strips.hip) == strips.StripPartition, every strip of every scheme"""
+    import ctypes as C
+
+    from nebulae_amd import _lib
+    from nebulae_amd.svgf import SVGFDenoiser
+    W = 64
+    part = strips.StripPartition(W, H, N, L, scheme=scheme)
+    for r in range(N):
+        res = part.resident(r)
+        d = SVGFDenoiser()
+        d.init(W, H, atrous_levels=L, row_begin=res[0], row_end=res[1] if N > 1 else 0)
+        out = (C.c_uint32 * 8)()
+        plan = _lib.StripPlan(N, r, _lib.STRIP_SCHEMES[scheme], 0)
+        d._check(d._lib.neb_strip_rows(d._ctx, C.byref(plan), out), "neb_strip_rows")
+        assert tuple(out) == (*part.owned(r), *part.resident(r), *part.gi_rows(r), part.halo, part.band), (scheme, r, tuple(out))
+        d.destroy()
+
+
+@pytest.mark.parametrize("W,H,N", [(256, 192, 2), (1920, 1080, 8)])
+def test_one_call_strip_frames_with_the_local_transport_equal_full_image(W, H, N):
+    """neb_strip_frame_begin / _finish (ONE library call per strip and phase: GI rows -> temporal rows -> halo rows pushed into the neighbours'
+    contexts -> level 0's interior beside them -> its border rows -> the other levels) on N strip contexts of one GPU, all on one stream and
+    without a host synchronisation inside the frame: the strips must equal the full image (fused chain, one context) bit for bit -- frame
+    policy included (frame 1 moves: SVGF skipped; frame 2 resets the history)."""
+    L = 5
+    sc = S.atrium_standin(target_triangles=20000, n_submeshes=40, tex_size=32)
+    cam = S.sponza_camera()
+    full = strips.StripRenderer(strips.StripPartition(W, H, 1, L), 0)
+    part = strips.StripPartition(W, H, N, L, scheme="once")
+    rs = [strips.StripRenderer(part, k) for k in range(N)]
+    for f in range(1, 7):
+        info = RenderInfo(scene=sc, camera=cam, frame_index=f)
+        for r in [full] + rs:
+            r.begin_frame(info)
+            r.submit_commands_gbuffer()
+            r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).fill_(0.125)
+        ran_full = full.submit_strip_frame()  # one strip = the whole frame, through the same entry point
+        ran = [r.submit_strip_frame_local("begin", rs[k - 1] if k > 0 else None, rs[k + 1] if k + 1 < N else None) for k, r in enumerate(rs)]
+        ran2 = [r.submit_strip_frame_local("finish", rs[k - 1] if k > 0 else None, rs[k + 1] if k + 1 < N else None) for k, r in enumerate(rs)]
+        assert ran == ran2 == [ran_full] * N
+        for r in [full] + rs:
+            r.end_frame()
+    torch.cuda.synchronize()
+    want = full.svgf.download(PLANE_RADIANCE)
+    got = np.concatenate([r.svgf.download(PLANE_RADIANCE, row0=part.owned(r.rank)[0], nrows=part.owned(r.rank)[1] - part.owned(r.rank)[0]) for r in rs], axis=0)
+    assert np.isfinite(want).all() and float(np.abs(want[..., :3]).max()) > 0.2
+    assert np.array_equal(got, want)
+    # a plan that does not fit the context is refused with a message, before anything is enqueued
+    import ctypes as C
+
+    from nebulae_amd import _lib
+    bad = _lib.StripPlan(N, 0, _lib.STRIP_SCHEMES["per_level"], 0)
+    assert rs[0]._lib.neb_strip_frame(rs[0]._ctx, None, None, C.byref(bad), None) != 0
+    full.destroy()
+    for r in rs:
+        r.destroy()

@@ -15,7 +15,7 @@ from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL, PLANE_RADIANCE  # noqa: 
 
 sc, cam = S.atrium_standin(), S.sponza_camera()
 MODES = [int(m) for m in os.environ.get("NEB_SUN_TABLE_MODES", "1").split(",")]  # "gi_sun_table": 1 table + ray lists, 2 table + tiled / sorted pass, 0 off
-for N in (8, 8, 4, 2):  # (the first configuration also pays the process's one-time costs: listed twice)
+for N in ((8, 8, 4, 2) if not os.environ.get("NEB_HOST_COST_C_ONLY") else ()):  # (the first configuration also pays the process's one-time costs: listed twice)
     for scheme, mode in [(sch, m) for sch in ("once", "per_level") for m in MODES]:
         part = strips.StripPartition(1920, 1080, N, 5, scheme=scheme)
         r = strips.StripRenderer(part, N // 2)
@@ -47,4 +47,56 @@ for N in (8, 8, 4, 2):  # (the first configuration also pays the process's one-t
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         print(f"N = {N} ({part.H // N} rows), scheme {scheme}, gi_sun_table {mode}: host submits a frame in {(t1 - t0) / n * 1e6:.0f} us; wall {(t2 - t0) / n * 1e6:.0f} us per frame", flush=True)
+        r.destroy()
+
+# ---- round 5: the same strip frame as ONE library call per phase (neb_strip_frame_begin / _finish), all N strips of the frame on this one GPU
+# with the local transport (rows pushed between the contexts): host time per STRIP frame, the library calls alone and with the Python around them ----
+for N in (8, 4, 2):
+    part = strips.StripPartition(1920, 1080, N, 5, scheme="once")
+    rs = [strips.StripRenderer(part, k) for k in range(N)]
+    directs = []
+    for r in rs:
+        r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+        r.submit_commands_gbuffer()
+        torch.cuda.synchronize()
+        for pl in (PLANE_NORMAL, PLANE_DEPTH):
+            r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
+        r.submit_commands_pbr_lighting()
+        torch.cuda.synchronize()
+        directs.append(r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).clone())
+    nb = [(rs[k - 1] if k > 0 else None, rs[k + 1] if k + 1 < N else None) for k in range(N)]
+    t_calls = 0.0
+
+    def frame(f, timed=False):
+        global t_calls
+        info = RenderInfo(scene=sc, camera=cam, frame_index=f)
+        for r, d in zip(rs, directs):
+            r.begin_frame(info)
+            r.svgf.plane_tensor(PLANE_RADIANCE, r.svgf.get_current_resource_index()).copy_(d, non_blocking=True)
+        ta = time.perf_counter()
+        for phase in ("begin", "finish"):
+            for r, (up, down) in zip(rs, nb):
+                r.submit_strip_frame_local(phase, up, down)
+        t_calls += time.perf_counter() - ta
+        for r in rs:
+            r.end_frame()
+    for f in range(2, 40):
+        frame(f)
+    torch.cuda.synchronize()
+    # (N strips' worth of launches per frame on ONE device: the host is only "submitting" while the launch queue has room -- batches of three
+    # frames, drained in between, so that what is timed is the host's own work and not the device's back-pressure)
+    n, t_calls, t_host, t_wall, f = 0, 0.0, 0.0, 0.0, 40
+    for batch in range(12):
+        t0 = time.perf_counter()
+        for _ in range(3):
+            frame(f)
+            f += 1
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t_host += t1 - t0
+        t_wall += time.perf_counter() - t0
+        n += 3
+    print(f"N = {N} ({part.H // N} rows), one library call per strip and phase (local transport, all {N} strips on this GPU): host submits a STRIP frame in "
+          f"{t_host / n / N * 1e6:.0f} us, of which the two library calls {t_calls / n / N * 1e6:.0f} us; wall {t_wall / n / N * 1e6:.0f} us per strip frame", flush=True)
+    for r in rs:
         r.destroy()
