@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TEMPORAL_BYTES_PX = 82  # 60 B read + 22 B written
 ATROUS_BYTES_PX = 46    # per level: 30 B read + 16 B written
 GI_STREAM_BYTES_PX = 56  # 24 B G-buffer read + 32 B radiance read-modify-write
-PROFILE_ROUND = "r04"   # only PMC summaries of this round's kernels are quoted (profiles/r04*_*.json), and only of this very build
+PROFILE_ROUND = "r05"   # only PMC summaries of this round's kernels are quoted (profiles/r05*_*.json), and only of this very build
 
 
 def parse(argv=None):
@@ -97,6 +97,14 @@ def launch_ranks(n, argv, child=None, emit=None, timeout=None):
     process that initialised a GPU is ever replaced by exec."""
     import signal
     import subprocess
+    # Under a profiler this process is not what it seems: rocprofv3's preloaded tool library initialises the GPU before main() runs, and every
+    # rank started from here would be an exec out of a fork of a process that holds a GPU -- what this pool forbids (it takes the machine
+    # down).  Profile the ranks themselves instead: put rocprofv3 inside each rank's command, the rank program right after `--`.
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "HSA_TOOLS_LIB"))
+    if child is None and any(t in preload.lower() for t in ("rocprof", "roctracer", "rocprofiler")):
+        print("bench.py --gpus N refuses to start ranks from under a profiler (its preloaded library has initialised the GPU in this process): "
+              "launch the ranks with torch.distributed.run and profile each rank's own command", file=sys.stderr)
+        return 2
     child = child or [sys.executable, os.path.abspath(__file__)]
     port = _free_port()
     procs = []

@@ -24,10 +24,11 @@ class SvgfState(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(ORACLE_DIR, "libneb_oracle.so")
+        san = bool(os.environ.get("NEB_ORACLE_SAN"))  # tools/run_sanitized.sh: the ASan + UBSan build (libasan must be preloaded)
+        so = os.path.join(ORACLE_DIR, "libneb_oracle_san.so" if san else "libneb_oracle.so")
         srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".cpp", ".h"))]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["SAN=1"] if san else []))
         L = C.CDLL(so)
         L.svgf_ref_create.restype = C.POINTER(SvgfState)
         L.svgf_ref_create.argtypes = [C.c_int, C.c_int, C.c_int]

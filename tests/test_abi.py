@@ -58,6 +58,13 @@ def test_strip_exchange_entry_points_validate_arguments_without_a_gpu():
     assert lib.neb_strips_unique_id(None) == -1
     assert lib.neb_strips_comm_destroy(None) == 0
     assert lib.neb_strips_exchange(None, None, None, 0, None, 0, None) == -1
+    # the one-call strip frame: a null context is refused before anything else is looked at
+    plan = _lib.StripPlan(2, 0, 0, 0)
+    out = (C.c_uint32 * 8)()
+    assert lib.neb_strip_frame(None, None, None, C.byref(plan), None) == -1
+    assert lib.neb_strip_frame_begin(None, None, C.byref(plan), None, None) == -1
+    assert lib.neb_strip_frame_finish(None, None, C.byref(plan), None, None) == -1
+    assert lib.neb_strip_rows(None, C.byref(plan), out) == -1
 
 
 def test_strip_calls_report_a_missing_rccl_instead_of_crashing():

@@ -260,11 +260,26 @@ def test_bare_bench_gpus_2_is_its_own_launcher_and_fails_loudly_without_a_gpu():
     (no "launch with torch.distributed.run" refusal), each rank must refuse to run without a device (no CPU fallback), and the
     parent must exit non-zero."""
     import subprocess
+    if torch.cuda.is_available():  # (before anything is started: on a GPU box this would be a real two-rank 1080p bench)
+        pytest.skip("a GPU is present: covered by tests/test_bench_gpu.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-frames", "0"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present: covered by tests/test_bench_gpu.py")
     assert p.returncode != 0
     assert "needs a GPU" in p.stderr and "exited with code" in p.stderr and "torch.distributed.run" not in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_launcher_refuses_to_start_ranks_from_under_a_profiler():
+    """rocprofv3 preloads a tool library that initialises the GPU before bench.py's main() runs: starting the ranks from such a process would
+    be an exec out of a fork of a process that holds a GPU.  `bench.py --gpus N` then exits with 2 and says what to do instead."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ROCP_TOOL_LIBRARIES"] = "/opt/rocm/lib/librocprofiler-sdk-tool.so"  # (the variable alone: nothing is preloaded here)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-frames", "0"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert p.returncode == 2 and "refuses to start ranks from under a profiler" in p.stderr
+    for script in ("profile_round.sh", "ab_env.sh", "ab_svgf.sh"):
+        q = subprocess.run(["bash", os.path.join(ROOT, "tools", script), "tag", "--gpus", "2"], capture_output=True, text=True, timeout=60, cwd=ROOT,
+                           env=dict(os.environ, AB_BENCH_FLAGS="--gpus 2"))
+        assert q.returncode == 2 and "refuses --gpus" in q.stdout, (script, q.stdout, q.stderr)

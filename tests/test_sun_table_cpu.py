@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def proto(tmp_path_factory):
     so = tmp_path_factory.mktemp("lit") / "liblit_proto.so"
-    subprocess.check_call(["g++", "-O2", "-fopenmp", "-shared", "-fPIC", "-I", os.path.join(ROOT, "nebulae_amd", "csrc"),
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("NEB_ORACLE_SAN") else []  # tools/run_sanitized.sh
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-shared", "-fPIC"] + san + ["-I", os.path.join(ROOT, "nebulae_amd", "csrc"),
                            os.path.join(ROOT, "tools", "lit_proto.cpp"), "-o", str(so)])
     return C.CDLL(str(so))
 

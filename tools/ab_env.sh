@@ -1,6 +1,7 @@
 #!/bin/bash
 # tuning only: per-kernel mean durations (rocprofv3 --kernel-trace --stats) of `python bench.py` under different environment
 # settings.  usage (GPU box):  bash tools/ab_env.sh "NEB_PLOC_BUDGET=0" "NEB_PLOC_BUDGET=8388608 NEB_PLOC_RADIUS=32" ...
+case " $* $AB_BENCH_FLAGS " in *" --gpus "*) echo "$0 refuses --gpus: under rocprofv3 bench.py would start its ranks from a process the profiler has given a GPU (profile each rank's own command instead)"; exit 2;; esac
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 k=0

@@ -3,6 +3,7 @@
 # for each build_variants/lib_<name>.so given ("product" = the in-tree library).  AB_TEST=1 also runs the SVGF parity tests.
 # AB_FULL=1 profiles the whole frame (GI + SVGF) instead: the fused level-0 kernel then follows the GI kernels, as in the product.
 # usage (GPU box): bash tools/ab_svgf.sh product pipe1 ...
+case " $* $AB_BENCH_FLAGS " in *" --gpus "*) echo "$0 refuses --gpus: under rocprofv3 bench.py would start its ranks from a process the profiler has given a GPU (profile each rank's own command instead)"; exit 2;; esac
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 mode=--svgf-only; [ -n "$AB_FULL" ] && mode=

@@ -4,6 +4,7 @@
 #   The profiled runs keep ONE frame in flight (--overlap off): a kernel's duration and counters are then its own, not those of a kernel that ran beside
 #   the next frame's closest-hit walk (the bench line itself is the default run; its per-kernel times come from serial, event-timed frames anyway).
 # usage (on the GPU box, from the repo root):  bash tools/profile_round.sh r02a [extra bench.py flags]
+case " $* $AB_BENCH_FLAGS " in *" --gpus "*) echo "$0 refuses --gpus: under rocprofv3 bench.py would start its ranks from a process the profiler has given a GPU (profile each rank's own command instead)"; exit 2;; esac
 set -o pipefail
 tag=$1
 [ -n "$tag" ] || { echo "usage: $0 <tag> [bench.py flags]"; exit 2; }
