@@ -55,6 +55,9 @@
 #ifndef NEB_ATROUS_PK_CLASSIC // and in the separate levels (row strips, svgf_fuse = 0), which prefetch the next tile's radiance into registers
 #define NEB_ATROUS_PK_CLASSIC 1
 #endif
+#ifndef NEB_ATROUS_FEWER_LDS_READS // timing only (wrong results), see load_group
+#define NEB_ATROUS_FEWER_LDS_READS 0
+#endif
 #ifndef NEB_ATROUS_STAMPS // diagnostic builds only (tools/atrous_stamps.py): per-wave phase times from s_memtime
 #define NEB_ATROUS_STAMPS 0
 #endif
@@ -702,19 +705,19 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
 #pragma unroll
         for (int j = i; j < 3; ++j) {
             lkp[i][j] = tap_constant(phiN, i, j);
-            if constexpr (IN != kInLum)
+            if constexpr (IN != kInLum || R == 4) // (R = 4: two pairs of rows per lane leave no registers for the constants either)
                 lkp[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lkp[i][j])));
             else
                 asm volatile("" : "+v"(lkp[i][j]));
             lkp[j][i] = lkp[i][j];
         }
-    if constexpr (IN == kInLum)
+    if constexpr (IN == kInLum && R != 4)
         asm volatile("" : "+v"(cz), "+v"(phiN));
     // the packed tap's constants: {phiNormal, cz}, and per |dx| the pairs {lkp[.][0], lkp[.][1]} and {lkp[.][1], lkp[.][2]} (read straight
     // or swapped by op_sel): 14 registers where the scalar form holds 8
-    constexpr bool kPacked = NEB_ATROUS_PK && R == 2 && (IN == kInLum || (IN == kInFused && NEB_ATROUS_PK_FUSED) || (IN == kInClassic && NEB_ATROUS_PK_CLASSIC));
-    constexpr bool kLkScalar = IN != kInLum;
-    constexpr bool kPhased = NEB_ATROUS_PK != 3 && IN == kInLum; // (the fused kernel has no registers for a whole group's intermediate values)
+    constexpr bool kPacked = NEB_ATROUS_PK && (R == 2 || R == 4) && (IN == kInLum || (IN == kInFused && NEB_ATROUS_PK_FUSED) || (IN == kInClassic && NEB_ATROUS_PK_CLASSIC));
+    constexpr bool kLkScalar = IN != kInLum || R == 4;
+    constexpr bool kPhased = NEB_ATROUS_PK != 3 && IN == kInLum && R != 4; // (the fused kernel has no registers for a whole group's intermediate values)
     neb_f2 pcz = {phiN, cz}, lkq[3][2];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -879,22 +882,55 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
             if ((g & 1) == 0) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
+#if NEB_ATROUS_FEWER_LDS_READS == 1 // timing only (wrong results, and the compiler merges the identical taps: not a clean probe): one texel read per group instead of three / two -- what ANY saving of LDS reads could buy
+                    if (j > 0) {
+                        gA[0][j] = gA[0][0], gB[0][j] = gB[0][0];
+                        continue;
+                    }
+#endif
                     gA[0][j] = A[lrow_base + (j - 2) * XS];
+#if NEB_ATROUS_FEWER_LDS_READS == 2 // timing only (wrong results): the B plane read as 8 bytes instead of 16 -- a quarter of the LDS bytes gone, every VALU instruction still there
+                    {
+                        const float2 b2 = *reinterpret_cast<const float2*>(&B[lrow_base + (j - 2) * XS]);
+                        gB[0][j] = make_float4(b2.x, b2.y, gA[0][j].z, gA[0][j].w);
+                    }
+#else
                     gB[0][j] = B[lrow_base + (j - 2) * XS];
+#endif
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+#if NEB_ATROUS_FEWER_LDS_READS == 1
+                    if (j > 0) {
+                        gA[1][j] = gA[1][0], gB[1][j] = gB[1][0];
+                        continue;
+                    }
+#endif
                     gA[1][j] = A[lrow_base + (j + 1) * XS];
+#if NEB_ATROUS_FEWER_LDS_READS == 2
+                    {
+                        const float2 b2 = *reinterpret_cast<const float2*>(&B[lrow_base + (j + 1) * XS]);
+                        gB[1][j] = make_float4(b2.x, b2.y, gA[1][j].z, gA[1][j].w);
+                    }
+#else
                     gB[1][j] = B[lrow_base + (j + 1) * XS];
+#endif
                 }
             }
         };
         if constexpr (kPacked) {
-            // the lane's two output rows side by side (see tap2_geometry): staged row ir is tap dy = ir - 2 of row 0 and ir - 3 of row 1
-            const neb_f2 h0x = {n0x[0], n0x[1]}, h0y = {n0y[0], n0y[1]}, h0z = {n0z[0], n0z[1]};
-            const neb_f2 nz0 = {-z0[0], -z0[1]}, nl0 = {-lum0[0], -lum0[1]}, cl2 = {cl[0], cl[1]};
-            neb_f2 sr2 = {0.f, 0.f}, sg2 = {0.f, 0.f}, sb2 = {0.f, 0.f}, sw2 = {0.f, 0.f};
+            // the lane's output rows side by side in PAIRS (see tap2_geometry): pair p = rows 2 p, 2 p + 1; staged row ir is row lir = ir - 2 p of the
+            // pair's own six, tap dy = lir - 2 of its first row and lir - 3 of its second.  (R = 4, round 5: two pairs per lane -- a staged texel is
+            // read from LDS once for up to four output rows, 20 reads per pixel instead of 30 -- at the price of 16-row tiles and their registers.)
+            constexpr int NP = R / 2;
+            neb_f2 h0x[NP], h0y[NP], h0z[NP], nz0[NP], nl0[NP], cl2[NP], sr2[NP], sg2[NP], sb2[NP], sw2[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                h0x[p] = (neb_f2){n0x[2 * p], n0x[2 * p + 1]}, h0y[p] = (neb_f2){n0y[2 * p], n0y[2 * p + 1]}, h0z[p] = (neb_f2){n0z[2 * p], n0z[2 * p + 1]};
+                nz0[p] = (neb_f2){-z0[2 * p], -z0[2 * p + 1]}, nl0[p] = (neb_f2){-lum0[2 * p], -lum0[2 * p + 1]}, cl2[p] = (neb_f2){cl[2 * p], cl[2 * p + 1]};
+                sr2[p] = sg2[p] = sb2[p] = sw2[p] = (neb_f2){0.f, 0.f};
+            }
             load_group(0);
 #pragma unroll
             for (int g = 0; g < 2 * (R + 4); ++g) {
@@ -906,75 +942,83 @@ __global__ __launch_bounds__(256 * WX, (AtrousTile<S, R, IN, WX>::WAVES_PER_SIMD
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int kMaxGroup = 3;
                 const int ng = (g & 1) ? 2 : 3; // texels of this group: dx = -2, -1, 0 or 1, 2
-                if (ir == 0 || ir == R + 3) { // taps of one row only (dy = -2 of row 0, dy = +2 of row 1)
-                    const int k = ir == 0 ? 0 : 1;
 #pragma unroll
-                    for (int j = 0; j < ng; ++j) {
-                        const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
-                        const float4 tA = gA[g & 1][j];
-                        const float4 tB = gB[g & 1][j];
-                        const float w = tap_weight_neg(h0x[k], h0y[k], h0z[k], nz0[k], nl0[k], cl2[k], tA, tB, pcz.x, pcz.y, lkq[adx][1].y);
-                        sr2[k] = fmaf(w, tA.x, sr2[k]);
-                        sg2[k] = fmaf(w, tA.y, sg2[k]);
-                        sb2[k] = fmaf(w, tA.z, sb2[k]);
-                        sw2[k] += w;
+                for (int p = 0; p < NP; ++p) {
+                    const int lir = ir - 2 * p;
+                    if (lir < 0 || lir > 5)
+                        continue;
+                    if (lir == 0 || lir == 5) { // taps of one row only (dy = -2 of the pair's first row, dy = +2 of its second)
+                        const int k = lir == 0 ? 0 : 1;
+#pragma unroll
+                        for (int j = 0; j < ng; ++j) {
+                            const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
+                            const float4 tA = gA[g & 1][j];
+                            const float4 tB = gB[g & 1][j];
+                            const float w = tap_weight_neg(h0x[p][k], h0y[p][k], h0z[p][k], nz0[p][k], nl0[p][k], cl2[p][k], tA, tB, pcz.x, pcz.y, lkq[adx][1].y);
+                            sr2[p][k] = fmaf(w, tA.x, sr2[p][k]);
+                            sg2[p][k] = fmaf(w, tA.y, sg2[p][k]);
+                            sb2[p][k] = fmaf(w, tA.z, sb2[p][k]);
+                            sw2[p][k] += w;
+                        }
+                    } else if constexpr (kLkScalar) {
+                        // the fused kernel: one texel at a time (its staging phase leaves no registers for a whole group's intermediate values)
+#pragma unroll
+                        for (int j = 0; j < ng; ++j) {
+                            const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
+                            const float4 tA = gA[g & 1][j];
+                            const Tap2 t = tap2_geometry(h0x[p], h0y[p], h0z[p], nz0[p], nl0[p], tA, gB[g & 1][j]);
+                            const neb_f2 w = (lir == 1)   ? tap2_weight<false, true>(t, cl2[p], pcz, lkq[adx][1])
+                                             : (lir == 2) ? tap2_weight<false, true>(t, cl2[p], pcz, lkq[adx][0])
+                                             : (lir == 3) ? tap2_weight<true, true>(t, cl2[p], pcz, lkq[adx][0])
+                                                          : tap2_weight<true, true>(t, cl2[p], pcz, lkq[adx][1]);
+                            const neb_f2 axy = {tA.x, tA.y}, azw = {tA.z, tA.w};
+                            sr2[p] = pk_fma(w, __builtin_shufflevector(axy, axy, 0, 0), sr2[p]);
+                            sg2[p] = pk_fma(w, __builtin_shufflevector(axy, axy, 1, 1), sg2[p]);
+                            sb2[p] = pk_fma(w, __builtin_shufflevector(azw, azw, 0, 0), sb2[p]);
+                            sw2[p] += w;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+                        Tap2 t[kMaxGroup];
+                        neb_f2 w[kMaxGroup];
+#pragma unroll
+                        for (int j = 0; j < ng; ++j)
+                            t[j] = tap2_geometry(h0x[p], h0y[p], h0z[p], nz0[p], nl0[p], gA[g & 1][j], gB[g & 1][j]);
+                        if constexpr (kPhased)
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < ng; ++j) {
+                            const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
+                            // (|dy0|, |dy1|) = (1, 2), (0, 1), (1, 0), (2, 1) for lir = 1 .. 4: the constant pairs {0, 1} and {1, 2}, straight or swapped
+                            w[j] = (lir == 1)   ? tap2_weight<false, kLkScalar>(t[j], cl2[p], pcz, lkq[adx][1])
+                                   : (lir == 2) ? tap2_weight<false, kLkScalar>(t[j], cl2[p], pcz, lkq[adx][0])
+                                   : (lir == 3) ? tap2_weight<true, kLkScalar>(t[j], cl2[p], pcz, lkq[adx][0])
+                                                : tap2_weight<true, kLkScalar>(t[j], cl2[p], pcz, lkq[adx][1]);
+                        }
+                        if constexpr (kPhased)
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < ng; ++j) {
+                            const float4 tA = gA[g & 1][j];
+                            const neb_f2 axy = {tA.x, tA.y}, azw = {tA.z, tA.w};
+                            sr2[p] = pk_fma(w[j], __builtin_shufflevector(axy, axy, 0, 0), sr2[p]);
+                            sg2[p] = pk_fma(w[j], __builtin_shufflevector(axy, axy, 1, 1), sg2[p]);
+                            sb2[p] = pk_fma(w[j], __builtin_shufflevector(azw, azw, 0, 0), sb2[p]);
+                            sw2[p] += w[j];
+                        }
                     }
-                } else if constexpr (kLkScalar) {
-                    // the fused kernel: one texel at a time (its staging phase leaves no registers for a whole group's intermediate values)
-#pragma unroll
-                    for (int j = 0; j < ng; ++j) {
-                        const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
-                        const float4 tA = gA[g & 1][j];
-                        const Tap2 t = tap2_geometry(h0x, h0y, h0z, nz0, nl0, tA, gB[g & 1][j]);
-                        const neb_f2 w = (ir == 1)   ? tap2_weight<false, true>(t, cl2, pcz, lkq[adx][1])
-                                         : (ir == 2) ? tap2_weight<false, true>(t, cl2, pcz, lkq[adx][0])
-                                         : (ir == 3) ? tap2_weight<true, true>(t, cl2, pcz, lkq[adx][0])
-                                                     : tap2_weight<true, true>(t, cl2, pcz, lkq[adx][1]);
-                        const neb_f2 axy = {tA.x, tA.y}, azw = {tA.z, tA.w};
-                        sr2 = pk_fma(w, __builtin_shufflevector(axy, axy, 0, 0), sr2);
-                        sg2 = pk_fma(w, __builtin_shufflevector(axy, axy, 1, 1), sg2);
-                        sb2 = pk_fma(w, __builtin_shufflevector(azw, azw, 0, 0), sb2);
-                        sw2 += w;
+                    asm volatile("" : "+v"(sr2[p]), "+v"(sg2[p]), "+v"(sb2[p]), "+v"(sw2[p])); // (pinned for the reason given below)
+                    if constexpr (NP > 1)
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-                    Tap2 t[kMaxGroup];
-                    neb_f2 w[kMaxGroup];
-#pragma unroll
-                    for (int j = 0; j < ng; ++j)
-                        t[j] = tap2_geometry(h0x, h0y, h0z, nz0, nl0, gA[g & 1][j], gB[g & 1][j]);
-                    if constexpr (kPhased)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < ng; ++j) {
-                        const int dx = (g & 1) ? j + 1 : j - 2, adx = dx < 0 ? -dx : dx;
-                        // (|dy0|, |dy1|) = (1, 2), (0, 1), (1, 0), (2, 1) for ir = 1 .. 4: the constant pairs {0, 1} and {1, 2}, straight or swapped
-                        w[j] = (ir == 1)   ? tap2_weight<false, kLkScalar>(t[j], cl2, pcz, lkq[adx][1])
-                               : (ir == 2) ? tap2_weight<false, kLkScalar>(t[j], cl2, pcz, lkq[adx][0])
-                               : (ir == 3) ? tap2_weight<true, kLkScalar>(t[j], cl2, pcz, lkq[adx][0])
-                                           : tap2_weight<true, kLkScalar>(t[j], cl2, pcz, lkq[adx][1]);
-                    }
-                    if constexpr (kPhased)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < ng; ++j) {
-                        const float4 tA = gA[g & 1][j];
-                        const neb_f2 axy = {tA.x, tA.y}, azw = {tA.z, tA.w};
-                        sr2 = pk_fma(w[j], __builtin_shufflevector(axy, axy, 0, 0), sr2);
-                        sg2 = pk_fma(w[j], __builtin_shufflevector(axy, axy, 1, 1), sg2);
-                        sb2 = pk_fma(w[j], __builtin_shufflevector(azw, azw, 0, 0), sb2);
-                        sw2 += w[j];
-                    }
                 }
-                asm volatile("" : "+v"(sr2), "+v"(sg2), "+v"(sb2), "+v"(sw2)); // (pinned for the reason given below)
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                sr[k] = sr2[k];
-                sg[k] = sg2[k];
-                sb[k] = sb2[k];
-                sw[k] = sw2[k];
+                sr[k] = sr2[k >> 1][k & 1];
+                sg[k] = sg2[k >> 1][k & 1];
+                sb[k] = sb2[k >> 1][k & 1];
+                sw[k] = sw2[k >> 1][k & 1];
             }
         } else {
             load_group(0);
