@@ -171,6 +171,25 @@ namespace Neb
         {
             ThrowIfFailed(strip.Context(), neb_strips_exchange(strip.Context(), m_comm, planes, nPlanes, swaps, nSwaps, commandList), "neb_strips_exchange");
         }
+        // One call per strip frame (round 5): the GI dispatch on the strip's rows (constants == nullptr: none), the temporal pass, the halo
+        // exchange(s) of the plan's scheme over this communicator and the a-trous levels on the row ranges the scheme prescribes.
+        void SubmitStripFrame(SVGFDenoiser& strip, const neb_gi_constants* constants, const neb_strip_plan& plan, neb_stream commandList)
+        {
+            ThrowIfFailed(strip.Context(), neb_strip_frame(strip.Context(), constants, m_comm, &plan, commandList), "neb_strip_frame");
+        }
+        // The same for a host that drives all strips from ONE thread and needs no communicator (the neighbouring strips' contexts instead):
+        // Begin for every strip, then Finish for every strip.
+        static void SubmitStripFrameBegin(SVGFDenoiser& strip, const neb_gi_constants* constants, const neb_strip_plan& plan, SVGFDenoiser* up, SVGFDenoiser* down,
+                                          neb_stream commandList)
+        {
+            const neb_strip_peers peers{up ? up->Context() : nullptr, down ? down->Context() : nullptr};
+            ThrowIfFailed(strip.Context(), neb_strip_frame_begin(strip.Context(), constants, &plan, &peers, commandList), "neb_strip_frame_begin");
+        }
+        static void SubmitStripFrameFinish(SVGFDenoiser& strip, const neb_strip_plan& plan, SVGFDenoiser* up, SVGFDenoiser* down, neb_stream commandList)
+        {
+            const neb_strip_peers peers{up ? up->Context() : nullptr, down ? down->Context() : nullptr};
+            ThrowIfFailed(strip.Context(), neb_strip_frame_finish(strip.Context(), nullptr, &plan, &peers, commandList), "neb_strip_frame_finish");
+        }
 
     private:
         static void Check(int status, const char* what)

@@ -190,6 +190,8 @@ struct GiState {
     float sun_table_pending[4] = {0, 0, 0, 0}; // a new sun seen once: the table follows when it is seen again
     float sun_table_key[4] = {0, 0, 0, 0}; // {sunLightDirection, sunTanHalfAngle} the flags were built for
     unsigned long long* d_sun_counts = nullptr; // sides proven lit {+, -} by the last build
+    uint32_t* d_sun_hint_list = nullptr;        // two-pass build: triangles whose primary side the first pass left unproven
+    uint32_t sun_hint_list_cap = 0;
     uint32_t sun_table_builds = 0;
     // The flags are rewritten IN PLACE in the shading records, on the stream of the dispatch that noticed the new sun, while the host
     // state says "table valid" from the moment of the enqueue: a dispatch on ANOTHER stream ("gi_defer_resolve" = 2, or a host that

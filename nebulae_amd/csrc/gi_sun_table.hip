@@ -23,6 +23,8 @@
 // as exact as its cells, and says nothing about the occluded rays; the per-triangle form uses the exact geometry.
 // (What the lit bits alone are worth: 8 us -- the unoccluded rays of an open court leave the tree after 3 node visits on average;
 // the hints and the compaction of what is left, gi.hip, are the other 77.)
+#include <cstdlib>
+
 #include "gi_device.h"
 #include "lit_predicate.h"
 
@@ -34,7 +36,11 @@ struct SunTableArgs {
     double scene_hmax; // highest point of the scene along L
     double box_pad;    // padding of the node boxes (floats) in the double-precision cull: an ulp of the scene's largest coordinate, at least 1e-5
     float4* shade;     // the shading records (writable view of S.shade)
-    unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint
+    unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint, [3] triangles listed for the hint pass, [4] ... for pass 3
+    uint32_t* hint_list;        // two-pass build: the triangles whose primary side is not proven lit (pass 1 appends, pass 2 reads)
+    uint32_t* retry_list;       // pass 1: the triangles whose budget of node visits ran out with a side still unproven (pass 3 walks them to the end)
+    uint32_t lit_budget;        // pass 1: node visits per triangle, 0 = unlimited (then no pass 3)
+    uint32_t hint_budget;       // pass 2: candidate triangles (those that shadow at least one sample origin) looked at per receiver, 0 = all
 };
 
 __device__ inline void node_child_box(const Bvh4Node& nd, int q, double lo[3], double hi[3])
@@ -47,15 +53,36 @@ __device__ inline void node_child_box(const Bvh4Node& nd, int q, double lo[3], d
     hi[0] = h0[q], hi[1] = h1[q], hi[2] = h2[q];
 }
 
+// PASS 0: lit bits and hints in one walk of the whole column (rounds 4: 15.5 ms at 262 k triangles; kept as the A/B arm, NEB_SUN_TABLE_PASSES=1).
+// PASS 1 + PASS 2 (round 5, the default): the lit bits first -- a walk that ENDS as soon as every valid side has met something it cannot rule out
+// (most unlit triangles do within a few leaves) -- and the triangles whose primary side is left unproven appended to a list; then the hint walk
+// for those only, in dense waves, over the primary side's own column, ending once the four best candidates cover all 28 sample origins.
+// Same certificate, same lit bits; the hints may differ from the one-pass choice (they are only ever hints: tried with the traverser's own test).
+constexpr uint32_t kSunLitBudget = 0u; // (see SunTableArgs::lit_budget; NEB_SUN_LIT_BUDGET overrides)
+constexpr uint32_t kSunHintBudget = 0u; // (see SunTableArgs::hint_budget; NEB_SUN_HINT_BUDGET overrides)
+template <int PASS>
 __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
 {
-    const uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
+    bool mine = ti < a.S.n_tris;
+    if constexpr (PASS == 2) {
+        mine = ti < (uint32_t)a.counts[3];
+        if (mine)
+            ti = a.hint_list[ti];
+    }
+    if constexpr (PASS == 3) { // the lit pass of the triangles pass 1 ran out of budget on: the same walk to its end, in dense waves
+        mine = ti < (uint32_t)a.counts[4];
+        if (mine)
+            ti = a.retry_list[ti];
+    }
+    constexpr bool kLit = PASS == 0 || PASS == 1 || PASS == 3, kHint = PASS == 0 || PASS == 2;
+    bool undecided = false;
     uint32_t flags = 0;
     uint32_t hint[kHints];
     for (int h = 0; h < kHints; ++h)
         hint[h] = kNoHint;
-    bool hinted = false;
-    if (ti < a.S.n_tris) {
+    bool hinted = false, listed = false;
+    if (mine) {
         const float4 t0 = a.S.tris[3 * ti], t1 = a.S.tris[3 * ti + 1], t2 = a.S.tris[3 * ti + 2];
         // the triangle the traverser tests: (v0, v0 + e1, v0 + e2) with e1, e2 as stored
         const double v[3][3] = {{t0.x, t0.y, t0.z},
@@ -101,6 +128,8 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
             double qa[2] = {1e300, -1e300}, qb[2] = {1e300, -1e300}, qh = 1e300;
             for (int s = 0; s < 2; ++s)
                 if (R[s].valid) {
+                    if (PASS == 2 && s != primary)
+                        continue; // (the hint pass: the primary side's own column)
                     const double reach = (a.scene_hmax - R[s].h_min + a.F.margin) * a.F.tau + a.F.margin;
                     qa[0] = fmin(qa[0], R[s].bb_a[0] - reach), qa[1] = fmax(qa[1], R[s].bb_a[1] + reach);
                     qb[0] = fmin(qb[0], R[s].bb_b[0] - reach), qb[1] = fmax(qb[1], R[s].bb_b[1] + reach);
@@ -109,6 +138,7 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
             int stack[64];
             int sp = 0;
             int node = a.S.root;
+            uint32_t cands_seen = 0;
             auto test_leaf = [&](int code) {
                 const uint32_t c = (uint32_t)~code, first = c >> 2, count = (c & 3u) + 1u;
                 for (uint32_t k = 0; k < count; ++k) {
@@ -120,12 +150,14 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                     lit::Tri O;
                     for (int i = 0; i < 3; ++i)
                         lit::to_sun(a.F, w[i], O.a[i], O.b[i], O.h[i]);
-                    for (int s = 0; s < 2; ++s)
-                        if (alive[s] && lit::may_occlude(a.F, R[s], O))
-                            alive[s] = false;
-                    if (R[primary].valid && tj != ti) {
+                    if (kLit)
+                        for (int s = 0; s < 2; ++s)
+                            if (alive[s] && lit::may_occlude(a.F, R[s], O))
+                                alive[s] = false;
+                    if (kHint && R[primary].valid && tj != ti) {
                         const uint32_t m = lit::cover_mask(R[primary], O);
                         const int pc = __popc(m);
+                        cands_seen += pc ? 1u : 0u;
                         if (pc > cand_pop[kCand - 1]) { // insertion into the sorted candidate list
                             int at = kCand - 1;
                             while (at > 0 && cand_pop[at - 1] < pc) {
@@ -141,7 +173,21 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                 test_leaf(node);
                 node = kTravDone;
             }
-            while (node != kTravDone) { // (the whole column: a side that is already known to be shadowed still wants its hints)
+            constexpr uint32_t kAllSamples = (1u << lit::kCoverSamples) - 1u;
+            uint32_t visits = 0;
+            auto walk_done = [&]() {
+                if (PASS == 1 && a.lit_budget && visits >= a.lit_budget && (alive[0] || alive[1])) {
+                    undecided = true; // out of budget with something still unproven: pass 3 walks this triangle to the end
+                    return true;
+                }
+                if (PASS == 1 || PASS == 3)
+                    return !alive[0] && !alive[1]; // nothing left to prove
+                if (PASS == 2) // the four best cover every sample origin -- or the receiver has seen its budget of shadowing triangles
+                    return ((cand_mask[0] | cand_mask[1] | cand_mask[2] | cand_mask[3]) & kAllSamples) == kAllSamples || (a.hint_budget && cands_seen >= a.hint_budget);
+                return false; // (one pass: the whole column -- a side that is already known to be shadowed still wants its hints)
+            };
+            while (node != kTravDone && !walk_done()) {
+                ++visits;
                 const Bvh4Node nd = a.S.nodes[node];
                 const int ch[4] = {nd.child.x, nd.child.y, nd.child.z, nd.child.w};
                 node = kTravDone;
@@ -179,12 +225,15 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                     node = stack[--sp];
             }
         }
-        flags = (alive[0] ? 1u : 0u) | (alive[1] ? 2u : 0u);
-        float4 w6 = r6;
-        w6.w = __uint_as_float(geom | (flags << kLitShift));
-        a.shade[8 * (size_t)ti + 6] = w6;
+        flags = undecided ? 0u : (alive[0] ? 1u : 0u) | (alive[1] ? 2u : 0u);
+        if constexpr (PASS != 2) {
+            float4 w6 = r6;
+            w6.w = __uint_as_float(geom | (flags << kLitShift));
+            a.shade[8 * (size_t)ti + 6] = w6;
+        }
+        listed = (PASS == 1 || PASS == 3) && !undecided && R[primary].valid && !alive[primary];
         // greedy cover: up to kHints candidates, each the one that adds most samples not yet covered
-        if (!alive[primary]) { // (a lit side needs no hints: every ray of it is answered by the lit bit)
+        if (kHint && (PASS == 2 || !alive[primary])) { // (a lit side needs no hints: every ray of it is answered by the lit bit)
             uint32_t covered = 0u;
             for (int h = 0; h < kHints; ++h) {
                 int best = -1, gain = 0;
@@ -206,7 +255,9 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
         a.shade[8 * (size_t)ti + 7] = w7;
         hinted = hint[0] != kNoHint;
     }
-    const unsigned long long m0 = __ballot((flags & 1u) != 0u), m1 = __ballot((flags & 2u) != 0u), m2 = __ballot(hinted);
+    const unsigned long long m0 = __ballot(kLit && (flags & 1u) != 0u), m1 = __ballot(kLit && (flags & 2u) != 0u), m2 = __ballot(hinted);
+    const unsigned long long m3 = __ballot(listed), m4 = __ballot(undecided);
+    unsigned long long base = 0, base4 = 0;
     if ((threadIdx.x & 63u) == 0) {
         if (m0)
             atomicAdd(a.counts + 0, (unsigned long long)__popcll(m0));
@@ -214,6 +265,20 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
             atomicAdd(a.counts + 1, (unsigned long long)__popcll(m1));
         if (m2)
             atomicAdd(a.counts + 2, (unsigned long long)__popcll(m2));
+        if (m3)
+            base = atomicAdd(a.counts + 3, (unsigned long long)__popcll(m3));
+        if (m4)
+            base4 = atomicAdd(a.counts + 4, (unsigned long long)__popcll(m4));
+    }
+    if (PASS == 1 && m4) {
+        base4 = (unsigned long long)__shfl((int)(uint32_t)base4, 0);
+        if (undecided)
+            a.retry_list[(uint32_t)base4 + (uint32_t)__popcll(m4 & ((1ull << (threadIdx.x & 63u)) - 1ull))] = ti;
+    }
+    if ((PASS == 1 || PASS == 3) && m3) { // one atomic per wave: the wave's listed triangles go to consecutive slots
+        base = (unsigned long long)__shfl((int)(uint32_t)base, 0);
+        if (listed)
+            a.hint_list[(uint32_t)base + (uint32_t)__popcll(m3 & ((1ull << (threadIdx.x & 63u)) - 1ull))] = ti;
     }
 }
 
@@ -310,7 +375,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     }
     if (!g->d_sun_counts) {
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, 4 * sizeof(unsigned long long));
+        hipError_t e = hipMalloc(&p, 8 * sizeof(unsigned long long));
         if (e != hipSuccess)
             return e;
         g->allocs.push_back(p);
@@ -319,7 +384,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     hipError_t e = quiesce();
     if (e != hipSuccess)
         return e;
-    e = hipMemsetAsync(g->d_sun_counts, 0, 4 * sizeof(unsigned long long), stream);
+    e = hipMemsetAsync(g->d_sun_counts, 0, 8 * sizeof(unsigned long long), stream);
     if (e != hipSuccess)
         return e;
     SunTableArgs a;
@@ -335,7 +400,31 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     a.scene_hmax = hmax + fmax(1e-3, a.F.margin);
     a.shade = const_cast<float4*>(g->view.shade);
     a.counts = g->d_sun_counts;
-    hipLaunchKernelGGL(sun_table_kernel, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
+    static const bool one_pass = getenv("NEB_SUN_TABLE_PASSES") && atoi(getenv("NEB_SUN_TABLE_PASSES")) == 1; // (A/B arm: round 4's single walk)
+    if (one_pass) {
+        a.hint_list = a.retry_list = nullptr;
+        a.hint_budget = a.lit_budget = 0;
+        hipLaunchKernelGGL(sun_table_kernel<0>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
+    } else {
+        if (g->sun_hint_list_cap < g->view.n_tris) { // (a scene rebuild may have changed the reference count)
+            void* p = nullptr;
+            if (hipError_t em = hipMalloc(&p, 2 * (size_t)g->view.n_tris * sizeof(uint32_t)); em != hipSuccess)
+                return em;
+            g->allocs.push_back(p);
+            g->d_sun_hint_list = (uint32_t*)p;
+            g->sun_hint_list_cap = g->view.n_tris;
+        }
+        a.hint_list = g->d_sun_hint_list;
+        a.retry_list = g->d_sun_hint_list + g->view.n_tris; // (the second half of the same allocation)
+        static const uint32_t lit_budget = getenv("NEB_SUN_LIT_BUDGET") ? (uint32_t)atoi(getenv("NEB_SUN_LIT_BUDGET")) : kSunLitBudget;
+        a.lit_budget = lit_budget;
+        static const uint32_t budget = getenv("NEB_SUN_HINT_BUDGET") ? (uint32_t)atoi(getenv("NEB_SUN_HINT_BUDGET")) : kSunHintBudget;
+        a.hint_budget = budget;
+        hipLaunchKernelGGL(sun_table_kernel<1>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
+        if (a.lit_budget)
+            hipLaunchKernelGGL(sun_table_kernel<3>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(sun_table_kernel<2>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a); // (waves past the list's end leave at once)
+    }
     if (hipError_t em = mark_rewrite(g, stream); em != hipSuccess)
         return em;
     memcpy(g->sun_table_key, key, sizeof(key));
