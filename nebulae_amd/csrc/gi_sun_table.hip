@@ -58,6 +58,9 @@ __device__ inline void node_child_box(const Bvh4Node& nd, int q, double lo[3], d
 // (most unlit triangles do within a few leaves) -- and the triangles whose primary side is left unproven appended to a list; then the hint walk
 // for those only, in dense waves, over the primary side's own column, ending once the four best candidates cover all 28 sample origins.
 // Same certificate, same lit bits; the hints may differ from the one-pass choice (they are only ever hints: tried with the traverser's own test).
+#ifndef NEB_SUN_EDGE_CULL
+#define NEB_SUN_EDGE_CULL 1
+#endif
 constexpr uint32_t kSunLitBudget = 0u; // (see SunTableArgs::lit_budget; NEB_SUN_LIT_BUDGET overrides)
 constexpr uint32_t kSunHintBudget = 0u; // (see SunTableArgs::hint_budget; NEB_SUN_HINT_BUDGET overrides)
 template <int PASS>
@@ -211,6 +214,30 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                     const double eh = e[0] * fabs(a.F.L[0]) + e[1] * fabs(a.F.L[1]) + e[2] * fabs(a.F.L[2]);
                     if (chh + eh < qh) // wholly below the lowest ray origin
                         continue;
+                    // (round 5) ... and against the receiver's FOOTPRINT, not only its box: a node wholly beyond one edge of the projected triangle --
+                    // pushed out by the offset box and by the drift a ray can have when it has climbed to the node's top, exactly the half-planes
+                    // lit::may_occlude clips every triangle with -- holds nothing that can matter to that side (may_occlude would clip each of its
+                    // triangles to nothing; cover_mask finds no sample under them).  For a large receiver the box is twice the triangle.
+                    if constexpr (NEB_SUN_EDGE_CULL) {
+                        bool keep = false;
+#pragma unroll
+                        for (int sd = 0; sd < 2; ++sd) {
+                            if (!R[sd].valid || (PASS == 2 && sd != primary) || (kLit && !kHint && !alive[sd]))
+                                continue;
+                            const double rho = ((chh + eh) - R[sd].h_min + a.F.margin) * a.F.tau + a.F.margin;
+                            bool outside = false;
+#pragma unroll
+                            for (int ed = 0; ed < 3; ++ed) {
+                                const double na = R[sd].en_a[ed], nb = R[sd].en_b[ed];
+                                const double lim = R[sd].en_c[ed] + R[sd].en_off[ed] + rho * (fabs(na) + fabs(nb));
+                                // least value of na * a + nb * b over the node's box (the box's sun-space extents ea, eb bound every corner)
+                                outside = outside || (na * ca + nb * cb - (fabs(na) * ea + fabs(nb) * eb) > lim);
+                            }
+                            keep = keep || !outside;
+                        }
+                        if (!keep)
+                            continue;
+                    }
                     if (ch[q] < 0) {
                         test_leaf(ch[q]);
                     } else if (node == kTravDone) {
