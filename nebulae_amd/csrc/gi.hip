@@ -150,47 +150,23 @@ __device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine
                           // kernel takes 380 us either way (377 us exact) although ray generation is ~15 % of its instructions, and
                           // six parity tests leave their 2e-5 band (a direction that moves by an ulp lands on another texel footprint)
 #endif
-// Workgroups of kRgWaves waves, one 8x8 pixel tile per wave (tile = workgroup * kRgWaves + wave): the waves of a workgroup share one copy of
-// the top of the tree in LDS (TreeletT: kRgTreelet nodes), staged when the workgroup starts; their stacks keep kRgStack entries in LDS.
-// LDS per CU at 8 waves per SIMD: 32 x kRgStack x 256 B of stacks + (32 / kRgWaves) x kRgTreelet x 64 B of treelets <= 160 KB.
-#ifndef NEB_RG_WAVES
-#define NEB_RG_WAVES 1
-#endif
+// One wave per 8x8 pixel tile.  LDS per wave: the closest-hit walk's stack (kRgStack entries per lane: no bounce ray of the bench frame ever holds
+// more than 12, tools/gi_wave_stamps.py; deeper entries go to the private array) + the child slots of traverse_core (16 bytes per lane) = 4 KB,
+// eight waves per SIMD.
 #ifndef NEB_RG_STACK
-#define NEB_RG_STACK 12 // (no bounce ray of the bench frame ever holds more than 12 entries: tools/gi_wave_stamps.py; deeper ones go to the private array)
+#define NEB_RG_STACK 12
 #endif
-#ifndef NEB_RG_TREELET
-#define NEB_RG_TREELET 0
-#endif
-#ifndef NEB_RG_LANE_FREE
-#define NEB_RG_LANE_FREE 0
-#endif
-constexpr int kRgWaves = NEB_RG_WAVES, kRgStack = NEB_RG_STACK, kRgTreelet = NEB_RG_TREELET;
-constexpr bool kRgLaneFree = NEB_RG_LANE_FREE != 0;
-#ifndef NEB_RG_MODE
-#define NEB_RG_MODE 3 // bit 0: address-as-stack-pointer (TravStackA), bit 1: child codes selected through LDS slots, bit 2: ... all four read up front, bit 3: ... and the three pushes without branches (with bit 0)
-#endif
-constexpr int kRgMode = NEB_RG_MODE;
-static_assert(32 * ((kRgStack + ((kRgMode & 8) ? 1 : 0)) * 256 + ((kRgMode & 46) ? 1024 : 0)) + (32 / kRgWaves) * kRgTreelet * 64 <= 160 * 1024 || NEB_TRACE_WAVES < 8,
-              "LDS budget of the closest-hit pass: 32 waves per CU of stacks and child slots (+ treelets) in 160 KB");
+constexpr int kRgStack = NEB_RG_STACK;
+static_assert(32 * (kRgStack * 256 + 1024) <= 160 * 1024 || NEB_TRACE_WAVES < 8, "LDS budget of the closest-hit pass: 32 waves per CU of stacks and child slots in 160 KB");
 template <bool FAST, bool FAST_TRIG>
-__global__ __launch_bounds__(64 * kRgWaves, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
+__global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
 {
-    __shared__ int stack_all[kRgWaves][(kRgStack + ((kRgMode & 8) ? 1 : 0)) * 64]; // (+ the spare row of TravStackA::push3)
-    __shared__ f32x4 treelet_mem[kRgTreelet > 0 ? 4 * kRgTreelet : 1];
-    __shared__ int child_slot_mem[(kRgMode & 46) ? kRgWaves * 256 : 4];
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u; // (wave: a scalar, and so is all tile arithmetic)
-    int* stack_mem = stack_all[wave];
-    [[maybe_unused]] TreeletT<(kRgTreelet > 0 ? kRgTreelet : 1)> tl{};
-    if constexpr (kRgTreelet > 0) {
-        tl = stage_treelet<(kRgTreelet > 0 ? kRgTreelet : 1)>(a.S, treelet_mem, threadIdx.x, 64u * kRgWaves);
-        __syncthreads();
-    }
-    const uint32_t tile = gi_block<kRaygenRuns>() * kRgWaves + wave;
-    const uint32_t tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    const uint32_t x = tile_x * 8 + (lane & 7), y = a.row0 + tile_y * 8 + (lane >> 3);
-    const uint32_t i = (y - a.row_begin) * a.W + x; // (32 bits: one register across the walk)
-    const bool active = x < a.W && y < a.row1; // (a tile past the last one has y >= row1)
+    __shared__ int stack_mem[kRgStack * 64];
+    __shared__ int child_slot_mem[256];
+    uint32_t x, y;
+    size_t i64;
+    const bool active = gi_pixel<kRaygenRuns>(a, x, y, i64);
+    const uint32_t i = (uint32_t)i64, lane = threadIdx.x; // (32 bits: one register across the walk)
     uint32_t rays = 0;
     uint32_t wave_stamp[5] = {0u, 0u, 0u, 0u, 0u}; // diagnostics (a.stats): the closest-hit loop's wave stamps, see Hit
     if (active) {
@@ -234,18 +210,8 @@ __global__ __launch_bounds__(64 * kRgWaves, NEB_TRACE_WAVES) void gi_raygen_trac
         }
         if (bounce && !a.raygen_only && a.S.n_tris) {
             Hit hit;
-            bool found;
-            [[maybe_unused]] int* slots = (kRgMode & 46) ? child_slot_mem + wave * 256u + 4u * lane : nullptr;
-            if constexpr (kRgMode != 0) {
-                static_assert(kRgMode == 0 || (kRgTreelet == 0 && !kRgLaneFree), "the round-5 stack / select forms are built without the treelet arms");
-                found = a.stats ? traverse_t<false, true, kRgStack, NoTreelet, false, kRgMode>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, NoTreelet{}, stack_mem, slots)
-                                : traverse_t<false, false, kRgStack, NoTreelet, false, kRgMode>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, NoTreelet{}, stack_mem, slots);
-            } else if constexpr (kRgTreelet > 0)
-                found = a.stats ? traverse_t<false, true, kRgStack, decltype(tl), kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit, tl)
-                                : traverse_t<false, false, kRgStack, decltype(tl), kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit, tl);
-            else
-                found = a.stats ? traverse_t<false, true, kRgStack, NoTreelet, kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit)
-                                : traverse_t<false, false, kRgStack, NoTreelet, kRgLaneFree>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + (kRgLaneFree ? 0u : lane), hit);
+            const bool found = a.stats ? traverse_t<false, true, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane)
+                                       : traverse_t<false, false, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane);
             if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only
@@ -262,9 +228,7 @@ __global__ __launch_bounds__(64 * kRgWaves, NEB_TRACE_WAVES) void gi_raygen_trac
         }
         a.R.hit[i] = h;
     }
-    if (tile >= a.tiles_x * ((a.row1 - a.row0 + 7u) / 8u))
-        return; // (a wave past the last tile: nothing to count)
-    count_rays(a.bounce_counts, rays, tile);
+    count_rays(a.bounce_counts, rays);
     if (a.stats) { // the stamps are wave-uniform among the lanes that walked longest: the wave's totals are the maxima over its lanes
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -1130,8 +1094,7 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
         for (uint32_t b = 1; b <= n_vertices; ++b) { // for (bounce = 1; bounce < nrcMaxPathVertices; ++bounce), :495
             a.bounce = b;
             if (b == 1 && phase != 2) {
-                hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), dim3((grid.x + kRgWaves - 1) / kRgWaves),
-                                   dim3(64 * kRgWaves), 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL((gi_raygen_trace_kernel<(NEB_FAST_RAYGEN >= 1), (NEB_FAST_RAYGEN >= 2)>), grid, block, 0, (hipStream_t)stream, a);
             }
             if (phase == 1)
                 continue;

@@ -8,7 +8,6 @@
 #pragma clang fp contract(off)
 
 #include "gi_internal.h"
-#include <type_traits>
 
 namespace neb {
 
@@ -235,27 +234,6 @@ template <bool FAST = false> __device__ float3 evaluate_direct_brdf(const Surfac
 #ifndef NEB_LDS_STACK
 #define NEB_LDS_STACK 16
 #endif
-#ifndef NEB_PROBE_VALU
-#define NEB_PROBE_VALU 0
-#endif
-#ifndef NEB_PROBE_SALU
-#define NEB_PROBE_SALU 0
-#endif
-#ifndef NEB_PROBE_NOP
-#define NEB_PROBE_NOP 0
-#endif
-#ifndef NEB_PROBE_LDS
-#define NEB_PROBE_LDS 0
-#endif
-#ifndef NEB_PROBE_LOAD
-#define NEB_PROBE_LOAD 0
-#endif
-#ifndef NEB_PROBE_ONE_TRI
-#define NEB_PROBE_ONE_TRI 0
-#endif
-#ifndef NEB_TRAV_PIPE
-#define NEB_TRAV_PIPE 0 // 1: every walk in the pop-ahead form (traverse_core<.., PIPE>: one memory wait per iteration)
-#endif
 constexpr int kLdsStack = NEB_LDS_STACK; // per-lane entries kept in LDS (4 KB per wave at 16)
 constexpr int kSpillStack = 64 - kLdsStack; // deeper entries go to a private (scratch) array; rarely touched (TravStackT)
 static_assert((kLdsStack + kSpillStack) / 3 == 21, "GiState::max_bvh_depth assumes a 64-entry traversal stack");
@@ -335,30 +313,18 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b)
 // sat in one struct the dynamically indexed array kept the whole struct (stack pointer included) in scratch memory,
 // and every push / pop paid a scratch round trip behind an s_waitcnt vmcnt(0).
 typedef __attribute__((address_space(3))) int LdsInt; // an LDS word, typed: a pop through a generic pointer became a flat_load (round 5)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) i32x4 LdsI4;
 // N = entries of the ray's stack kept in LDS (lane-contiguous columns of an array [N][64]); the deeper ones, 64 - N, live in a private array
-template <int N, bool LANE_FREE = false>
+template <int N>
 struct TravStackT {
-    static constexpr int kLds = N, kSpill = 64 - N;
-    LdsInt* lds; // this lane's column of an LDS array [N][64]; with LANE_FREE: the array itself (wave-uniform)
+    LdsInt* lds; // this lane's column of an LDS array [N][64]
     int* spill;  // private array of 64 - N entries
     int sp;
-    // LANE_FREE: the lane's column is found again at every push / pop (two v_mbcnt in an asm the compiler cannot hoist) instead of living in a
-    // register across the walk -- the closest-hit kernel sits at its 64-register budget, and the one register it did not have was this one,
-    // reloaded from scratch memory in front of every pop
-    __device__ __forceinline__ LdsInt* column() const
-    {
-        if constexpr (LANE_FREE) {
-            uint32_t lane;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-            return lds + lane;
-        } else {
-            return lds;
-        }
-    }
     __device__ __forceinline__ void push(int v)
     {
         if (sp < N)
-            column()[64 * sp] = v;
+            lds[64 * sp] = v;
         else if (sp < 64)
             spill[sp - N] = v;
         else
@@ -369,23 +335,20 @@ struct TravStackT {
     {
         sp--;
         // the LDS word is read whatever the depth (ds_read_b32, no branch in front of it); the rare deep entry replaces it
-        int v = column()[64 * (sp < N ? sp : 0)];
+        int v = lds[64 * (sp < N ? sp : 0)];
         if (sp >= N)
             v = spill[sp - N];
         return v;
     }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
     __device__ __forceinline__ int depth() const { return sp; }
-    static constexpr bool kHasPush3 = false;
-    __device__ __forceinline__ void push3(int, bool, int, bool, int, bool) {}
 };
-// The same stack with the ADDRESS of its next free LDS entry as its only state (round 5: the closest-hit pass is bound by instruction issue,
-// one VALU instruction per node phase ~ 2 us of a 295-us launch): a push is compare + ds_write + add, a pop add + compare + ds_read -- no
-// index-to-address arithmetic, no clamp.  `array`: the wave's LDS array [N][64] (wave-uniform: a scalar operand of the compares); entry k
-// of lane l at array + 64 k + l.  Entries N .. 63 live in the private array, addressed by the depth the address implies.
+// The same stack with the ADDRESS of its next free LDS entry as its only state (round 5, the closest-hit pass): a push is compare +
+// ds_write + add, a pop add + compare + ds_read -- no index-to-address arithmetic, no clamp.  `array`: the wave's LDS array [N][64]
+// (wave-uniform: a scalar operand of the compares); entry k of lane l at array + 64 k + l.  Entries N .. 63 live in the private array,
+// addressed by the depth the address implies.
 template <int N>
 struct TravStackA {
-    static constexpr int kLds = N, kSpill = 64 - N;
     LdsInt* top;   // next free entry of this lane's column (keeps counting past the LDS part: an address that is never dereferenced)
     LdsInt* array; // wave-uniform
     int* spill;
@@ -412,86 +375,7 @@ struct TravStackA {
             v = spill[depth() - N];
         return v;
     }
-    // Up to three pushes without a branch (the closest-hit node phase: children 3, 2, 1 of the ordered four, each only if hit): a push that
-    // does not happen writes to the lane's word of a spare row of the array (row N) instead, and does not move `top`.  4 VALU instructions
-    // per push and no scalar ones, against 3 + ~10 (compare / saveexec / branch / restore, twice nested) -- the probes price a scalar
-    // instruction per node phase at half a vector one.  Only while all three fit in the LDS part; otherwise the careful pushes.
-    // ... and with branches but ONE capacity check for the three (h3 implies h2 implies h1: the keys are sorted)
-    template <class F3, class F2, class F1>
-    __device__ __forceinline__ void push3_nested(F3 c3, bool h3, F2 c2, bool h2, F1 c1, bool h1)
-    {
-        if (top + 3 * 64 <= array + 64 * N) {
-            if (h1) {
-                if (h2) {
-                    if (h3) {
-                        *top = c3();
-                        top += 64;
-                    }
-                    *top = c2();
-                    top += 64;
-                }
-                *top = c1();
-                top += 64;
-            }
-        } else {
-            if (h3)
-                push(c3());
-            if (h2)
-                push(c2());
-            if (h1)
-                push(c1());
-        }
-    }
-    static constexpr bool kHasPush3 = true;
-    __device__ __forceinline__ void push3(int c3, bool h3, int c2, bool h2, int c1, bool h1)
-    {
-        if (top + 3 * 64 <= array + 64 * N) {
-            LdsInt* const dummy = array + 64 * N + ((uint32_t)(top - array) & 63u);
-            *(h3 ? top : dummy) = c3;
-            top += h3 ? 64 : 0;
-            *(h2 ? top : dummy) = c2;
-            top += h2 ? 64 : 0;
-            *(h1 ? top : dummy) = c1;
-            top += h1 ? 64 : 0;
-        } else {
-            if (h3)
-                push(c3);
-            if (h2)
-                push(c2);
-            if (h1)
-                push(c1);
-        }
-    }
 };
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) i32x4 LdsI4;
-typedef TravStackT<kLdsStack> TravStack;
-
-// A copy of the first `n` nodes of the (breadth-first) quantised node array in LDS, staged once per workgroup: the top of the tree, which
-// every ray walks -- the first 64 nodes take 37 % of a bounce ray's node visits on the bench scene, the first 256 51 % (tools/gi_wave_stamps.py)
-// -- and which then costs the texture-address path nothing.  Piece j (16 bytes) of node k sits at base[j * CAP + k]: plane by plane, so the
-// lanes of one ds_read_b128 spread over all banks (node by node they would meet in a quarter of them).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) f32x4 LdsF4;
-template <int CAP>
-struct TreeletT {
-    static constexpr int kCap = CAP;
-    const LdsF4* base;
-    int n; // nodes present: min(CAP, nodes of the tree)
-};
-struct NoTreelet {
-    static constexpr int kCap = 0;
-};
-// stages the treelet: every thread of the workgroup calls it, then __syncthreads()
-template <int CAP>
-__device__ __forceinline__ TreeletT<CAP> stage_treelet(const SceneView& S, f32x4* mem /* [4 * CAP] in LDS */, uint32_t tid, uint32_t nthreads)
-{
-    const int n = min((int)S.n_qnodes, CAP);
-    const f32x4* src = reinterpret_cast<const f32x4*>(S.qnodes);
-    for (uint32_t idx = tid; idx < 4u * (uint32_t)n; idx += nthreads)
-        mem[(idx & 3u) * CAP + (idx >> 2)] = src[idx];
-    return TreeletT<CAP>{(const LdsF4*)mem, n};
-}
 
 // Closest-hit (ANY_HIT = false) or first-hit (ANY_HIT = true) traversal of the BVH4.
 // A step handles an inner node and then, if the lane lands on a leaf, the leaf in the same iteration
@@ -500,45 +384,21 @@ __device__ __forceinline__ TreeletT<CAP> stage_treelet(const SceneView& S, f32x4
 constexpr int kTravDone = (int)0x80000000;
 
 // The traversal loop proper: starts from (node, st, hit, found) and runs until the ray is done.  Every ray walks the 64-byte
-// quantised nodes (Bvh4NodeQ, gi_internal.h): four 16-byte loads per visit.  (Measured and moved out of the product, round 2:
-// the 128-byte exact-plane walk -- seven loads per visit: closest-hit 377 against 293 us, any-hit 177 against 135 -- and
-// "tail suspension", parking the last lanes of a thinned-out wave for a dense follow-up pass: the closest-hit launch drops
-// from 383 to 338 us, but the parked rays are the longest ones and their follow-up pass costs what was saved)
-// child_slots (LDS_SELECT, closest-hit walks): 16 bytes of LDS per lane.  The node's four child codes are parked there and the (up to) four
-// that the ordered keys name are read back by slot -- `v_and, v_lshl_add, ds_read_b32` per child instead of the seven VALU instructions of a
-// two-level v_cndmask selection (round 5; the pass is bound by VALU issue, and the LDS pipe idles).
-// PIPE ("pop-ahead", round 5): the memory round trips of an iteration overlapped.  The plain loop pays two dependent round trips in the
-// 53 % of its iterations that run a leaf phase: the node fetch at the top, and -- after the node phase -- the leaf's triangles; the lanes
-// that go on with an inner node wait through the second one, and the lanes in the leaf only learn their next node (the pop) after the
-// triangle tests.  But the pop does not depend on the tests: a closest-hit ray pops whatever the tests say (a hit only shrinks hit.t,
-// which the NEXT node phase reads at compute time), and an any-hit ray that hits is finished.  So a lane that lands on a leaf takes its
-// next node off the stack BEFORE the tests, every lane's next node is then known at one point, its four 16-byte pieces are requested
-// there (16 VGPRs carried into the next iteration), and the triangle loads follow in the same batch: ONE wait per iteration instead of
-// two.  Same nodes, same order, same arithmetic on the same operands: the same results bit for bit.
-template <bool ANY_HIT, bool STATS, int LDS_SELECT /* 0: v_cndmask selection, 1: LDS slots read where needed, 2: all four read up front, 3: ... and branch-free pushes */,
-          bool PIPE, class Stack, class TL>
-__device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, float3 d, float tmin, Stack& st, int& node, Hit& hit, bool& found, const TL& tl,
+// quantised nodes (Bvh4NodeQ, gi_internal.h): four 16-byte loads per visit.
+// LDS_SELECT (closest-hit walks): child_slots = 16 bytes of LDS per lane; the node's four child codes are parked there and the (up to) four that
+// the ordered keys name are read back by slot -- `v_and, v_lshl_add, ds_read_b32` per child instead of the seven VALU instructions of a
+// two-level v_cndmask selection (round 5).
+// Measured and moved out of the product (git tag r05-traversal-arms holds them all, docs/NOTEBOOK.md 10.1 their numbers): the 128-byte
+// exact-plane walk and tail suspension (round 2); "pop-ahead" (the next node requested before the leaf's triangle tests: one memory wait
+// per iteration), the top of the tree in LDS, branch-free pushes, the four child codes read up front, multi-wave workgroups (round 5).
+template <bool ANY_HIT, bool STATS, bool LDS_SELECT, class Stack>
+__device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, float3 d, float tmin, Stack& st, int& node, Hit& hit, bool& found,
                                               LdsInt* child_slots = nullptr)
 {
-    static_assert(!PIPE || (TL::kCap == 0 && kMaxLeafTris <= 2), "the pipelined walk: no treelet, leaves of at most two triangles");
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
     constexpr uint32_t kMiss = 0xffffffffu;
-    [[maybe_unused]] float4 np0, np1; // PIPE: the four pieces of `node` (when it is an inner node), requested at the end of the iteration before
-    [[maybe_unused]] uint4 np2;
-    [[maybe_unused]] int4 nch;
-    auto request_node = [&](int n) {
-        const char* nodes = reinterpret_cast<const char*>(S.qnodes);
-        const uint32_t nb = (uint32_t)n << 6;
-        np0 = *reinterpret_cast<const float4*>(nodes + nb);
-        np1 = *reinterpret_cast<const float4*>(nodes + (nb + 16u));
-        np2 = *reinterpret_cast<const uint4*>(nodes + (nb + 32u));
-        nch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
-    };
-    if constexpr (PIPE)
-        if (node >= 0)
-            request_node(node);
     while (node != kTravDone) {
         if (STATS) {
             const uint32_t nn = (uint32_t)__popcll(__ballot(node >= 0));
@@ -554,37 +414,12 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
             uint32_t k0, k1, k2, k3;
             int4 ch;
             {
-                float4 p0, p1; // {origin.xyz, scale.x} {scale.yz, qlo.x, qlo.y}
-                uint4 p2;      // {qlo.z, qhi.xyz}
-                bool in_lds = false;
-                if constexpr (TL::kCap > 0) {
-                    in_lds = node < tl.n;
-                    if (in_lds) { // the top of the tree: four ds_read_b128
-                        const f32x4 q0 = tl.base[node], q1 = tl.base[TL::kCap + node], q2 = tl.base[2 * TL::kCap + node], q3 = tl.base[3 * TL::kCap + node];
-                        p0 = make_float4(q0.x, q0.y, q0.z, q0.w);
-                        p1 = make_float4(q1.x, q1.y, q1.z, q1.w);
-                        p2 = make_uint4(__float_as_uint(q2.x), __float_as_uint(q2.y), __float_as_uint(q2.z), __float_as_uint(q2.w));
-                        ch = make_int4(__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w));
-                    }
-                }
-#if NEB_PROBE_LOAD
-                f32x4 probe_extra[NEB_PROBE_LOAD];
-#endif
-                if constexpr (PIPE) {
-                    p0 = np0, p1 = np1, p2 = np2, ch = nch;
-                } else if (!in_lds) {
-                    const char* nodes = reinterpret_cast<const char*>(S.qnodes);
-                    const uint32_t nb = (uint32_t)node << 6;
-#if NEB_PROBE_LOAD // (sensitivity probe: extra 16-byte loads of the node's own line, issued first, consumed after the box tests)
-#pragma unroll
-                    for (int k = 0; k < NEB_PROBE_LOAD; ++k)
-                        asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(probe_extra[k]) : "v"(nb), "s"(nodes), "n"(16 * (k & 3)));
-#endif
-                    p0 = *reinterpret_cast<const float4*>(nodes + nb);
-                    p1 = *reinterpret_cast<const float4*>(nodes + (nb + 16u));
-                    p2 = *reinterpret_cast<const uint4*>(nodes + (nb + 32u));
-                    ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
-                }
+                const char* nodes = reinterpret_cast<const char*>(S.qnodes);
+                const uint32_t nb = (uint32_t)node << 6;
+                const float4 p0 = *reinterpret_cast<const float4*>(nodes + nb);         // {origin.xyz, scale.x}
+                const float4 p1 = *reinterpret_cast<const float4*>(nodes + (nb + 16u)); // {scale.yz, qlo.x, qlo.y}
+                const uint4 p2 = *reinterpret_cast<const uint4*>(nodes + (nb + 32u));   // {qlo.z, qhi.xyz}
+                ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
                 // plane distance = (origin + q scale - o) / d = q (scale inv) + (origin inv - o inv)
                 const float sx = p0.w * inv.x, sy = p1.x * inv.y, sz = p1.y * inv.z;
                 const float bx = fmaf(p0.x, inv.x, -oinv.x), by = fmaf(p0.y, inv.y, -oinv.y), bz = fmaf(p0.z, inv.z, -oinv.z);
@@ -598,17 +433,12 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
                                       fmaf(un(qfy), sy, by), fmaf(un(qfz), sz, bz), tmin, hit.t, c);
                 };
                 k0 = key(0u), k1 = key(1u), k2 = key(2u), k3 = key(3u);
-#if NEB_PROBE_LOAD
-#pragma unroll
-                for (int k = 0; k < NEB_PROBE_LOAD; ++k)
-                    asm volatile("s_waitcnt vmcnt(0)" ::"v"(probe_extra[k]));
-#endif
             }
-            if constexpr (!ANY_HIT && LDS_SELECT != 0)
+            if constexpr (!ANY_HIT && LDS_SELECT)
                 *reinterpret_cast<LdsI4*>(child_slots) = i32x4{ch.x, ch.y, ch.z, ch.w};
             // select by the slot bits without branches: from the lane's LDS slots, or by two levels of v_cndmask
             auto child_of = [&](uint32_t key) -> int {
-                if constexpr (LDS_SELECT != 0)
+                if constexpr (LDS_SELECT)
                     return child_slots[key & 3u];
                 const bool b0 = (key & 1u) != 0u, b1 = (key & 2u) != 0u;
                 const int lo = b0 ? ch.y : ch.x, hi = b0 ? ch.w : ch.z;
@@ -621,28 +451,7 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
                 cswap(k1, k3);
                 cswap(k1, k2);
                 node = kTravDone;
-                if constexpr (LDS_SELECT == 3) { // ... and the pushes without branches (TravStackA::push3); a miss of k0 is a miss of all (sorted)
-                    const int c0 = child_slots[k0 & 3u], c1 = child_slots[k1 & 3u], c2 = child_slots[k2 & 3u], c3 = child_slots[k3 & 3u];
-                    static_assert(Stack::kHasPush3, "LDS_SELECT 3 needs TravStackA");
-                    st.push3(c3, k3 != kMiss, c2, k2 != kMiss, c1, k1 != kMiss);
-                    node = k0 != kMiss ? c0 : kTravDone;
-                } else if constexpr (LDS_SELECT == 2) { // one LDS round trip for all four instead of one per push
-                    const int c0 = child_slots[k0 & 3u], c1 = child_slots[k1 & 3u], c2 = child_slots[k2 & 3u], c3 = child_slots[k3 & 3u];
-                    if (k0 != kMiss) {
-                        if (k3 != kMiss)
-                            st.push(c3);
-                        if (k2 != kMiss)
-                            st.push(c2);
-                        if (k1 != kMiss)
-                            st.push(c1);
-                        node = c0;
-                    }
-                } else if constexpr (LDS_SELECT == 4) { // on-demand reads, nested pushes behind one capacity check (TravStackA::push3_nested)
-                    if (k0 != kMiss) {
-                        st.push3_nested([&]() { return child_of(k3); }, k3 != kMiss, [&]() { return child_of(k2); }, k2 != kMiss, [&]() { return child_of(k1); }, k1 != kMiss);
-                        node = child_of(k0);
-                    }
-                } else if (k0 != kMiss) {
+                if (k0 != kMiss) {
                     if (k3 != kMiss)
                         st.push(child_of(k3));
                     if (k2 != kMiss)
@@ -673,26 +482,6 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
             }
             if (STATS)
                 hit.deep_sp += st.depth() > 12;
-#if NEB_PROBE_VALU || NEB_PROBE_SALU || NEB_PROBE_NOP || NEB_PROBE_LDS
-            // sensitivity probes (tuning builds only; results unchanged): what ONE more instruction of a class per node phase costs the launch
-            if (!ANY_HIT) {
-#pragma unroll
-                for (int k = 0; k < NEB_PROBE_VALU; ++k)
-                    asm volatile("v_add_u32 %0, %0, 1" : "+v"(hit.node_visits));
-#pragma unroll
-                for (int k = 0; k < NEB_PROBE_SALU; ++k)
-                    asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc");
-#pragma unroll
-                for (int k = 0; k < NEB_PROBE_NOP; ++k)
-                    asm volatile("s_nop 7");
-#pragma unroll
-                for (int k = 0; k < NEB_PROBE_LDS; ++k) {
-                    int w;
-                    asm volatile("ds_read_b32 %0, %1" : "=v"(w) : "v"(0));
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_u32 %0, %0, %1" : "+v"(hit.node_visits) : "v"(w));
-                }
-            }
-#endif
             if (node == kTravDone && !st.empty())
                 node = st.pop();
         }
@@ -708,17 +497,13 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
             hit.w_leaf_iters += nl ? 1u : 0u;
             hit.w_leaf_lanes += nl;
         }
-        const uint32_t code = (uint32_t)~node;
-        if constexpr (PIPE) {
-            if (holds_leaf && run_leaves) // pop-ahead: the lane's next node, before its triangles are even requested
-                node = st.empty() ? kTravDone : st.pop();
-            if (node >= 0) // every lane's next inner node is known here: one request for the whole wave, in flight beside the triangle loads
-                request_node(node);
-        }
         if (holds_leaf && run_leaves) {
+            const uint32_t code = (uint32_t)~node;
             const uint32_t first = code >> 2, count = (code & 3u) + 1u;
             if (STATS)
                 hit.tri_tests += count;
+            // (closest-hit walks do not keep `found` through the loop -- a lane mask in scalar registers, re-merged every iteration: it is
+            // hit.tri != ~0u at the end)
             if constexpr (kMaxLeafTris <= 2) {
                 // both triangles are fetched before the first test (one memory round trip per leaf).  A one-triangle
                 // leaf tests its triangle twice: the second test cannot pass t < hit.t again.
@@ -730,8 +515,6 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
                 // first triangle, a second dependent memory access per leaf
                 asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z));
                 float t, u, v;
-                // (closest-hit walks do not keep `found` through the loop -- a lane mask in scalar registers, re-merged every iteration: it is
-                // hit.tri != ~0u at the end)
                 if (intersect_tri_regs(a0, b0, c0, o, d, tmin, hit.t, t, u, v)) {
                     hit.t = t, hit.u = u, hit.v = v, hit.tri = first;
                     if constexpr (ANY_HIT)
@@ -756,19 +539,19 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
                 node = kTravDone;
                 return;
             }
-            if constexpr (!PIPE)
-                node = st.empty() ? kTravDone : st.pop();
+            node = st.empty() ? kTravDone : st.pop();
         }
     }
     if constexpr (!ANY_HIT)
         found = hit.tri != ~0u;
 }
 
-// lds_stack: this lane's column of the wave's LDS array [N][64] -- or, with LANE_FREE, the array itself (see TravStackT).
-// MODE bit 0: the address-as-stack-pointer form (TravStackA; lds_array = the wave's array); bit 1 / 2 / 3: child_slots forms, bit 4: PIPE; see traverse_core.
-template <bool ANY_HIT, bool STATS, int N = kLdsStack, class TL = NoTreelet, bool LANE_FREE = false, int MODE = 0>
-__device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit, const TL& tl = TL{},
-                           int* lds_array = nullptr, int* child_slots = nullptr)
+// lds_stack: this lane's column of the wave's LDS array [N][64].  FAST (the closest-hit pass of the frame, round 5): the stack's state is the
+// LDS address of its next free entry (TravStackA; lds_array = the wave's array) and the child codes go through child_slots (16 bytes of LDS
+// per lane, see traverse_core).
+template <bool ANY_HIT, bool STATS, int N = kLdsStack, bool FAST = false>
+__device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit, int* lds_array = nullptr,
+                           int* child_slots = nullptr)
 {
     hit.t = tmax;
     hit.tri = ~0u;
@@ -779,21 +562,19 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
         return false;
     bool found = false;
     int spill_mem[64 - N];
-    using Stack = std::conditional_t<(MODE & 1) != 0, TravStackA<N>, TravStackT<N, LANE_FREE>>;
-    Stack st = [&]() {
-        if constexpr ((MODE & 1) != 0)
-            return TravStackA<N>((LdsInt*)lds_stack, (LdsInt*)lds_array, spill_mem);
-        else
-            return TravStackT<N, LANE_FREE>{(LdsInt*)lds_stack, spill_mem, 0};
-    }();
     // A ray whose direction is zero or whose origin / direction is not a number (a G-buffer normal of 0 makes one) would pass every
     // slab test -- min / max drop the NaNs -- and walk the WHOLE tree, 0.1 s per wave on a 262 k-triangle scene, without ever
     // hitting a triangle (det == 0 or NaN).  It hits nothing: it does not start.
     const float dd = dot3(d, d), oo = dot3(o, o);
     const bool walkable = dd > 0.0f && dd < __builtin_inff() && oo < __builtin_inff();
     int node = walkable ? S.root : kTravDone;
-    traverse_core<ANY_HIT, STATS, ((MODE & 32) ? 4 : (MODE & 8) ? 3 : (MODE & 4) ? 2 : (MODE & 2) ? 1 : 0), ((MODE & 16) != 0 || NEB_TRAV_PIPE != 0)>(S, o, d, tmin, st, node, hit, found, tl,
-                                                                                                                                    (LdsInt*)child_slots);
+    if constexpr (FAST) {
+        TravStackA<N> st((LdsInt*)lds_stack, (LdsInt*)lds_array, spill_mem);
+        traverse_core<ANY_HIT, STATS, !ANY_HIT>(S, o, d, tmin, st, node, hit, found, (LdsInt*)child_slots);
+    } else {
+        TravStackT<N> st{(LdsInt*)lds_stack, spill_mem, 0};
+        traverse_core<ANY_HIT, STATS, false>(S, o, d, tmin, st, node, hit, found);
+    }
     return found;
 }
 

@@ -143,7 +143,7 @@ struct SceneView {
     const float4* shade;     // 8 x float4 (one 128-B line) per sorted triangle: see pack_shade_records_kernel
     uint32_t n_tris;
     int32_t root;            // root node index, or a leaf code (< 0) for a single-triangle scene
-    uint32_t n_qnodes;       // nodes in qnodes (breadth-first: the first ones are the top of the tree, see TreeletT)
+    uint32_t n_qnodes;       // nodes in qnodes (breadth-first: the first ones are the top of the tree)
 };
 
 struct GiState {
