@@ -211,8 +211,7 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         if (bounce && !a.raygen_only && a.S.n_tris) {
             Hit hit;
             const bool found = a.stats ? traverse_t<false, true, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane)
-                                       : traverse_t<false, false, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane,
-                                                                                  child_slot_mem /* (the slots double as the tail's hand-out table: the one-lane loop is not running then) */);
+                                       : traverse_t<false, false, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane);
             if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only

@@ -234,13 +234,6 @@ template <bool FAST = false> __device__ float3 evaluate_direct_brdf(const Surfac
 #ifndef NEB_LDS_STACK
 #define NEB_LDS_STACK 16
 #endif
-#ifndef NEB_PROBE_CUT_TAIL
-#define NEB_PROBE_CUT_TAIL 0
-#endif
-#ifndef NEB_TAIL_LANES
-#define NEB_TAIL_LANES 16 // live lanes at which a full closest-hit wave hands its rays to four lanes each (0: never)
-#endif
-constexpr int kTailLanes = NEB_TAIL_LANES;
 constexpr int kLdsStack = NEB_LDS_STACK; // per-lane entries kept in LDS (4 KB per wave at 16)
 constexpr int kSpillStack = 64 - kLdsStack; // deeper entries go to a private (scratch) array; rarely touched (TravStackT)
 static_assert((kLdsStack + kSpillStack) / 3 == 21, "GiState::max_bvh_depth assumes a 64-entry traversal stack");
@@ -398,23 +391,15 @@ constexpr int kTravDone = (int)0x80000000;
 // Measured and moved out of the product (git tag r05-traversal-arms holds them all, docs/NOTEBOOK.md 10.1 their numbers): the 128-byte
 // exact-plane walk and tail suspension (round 2); "pop-ahead" (the next node requested before the leaf's triangle tests: one memory wait
 // per iteration), the top of the tree in LDS, branch-free pushes, the four child codes read up front, multi-wave workgroups (round 5).
-// tail_lanes (wave-uniform, closest-hit walks of full waves): the loop is left -- by all lanes still walking, together -- once no more than this many are
-// (0: never); the caller hands them to traverse_tail_quads.
 template <bool ANY_HIT, bool STATS, bool LDS_SELECT, class Stack>
 __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, float3 d, float tmin, Stack& st, int& node, Hit& hit, bool& found,
-                                              LdsInt* child_slots = nullptr, int tail_lanes = 0)
+                                              LdsInt* child_slots = nullptr)
 {
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
     constexpr uint32_t kMiss = 0xffffffffu;
     while (node != kTravDone) {
-#if NEB_PROBE_CUT_TAIL // timing only (wrong results): the wave stops when this few lanes are still walking -- what the thin tail of a wave costs the launch
-        if (!ANY_HIT && __popcll(__ballot(true)) <= NEB_PROBE_CUT_TAIL)
-            break;
-#endif
-        if (!ANY_HIT && tail_lanes && (int)__popcll(__ballot(true)) <= tail_lanes)
-            break; // (the lanes that are done have left the loop: the ballot counts the ones still walking)
         if (STATS) {
             const uint32_t nn = (uint32_t)__popcll(__ballot(node >= 0));
             hit.w_iters++;
@@ -561,151 +546,12 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
         found = hit.tri != ~0u;
 }
 
-// ---- The thin tail of a closest-hit wave, four lanes per ray (round 5) ----
-// A wave of bounce rays runs 28 iterations for rays that need 16: 35 % of its iterations serve 16 rays or fewer, 22 % four or fewer
-// (tools/gi_tail_lanes.py), and each of them still costs the whole node phase -- cutting the wave off at 16 live lanes (timing only) takes 64 us
-// of a 292-us launch.  So when no more than 16 rays of a FULL wave are still walking, they are dealt out to the wave's 16 quads (lanes 4 k .. 4 k + 3):
-// lane q of a quad decodes and tests child q of the node -- a quarter of the arithmetic, no sorting network: a child's rank among the quad's keys
-// is three DPP compares, the nearest child's code meets the other lanes in two DPP steps, the other hit children are written to the ray's stack by
-// their own lanes in parallel at the very positions the one-lane walk pushes them to; in a leaf lanes 0 and 1 test its (up to) two triangles.
-// Same nodes, same keys (slab_key_t on the same plane distances), same visiting order, same triangle test on the same operands, and the merge of the
-// two triangle tests is the sequential rule (the second wins only with a strictly smaller t): the hit is the one-lane walk's, bit for bit.
-// A ray keeps the LDS column of the lane it came from (its stack is there); one whose stack would outgrow the column's N rows cannot go on here
-// (the deeper entries live in a lane's private array): the whole wave then returns to the one-lane loop, which finishes it -- `false`.
-template <int CTRL>
-__device__ __forceinline__ int quad_perm(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
-}
-constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadXor3 = 0x1B, kQuadLane0 = 0x00, kQuadLane1 = 0x55; // quad_perm [1,0,3,2] [2,3,0,1] [3,2,1,0] [0,0,0,0] [1,1,1,1]
-template <int N>
-__device__ __forceinline__ bool traverse_tail_quads(const SceneView& S, float3& o, float3& d, float tmin, TravStackA<N>& st, int& node, Hit& hit, LdsInt* scratch)
-{
-    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
-    // ---- deal the live rays out to the quads: ray number r (in lane order) goes to quad r ----
-    const bool live = node != kTravDone;
-    const unsigned long long lm = __ballot(live);
-    const uint32_t n_live = (uint32_t)__popcll(lm);
-    if (__ballot(live && st.top > st.array + 64 * N)) // a ray with entries in its private array: not movable
-        return false;
-    const uint32_t my_rank = (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
-    if (live)
-        scratch[my_rank] = (int)lane;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const bool has_ray = quad < n_live;
-    const int src = has_ray ? scratch[quad] : (int)lane;
-    auto take_f = [&](float v) { return __shfl(v, src); };
-    auto take_i = [&](int v) { return __shfl(v, src); };
-    const float3 qo = f3(take_f(o.x), take_f(o.y), take_f(o.z)), qd = f3(take_f(d.x), take_f(d.y), take_f(d.z));
-    float ht = take_f(hit.t), hu = take_f(hit.u), hv = take_f(hit.v);
-    int htri = take_i((int)hit.tri);
-    int qnode = take_i(node);
-    LdsInt* top = st.array + take_i((int)(st.top - st.array));
-    if (!has_ray)
-        qnode = kTravDone;
-    // the ray set-up of traverse_core, on the same operands
-    const float3 inv = f3(1.0f / qd.x, 1.0f / qd.y, 1.0f / qd.z);
-    const float3 oinv = f3(qo.x * inv.x, qo.y * inv.y, qo.z * inv.z);
-    const bool negx = qd.x < 0.0f, negy = qd.y < 0.0f, negz = qd.z < 0.0f;
-    constexpr uint32_t kMiss = 0xffffffffu;
-    const uint32_t shift = 8u * q;
-    LdsInt* const limit = st.array + 64 * N;
-    bool completed = true;
-    for (;;) {
-        if (!__ballot(qnode != kTravDone))
-            break;
-        if (__ballot(qnode >= 0 && top + 3 * 64 > limit)) { // this node's pushes might not fit the LDS rows: back to the one-lane loop
-            completed = false;
-            break;
-        }
-        if (qnode >= 0) {
-            const char* nodes = reinterpret_cast<const char*>(S.qnodes);
-            const uint32_t nb = (uint32_t)qnode << 6;
-            const float4 p0 = *reinterpret_cast<const float4*>(nodes + nb);
-            const float4 p1 = *reinterpret_cast<const float4*>(nodes + (nb + 16u));
-            const uint4 p2 = *reinterpret_cast<const uint4*>(nodes + (nb + 32u));
-            const int4 ch = *reinterpret_cast<const int4*>(nodes + (nb + 48u));
-            const float sx = p0.w * inv.x, sy = p1.x * inv.y, sz = p1.y * inv.z;
-            const float bx = fmaf(p0.x, inv.x, -oinv.x), by = fmaf(p0.y, inv.y, -oinv.y), bz = fmaf(p0.z, inv.z, -oinv.z);
-            const uint32_t lox = __float_as_uint(p1.z), loy = __float_as_uint(p1.w);
-            const uint32_t qnx = negx ? p2.y : lox, qfx = negx ? lox : p2.y;
-            const uint32_t qny = negy ? p2.z : loy, qfy = negy ? loy : p2.z;
-            const uint32_t qnz = negz ? p2.w : p2.x, qfz = negz ? p2.x : p2.w;
-            auto un = [&](uint32_t w) { return (float)((w >> shift) & 0xffu); };
-            const uint32_t key = slab_key_t(fmaf(un(qnx), sx, bx), fmaf(un(qny), sy, by), fmaf(un(qnz), sz, bz), fmaf(un(qfx), sx, bx), fmaf(un(qfy), sy, by),
-                                            fmaf(un(qfz), sz, bz), tmin, ht, q);
-            const bool hitq = key != kMiss;
-            const uint32_t k1 = (uint32_t)quad_perm<kQuadXor1>((int)key), k2 = (uint32_t)quad_perm<kQuadXor2>((int)key), k3 = (uint32_t)quad_perm<kQuadXor3>((int)key);
-            const int rank = (k1 < key) + (k2 < key) + (k3 < key); // (the slot bits make the quad's hit keys distinct)
-            const int h = (k1 != kMiss) + (k2 != kMiss) + (k3 != kMiss) + (hitq ? 1 : 0);
-            const int child = q == 0 ? ch.x : q == 1 ? ch.y : q == 2 ? ch.z : ch.w;
-            // the nearest hit child goes on: its lane's code meets the other three
-            int next = (hitq && rank == 0) ? child : kTravDone;
-            const int n1 = quad_perm<kQuadXor1>(next);
-            next = next != kTravDone ? next : n1;
-            const int n2 = quad_perm<kQuadXor2>(next);
-            next = next != kTravDone ? next : n2;
-            // the others onto the stack, farthest first: rank r lands h - 1 - r entries above the old top (where traverse_core's three pushes put it)
-            if (hitq && rank >= 1)
-                top[64 * (h - 1 - rank)] = child;
-            top += 64 * (h > 1 ? h - 1 : 0);
-            if (next == kTravDone && top >= st.array + 64) { // no child hit: the next pending node (the quad's four lanes read one word)
-                top -= 64;
-                next = *top;
-            }
-            qnode = next;
-        }
-        if (qnode < 0 && qnode != kTravDone) { // a leaf: lanes 0 and 1 of the quad test its (up to) two triangles
-            const uint32_t code = (uint32_t)~qnode;
-            const uint32_t first = code >> 2, count = (code & 3u) + 1u;
-            const uint32_t ti = first + min(q & 1u, count - 1u);
-            float t, u, v;
-            bool hh = intersect_tri(S.tris, ti, qo, qd, tmin, ht, t, u, v);
-            // the sequential rule: the second triangle wins only with a strictly smaller t than the first's (a one-triangle leaf: both lanes hold the same test)
-            const int h1 = quad_perm<kQuadLane1>(hh ? 1 : 0), h0 = quad_perm<kQuadLane0>(hh ? 1 : 0);
-            const float t1 = __int_as_float(quad_perm<kQuadLane1>(__float_as_int(t))), t0 = __int_as_float(quad_perm<kQuadLane0>(__float_as_int(t)));
-            const bool second = h1 && (!h0 || t1 < t0);
-            if (h0 | h1) {
-                if (second) {
-                    ht = t1;
-                    hu = __int_as_float(quad_perm<kQuadLane1>(__float_as_int(u)));
-                    hv = __int_as_float(quad_perm<kQuadLane1>(__float_as_int(v)));
-                    htri = quad_perm<kQuadLane1>((int)ti);
-                } else {
-                    ht = t0;
-                    hu = __int_as_float(quad_perm<kQuadLane0>(__float_as_int(u)));
-                    hv = __int_as_float(quad_perm<kQuadLane0>(__float_as_int(v)));
-                    htri = quad_perm<kQuadLane0>((int)ti);
-                }
-            }
-            if (top >= st.array + 64) {
-                top -= 64;
-                qnode = *top;
-            } else {
-                qnode = kTravDone;
-            }
-        }
-    }
-    // ---- every ray back to the lane it came from (ray r sits in lane 4 r) ----
-    const int from = (int)(4u * my_rank);
-    const float bt = __shfl(ht, from), bu = __shfl(hu, from), bv = __shfl(hv, from);
-    const int btri = __shfl(htri, from), bnode = __shfl(qnode, from), btop = __shfl((int)(top - st.array), from);
-    if (live) {
-        hit.t = bt, hit.u = bu, hit.v = bv, hit.tri = (uint32_t)btri;
-        node = bnode;
-        st.top = st.array + btop;
-    }
-    return completed;
-}
-
 // lds_stack: this lane's column of the wave's LDS array [N][64].  FAST (the closest-hit pass of the frame, round 5): the stack's state is the
 // LDS address of its next free entry (TravStackA; lds_array = the wave's array) and the child codes go through child_slots (16 bytes of LDS
 // per lane, see traverse_core).
 template <bool ANY_HIT, bool STATS, int N = kLdsStack, bool FAST = false>
 __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit, int* lds_array = nullptr,
-                           int* child_slots = nullptr, int* tail_scratch = nullptr /* 16 words of LDS, wave-uniform: the quads' hand-out table */)
+                           int* child_slots = nullptr)
 {
     hit.t = tmax;
     hit.tri = ~0u;
@@ -724,18 +570,7 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     int node = walkable ? S.root : kTravDone;
     if constexpr (FAST) {
         TravStackA<N> st((LdsInt*)lds_stack, (LdsInt*)lds_array, spill_mem);
-        // the thin tail of a FULL wave goes to four lanes per ray (traverse_tail_quads); a wave with lanes that never came here walks one lane per ray throughout
-        bool tail_ok = !ANY_HIT && !STATS && kTailLanes > 0 && tail_scratch != nullptr && __ballot(true) == ~0ull;
-        for (;;) {
-            traverse_core<ANY_HIT, STATS, !ANY_HIT>(S, o, d, tmin, st, node, hit, found, (LdsInt*)child_slots, tail_ok ? kTailLanes : 0);
-            if (!tail_ok || !__ballot(node != kTravDone))
-                break;
-            if (traverse_tail_quads<N>(S, o, d, tmin, st, node, hit, (LdsInt*)tail_scratch))
-                break;
-            tail_ok = false; // (a stack outgrew its LDS rows: the one-lane loop finishes the wave)
-        }
-        if (!ANY_HIT)
-            found = hit.tri != ~0u;
+        traverse_core<ANY_HIT, STATS, !ANY_HIT>(S, o, d, tmin, st, node, hit, found, (LdsInt*)child_slots);
     } else {
         TravStackT<N> st{(LdsInt*)lds_stack, spill_mem, 0};
         traverse_core<ANY_HIT, STATS, false>(S, o, d, tmin, st, node, hit, found);
