@@ -957,8 +957,8 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
     if (phase == 0 && g->begun != g->finished)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace: a dispatch begun with neb_gi_trace_begin still waits for its neb_gi_trace_finish");
     if (phase != 0) {
-        if (g->defer_resolve)
-            return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_begin / _finish: not together with gi_defer_resolve (the finish call adds into radiance[cur] itself)");
+        if (g->defer_resolve == 2)
+            return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_begin / _finish: not together with gi_defer_resolve = 2 (the two-call form alternates the record sets itself; 1 is fine)");
         if (c->samplesPerPixel != 1 || c->maxPathVertices > 2 || g->sort_bounce)
             return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_trace_begin / _finish: one sample and one bounce per pixel only, bounce-ray sorting off (use neb_gi_trace)");
         if (phase == 1 && g->begun - g->finished >= 2u)
@@ -1055,6 +1055,10 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
     ds.pending_row1 = row1;
     if (g->defer_resolve == 2)
         g->traces++;
+    if (g->defer_resolve == 1 && phase != 1) { // this set's sums wait for neb_gi_resolve, oldest first (the two-call form alternates the sets)
+        ds.awaiting_resolve = true;
+        ds.resolve_seq = ++g->resolve_seq;
+    }
     const uint32_t tiles_y = (row1 - row0 + 7) / 8;
     const dim3 grid(a.tiles_x * tiles_y), block(64);
     const size_t n_blocks = (size_t)a.tiles_x * ((ctx->row_end - ctx->row_begin + 7) / 8 + 1);
@@ -1178,7 +1182,15 @@ int neb_gi_resolve(neb_ctx* ctx, neb_stream stream)
     GiState* g = ctx->gi;
     if (!g || !g->defer_resolve || (g->defer_resolve == 2 && g->resolves == g->traces))
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
-    GiState::DispatchSet& ds = g->sets[g->defer_resolve == 2 ? (g->resolves & 1u) : 0u]; // (two sets: the oldest dispatch first)
+    uint32_t which = g->defer_resolve == 2 ? (g->resolves & 1u) : 0u; // (two sets: the oldest dispatch first)
+    if (g->defer_resolve == 1) {
+        const bool a0 = g->sets[0].awaiting_resolve, a1 = g->sets[1].awaiting_resolve;
+        if (!a0 && !a1)
+            return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
+        which = (a0 && a1) ? (g->sets[1].resolve_seq < g->sets[0].resolve_seq ? 1u : 0u) : (a1 ? 1u : 0u);
+        g->sets[which].awaiting_resolve = false;
+    }
+    GiState::DispatchSet& ds = g->sets[which];
     if (!ds.d_records)
         return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_resolve: nothing pending (set option gi_defer_resolve=1 and call neb_gi_trace first)");
     if (g->defer_resolve == 2)

@@ -170,9 +170,12 @@ struct GiState {
         uint32_t* d_list = nullptr;  // [2][kListSegments] counters, then [kListSegments][cap] ray records
         uint32_t list_epoch = 0;     // shade launches so far: picks the counter set
         uint32_t pending_spp = 1, pending_row0 = 0, pending_row1 = 0;
+        bool awaiting_resolve = false; // "gi_defer_resolve" = 1: this set's sums have not been added into radiance[cur] yet
+        uint32_t resolve_seq = 0;      // ... and the order in which the sets were filled (neb_gi_resolve takes the oldest)
         neb_gi_constants split_c{}; // neb_gi_trace_begin's arguments, for its neb_gi_trace_finish
         uint32_t split_row0 = 0, split_row1 = 0;
     } sets[2];
+    uint32_t resolve_seq = 0;
     uint32_t traces = 0, resolves = 0; // deferred dispatches issued / retired (set = count & 1 with two sets)
     uint32_t begun = 0, finished = 0;  // neb_gi_trace_begin / _finish calls (set = count & 1)
     uint32_t* d_direct_counts = nullptr; // neb_pbr_direct's own per-workgroup ray counts (it may run beside a GI dispatch)

@@ -731,3 +731,62 @@ def test_degenerate_normals_do_not_walk_the_whole_tree():
     assert after["bounce_nodes"] == before["bounce_nodes"], (before, after)  # no bounce ray walked the tree
     assert degenerate < 5.0 * usual + 2e-3, (degenerate, usual)
     r.destroy()
+
+
+def test_two_call_dispatch_with_a_deferred_resolve_is_bit_exact():
+    """neb_gi_trace_begin / _finish together with "gi_defer_resolve" = 1 (round 5): the GI chain of frame f on a side stream, back to back, its sums left in the
+    record set the two-call form alternates; neb_gi_resolve takes the oldest set; the denoiser of frame f - 1 enqueued AFTER the walk of frame f (the context
+    switched back to frame f - 1 for it).  The schedule of tools/frame_stagger.py -- measured slower than bench.py's form, kept as a supported order: same bits."""
+    import torch
+    from nebulae_amd.svgf import PLANE_DEPTH, PLANE_NORMAL
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    outs = []
+    for mode in ("serial", "stagger"):
+        r = DeferredRenderer()
+        r.init(W, H, atrous_levels=4)
+        main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+        info = lambda f: RenderInfo(scene=sc, camera=cam, frame_index=f, stream=main.cuda_stream)
+        r.begin_frame(info(1))
+        r.submit_commands_gbuffer()
+        torch.cuda.synchronize()
+        for pl in (PLANE_NORMAL, PLANE_DEPTH):
+            r.svgf.plane_tensor(pl, 0).copy_(r.svgf.plane_tensor(pl, 1))
+        rad = [r.svgf.plane_tensor(PLANE_RADIANCE, 0), r.svgf.plane_tensor(PLANE_RADIANCE, 1)]
+        direct = torch.full_like(rad[0], 0.125)
+        if mode == "serial":
+            for f in range(2, 10):
+                r.begin_frame(info(f))
+                rad[r.svgf.get_current_resource_index()].copy_(direct, non_blocking=True)
+                r.submit_commands_gi_pathtrace()
+                r.submit_commands_svgf_denoising()
+                r.end_frame()
+        else:
+            r.set_defer_resolve(1)
+            gi_done = None
+            for f in range(2, 11):  # (the last pass only flushes frame 9's denoiser)
+                walked = None
+                if f < 10:
+                    r.begin_frame(info(f))
+                    r.submit_commands_gi_pathtrace_begin(stream=side.cuda_stream)
+                    walked = torch.cuda.Event()
+                    walked.record(side)
+                if gi_done is not None:
+                    r.begin_frame(info(f - 1))
+                    rad[r.svgf.get_current_resource_index()].copy_(direct, non_blocking=True)
+                    main.wait_event(gi_done)
+                    r.submit_commands_gi_resolve()
+                    if walked is not None:
+                        main.wait_event(walked)
+                    r.submit_commands_svgf_denoising()
+                    r.end_frame()
+                if f < 10:
+                    r.begin_frame(info(f))
+                    r.submit_commands_gi_pathtrace_finish(stream=side.cuda_stream)
+                    gi_done = torch.cuda.Event()
+                    gi_done.record(side)
+        torch.cuda.synchronize()
+        outs.append(r.svgf.download(PLANE_RADIANCE, slot=1))  # (frame 9's slot, whatever the context's current frame is)
+        r.destroy()
+    assert float(np.abs(outs[0][..., :3]).max()) > 0.2
+    assert np.array_equal(outs[0], outs[1])
