@@ -324,11 +324,11 @@ uint32_t strip_swaps(const StripRows& R, uint32_t n, neb_halo_swap out[2])
 int strip_sync(neb_ctx* ctx)
 {
     auto& s = ctx->strip;
-    if (s.xstream)
+    if (s.xstream && s.ready && s.done && s.pushed && s.frame_done)
         return NEB_OK;
-    hipError_t e = hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking);
+    hipError_t e = s.xstream ? hipSuccess : hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking);
     for (hipEvent_t* ev : {&s.ready, &s.done, &s.pushed, &s.frame_done})
-        if (e == hipSuccess)
+        if (e == hipSuccess && !*ev) // (a call that failed half way is completed by the next one)
             e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess)
         return strip_fail(ctx, NEB_ERR_HIP, std::string("neb_strip_frame: stream / event creation: ") + hipGetErrorString(e));
