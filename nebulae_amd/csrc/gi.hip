@@ -76,6 +76,7 @@ struct GiArgs {
     uint32_t bounce;             // path vertex this launch handles: 1 .. maxPathVertices - 1
     uint32_t stats;              // 1: also count shadow-ray traversal steps (slow path, diagnostics)
     uint32_t defer_resolve;      // 1: leave the frame's sum in the record plane; neb_gi_resolve adds it into radiance[cur] later
+    const uint32_t* tile_order;  // closest-hit pass: workgroup b takes tile tile_order[b] (tuning: neb_gi_debug_set_tile_order), or null: the XCD-aware default
     uint32_t* sort_keys;         // shadow-ray sorting ("gi_sort_shadow_rays"): Morton key of the ray origin per pixel, or null
     uint32_t* sort_vals;         // pixel index per key
     const uint32_t* sort_order;  // pixel indices in key order (after the radix sort), or null: pixel order
@@ -165,7 +166,16 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
     __shared__ int child_slot_mem[256];
     uint32_t x, y;
     size_t i64;
-    const bool active = gi_pixel<kRaygenRuns>(a, x, y, i64);
+    bool active;
+    if (a.tile_order) { // (tuning arm: an explicit tile order, e.g. the most expensive tiles of the last frame first)
+        const uint32_t blk = a.tile_order[blockIdx.x], tile_x = blk % a.tiles_x, tile_y = blk / a.tiles_x;
+        x = tile_x * 8 + (threadIdx.x & 7);
+        y = a.row0 + tile_y * 8 + (threadIdx.x >> 3);
+        i64 = (size_t)(y - a.row_begin) * a.W + x;
+        active = x < a.W && y < a.row1;
+    } else {
+        active = gi_pixel<kRaygenRuns>(a, x, y, i64);
+    }
     const uint32_t i = (uint32_t)i64, lane = threadIdx.x; // (32 bits: one register across the walk)
     uint32_t rays = 0;
     uint32_t wave_stamp[5] = {0u, 0u, 0u, 0u, 0u}; // diagnostics (a.stats): the closest-hit loop's wave stamps, see Hit
@@ -1002,6 +1012,7 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
     a.stats = g->debug_hits ? 1u : 0u;
     a.sort_keys = a.sort_vals = nullptr;
     a.sort_order = nullptr;
+    a.tile_order = (g->d_tile_order && g->tile_order_n == a.tiles_x * ((row1 - row0 + 7) / 8)) ? g->d_tile_order : nullptr;
     a.first_px = (uint32_t)((size_t)(row0 - ctx->row_begin) * ctx->W);
     a.n_px = (uint32_t)((size_t)(row1 - row0) * ctx->W);
     for (int q = 0; q < 3; ++q) {
@@ -1323,6 +1334,29 @@ int neb_gi_wave_stats(neb_ctx* ctx, uint64_t out[6])
         return NEB_ERR_INVALID_ARG;
     for (int k = 0; k < 6; ++k)
         out[k] = ctx->gi->last_stats[5 + k];
+    return NEB_OK;
+}
+
+int neb_gi_debug_set_tile_order(neb_ctx* ctx, const uint32_t* order, uint32_t n)
+{
+    if (!ctx || !ctx->gi)
+        return NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    GI_GUARD(ctx);
+    GI_HIP(ctx, hipDeviceSynchronize());
+    if (!order || n == 0) {
+        g->tile_order_n = 0;
+        return NEB_OK;
+    }
+    if (g->tile_order_cap < n) {
+        void* p = nullptr;
+        GI_HIP(ctx, hipMalloc(&p, (size_t)n * sizeof(uint32_t)));
+        g->allocs.push_back(p);
+        g->d_tile_order = (uint32_t*)p;
+        g->tile_order_cap = n;
+    }
+    GI_HIP(ctx, hipMemcpy(g->d_tile_order, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g->tile_order_n = n;
     return NEB_OK;
 }
 

@@ -176,6 +176,8 @@ struct GiState {
         uint32_t split_row0 = 0, split_row1 = 0;
     } sets[2];
     uint32_t resolve_seq = 0;
+    uint32_t* d_tile_order = nullptr; // tuning: an explicit tile order for the closest-hit pass (neb_gi_debug_set_tile_order)
+    uint32_t tile_order_n = 0, tile_order_cap = 0;
     uint32_t traces = 0, resolves = 0; // deferred dispatches issued / retired (set = count & 1 with two sets)
     uint32_t begun = 0, finished = 0;  // neb_gi_trace_begin / _finish calls (set = count & 1)
     uint32_t* d_direct_counts = nullptr; // neb_pbr_direct's own per-workgroup ray counts (it may run beside a GI dispatch)
