@@ -1360,6 +1360,16 @@ int neb_gi_debug_set_tile_order(neb_ctx* ctx, const uint32_t* order, uint32_t n)
     return NEB_OK;
 }
 
+int neb_gi_debug_sun_walk_stats(neb_ctx* ctx, uint64_t out[12])
+{
+    if (!ctx || !ctx->gi || !out || !ctx->gi->d_sun_counts)
+        return NEB_ERR_INVALID_ARG;
+    GI_GUARD(ctx);
+    GI_HIP(ctx, hipDeviceSynchronize());
+    GI_HIP(ctx, hipMemcpy(out, ctx->gi->d_sun_counts + 8, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return NEB_OK;
+}
+
 int neb_gi_node_index_stats(neb_ctx* ctx, uint64_t out[5])
 {
     if (!ctx || !ctx->gi || !out)

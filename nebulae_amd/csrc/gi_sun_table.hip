@@ -38,6 +38,7 @@ struct SunTableArgs {
     float4* shade;     // the shading records (writable view of S.shade)
     unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint, [3] triangles listed for the hint pass, [4] ... for pass 3
     uint32_t* hint_list;        // two-pass build: the triangles whose primary side is not proven lit (pass 1 appends, pass 2 reads)
+    unsigned long long* walk_stats; // diagnostics or null: [3 * PASS + {0, 1, 2}] = {node visits, longest walk, walks over 1000 visits}
     uint32_t* retry_list;       // pass 1: the triangles whose budget of node visits ran out with a side still unproven (pass 3 walks them to the end)
     uint32_t lit_budget;        // pass 1: node visits per triangle, 0 = unlimited (then no pass 3)
     uint32_t hint_budget;       // pass 2: candidate triangles (those that shadow at least one sample origin) looked at per receiver, 0 = all
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
     for (int h = 0; h < kHints; ++h)
         hint[h] = kNoHint;
     bool hinted = false, listed = false;
+    uint32_t visits_total = 0;
     if (mine) {
         const float4 t0 = a.S.tris[3 * ti], t1 = a.S.tris[3 * ti + 1], t2 = a.S.tris[3 * ti + 2];
         // the triangle the traverser tests: (v0, v0 + e1, v0 + e2) with e1, e2 as stored
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
             };
             while (node != kTravDone && !walk_done()) {
                 ++visits;
+                ++visits_total;
                 const Bvh4Node nd = a.S.nodes[node];
                 const int ch[4] = {nd.child.x, nd.child.y, nd.child.z, nd.child.w};
                 node = kTravDone;
@@ -283,6 +286,20 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
         hinted = hint[0] != kNoHint;
     }
     const unsigned long long m0 = __ballot(kLit && (flags & 1u) != 0u), m1 = __ballot(kLit && (flags & 2u) != 0u), m2 = __ballot(hinted);
+    if (a.walk_stats) { // diagnostics (tools/sun_table_walks.py): how long the walks are -- per pass {sum of node visits, longest walk, walks over 1000 visits}
+        unsigned long long v = visits_total, mx = visits_total, big = visits_total > 1000u ? 1ull : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_down(v, off);
+            mx = max(mx, (unsigned long long)__shfl_down(mx, off));
+            big += __shfl_down(big, off);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(a.walk_stats + 3 * PASS + 0, v);
+            atomicMax(a.walk_stats + 3 * PASS + 1, mx);
+            atomicAdd(a.walk_stats + 3 * PASS + 2, big);
+        }
+    }
     const unsigned long long m3 = __ballot(listed), m4 = __ballot(undecided);
     unsigned long long base = 0, base4 = 0;
     if ((threadIdx.x & 63u) == 0) {
@@ -402,7 +419,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     }
     if (!g->d_sun_counts) {
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, 8 * sizeof(unsigned long long));
+        hipError_t e = hipMalloc(&p, 24 * sizeof(unsigned long long));
         if (e != hipSuccess)
             return e;
         g->allocs.push_back(p);
@@ -411,7 +428,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     hipError_t e = quiesce();
     if (e != hipSuccess)
         return e;
-    e = hipMemsetAsync(g->d_sun_counts, 0, 8 * sizeof(unsigned long long), stream);
+    e = hipMemsetAsync(g->d_sun_counts, 0, 24 * sizeof(unsigned long long), stream);
     if (e != hipSuccess)
         return e;
     SunTableArgs a;
@@ -427,6 +444,7 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     a.scene_hmax = hmax + fmax(1e-3, a.F.margin);
     a.shade = const_cast<float4*>(g->view.shade);
     a.counts = g->d_sun_counts;
+    a.walk_stats = getenv("NEB_SUN_WALK_STATS") ? g->d_sun_counts + 8 : nullptr;
     static const bool one_pass = getenv("NEB_SUN_TABLE_PASSES") && atoi(getenv("NEB_SUN_TABLE_PASSES")) == 1; // (A/B arm: round 4's single walk)
     if (one_pass) {
         a.hint_list = a.retry_list = nullptr;
