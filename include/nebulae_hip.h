@@ -382,8 +382,9 @@ int neb_gi_node_index_stats(neb_ctx* ctx, uint64_t out[5]);
 /* Tuning: the order in which the closest-hit pass takes its 8x8 tiles -- workgroup b walks tile order[b] (a permutation of 0 .. n - 1, n = the tiles of the
  * dispatches it applies to; any other dispatch keeps the default, XCD-aware order); NULL / 0 restores the default.  Results do not depend on it.  Synchronises. */
 int neb_gi_debug_set_tile_order(neb_ctx* ctx, const uint32_t* order, uint32_t n);
-/* Diagnostics of the sun-table build (collected when the environment variable NEB_SUN_WALK_STATS is set at build time of the table): per pass 0 .. 3 of
- * sun_table_kernel {node visits of all walks, the longest walk, walks of more than 1000 visits}.  Synchronises. */
+/* Diagnostics of the sun-table build (collected when the environment variable NEB_SUN_WALK_STATS is set at build time of the table): for the lit pass
+ * (out[0 .. 5]) and the hint pass (out[6 .. 11]) {node visits of all walks, the longest walk, candidate triangles tested, sum of the waves' run times and
+ * the longest wave in 10-ns ticks, waves}.  Synchronises. */
 int neb_gi_debug_sun_walk_stats(neb_ctx* ctx, uint64_t out[12]);
 /* Debug: when option "gi_debug_hits" is 1, every trace also records neb_gi_hit per resident pixel. */
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream);

@@ -14,7 +14,7 @@
 // Both live in the spare bits / last 12 bytes of the triangle's 128-byte shading record, which gi_shade_kernel has in LDS anyway:
 // not one extra byte of traffic for the flags, 48 bytes per hint tried.  The answer is the traversal's own
 // (tests/test_sun_table_gpu.py: radiance, hit records and sun-visibility flags bit-identical with the table on and off, every GI scene
-// and the bench frame).  Rebuilt (15 ms at 262 k triangles) when sunLightDirection / sunTanHalfAngle have changed AND held for two
+// and the bench frame).  Rebuilt (6 ms at 262 k triangles) when sunLightDirection / sunTanHalfAngle have changed AND held for two
 // dispatches, or the scene is rebuilt; a sun that moves every frame -- the reference marks such frames dynamic,
 // src/DeferredRenderer.cpp:169-171 -- is traced the plain way meanwhile.
 //
@@ -36,12 +36,9 @@ struct SunTableArgs {
     double scene_hmax; // highest point of the scene along L
     double box_pad;    // padding of the node boxes (floats) in the double-precision cull: an ulp of the scene's largest coordinate, at least 1e-5
     float4* shade;     // the shading records (writable view of S.shade)
-    unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint, [3] triangles listed for the hint pass, [4] ... for pass 3
-    uint32_t* hint_list;        // two-pass build: the triangles whose primary side is not proven lit (pass 1 appends, pass 2 reads)
-    unsigned long long* walk_stats; // diagnostics or null: [3 * PASS + {0, 1, 2}] = {node visits, longest walk, walks over 1000 visits}
-    uint32_t* retry_list;       // pass 1: the triangles whose budget of node visits ran out with a side still unproven (pass 3 walks them to the end)
-    uint32_t lit_budget;        // pass 1: node visits per triangle, 0 = unlimited (then no pass 3)
-    uint32_t hint_budget;       // pass 2: candidate triangles (those that shadow at least one sample origin) looked at per receiver, 0 = all
+    unsigned long long* counts; // [0] sides proven lit (+), [1] (-), [2] triangles with an occluder hint, [3] triangles listed for the hint pass
+    uint32_t* hint_list;        // the triangles whose primary side is not proven lit, | that side << 31 (pass 1 appends, pass 2 reads)
+    unsigned long long* walk_stats; // diagnostics or null: [6 * (PASS - 1) + ...] = {node visits, longest walk, candidates tested, wave time sum, longest wave (10-ns ticks), waves}
 };
 
 __device__ inline void node_child_box(const Bvh4Node& nd, int q, double lo[3], double hi[3])
@@ -54,39 +51,209 @@ __device__ inline void node_child_box(const Bvh4Node& nd, int q, double lo[3], d
     hi[0] = h0[q], hi[1] = h1[q], hi[2] = h2[q];
 }
 
-// PASS 0: lit bits and hints in one walk of the whole column (rounds 4: 15.5 ms at 262 k triangles; kept as the A/B arm, NEB_SUN_TABLE_PASSES=1).
-// PASS 1 + PASS 2 (round 5, the default): the lit bits first -- a walk that ENDS as soon as every valid side has met something it cannot rule out
-// (most unlit triangles do within a few leaves) -- and the triangles whose primary side is left unproven appended to a list; then the hint walk
-// for those only, in dense waves, over the primary side's own column, ending once the four best candidates cover all 28 sample origins.
-// Same certificate, same lit bits; the hints may differ from the one-pass choice (they are only ever hints: tried with the traverser's own test).
+// Two passes (round 5; round 4 did both in one walk of the whole column, 15.5 ms at 262 k triangles):
+// PASS 1, the lit bits: per side a walk that ENDS as soon as the side has met something it cannot rule out (a side turned away from the sun meets its own
+// triangle before any walk), and the triangles whose primary side is left unproven appended to a list;
+// PASS 2, the hints, for those only, in dense waves, over the primary side's column, ending once the four best candidates cover all 28 sample origins.
+// One Receiver is live at a time and nothing a lane keeps is indexed at run time except the node stack and may_occlude's clip buffers (round 5: the one-walk
+// kernel held both sides' receivers and the candidate table in scratch, 1.5-1.8 KB per lane at 255 registers; the build's time was its candidate tests).
 #ifndef NEB_SUN_EDGE_CULL
 #define NEB_SUN_EDGE_CULL 1
 #endif
-constexpr uint32_t kSunLitBudget = 0u; // (see SunTableArgs::lit_budget; NEB_SUN_LIT_BUDGET overrides)
-constexpr uint32_t kSunHintBudget = 0u; // (see SunTableArgs::hint_budget; NEB_SUN_HINT_BUDGET overrides)
-template <int PASS>
-__global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
+#ifndef NEB_SUN_WAVES
+#define NEB_SUN_WAVES 1 // waves per SIMD the register allocation of the lit pass aims for (measured: 1 = 256 registers 1.91 ms, 2 = 176 registers + spills 2.14 ms)
+#endif
+
+// the kCand candidates that cover most sample origins so far, best first -- registers only: insertion is a chain of compare-and-swap
+constexpr int kCand = 8;
+struct SunCands {
+    uint32_t tri[kCand], mask[kCand];
+    int pop[kCand];
+    uint32_t seen;
+    __device__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < kCand; ++k)
+            tri[k] = kNoHint, mask[k] = 0u, pop[k] = 0;
+        seen = 0u;
+    }
+    __device__ void insert(uint32_t tj, uint32_t m)
+    {
+        int pc = __popc(m);
+        seen += pc ? 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < kCand; ++k) { // (behind the entries that cover as many: first found stays first)
+            const bool up = pc > pop[k];
+            const uint32_t t_ = tri[k], m_ = mask[k];
+            const int p_ = pop[k];
+            tri[k] = up ? tj : t_, mask[k] = up ? m : m_, pop[k] = up ? pc : p_;
+            tj = up ? t_ : tj, m = up ? m_ : m, pc = up ? p_ : pc;
+        }
+    }
+    __device__ bool top4_cover_all() const
+    {
+        constexpr uint32_t kAll = (1u << lit::kCoverSamples) - 1u;
+        return ((mask[0] | mask[1] | mask[2] | mask[3]) & kAll) == kAll;
+    }
+    // greedy cover: up to kHints candidates, each the one that adds most samples not yet covered
+    __device__ void choose(uint32_t hint[kHints])
+    {
+        uint32_t covered = 0u;
+#pragma unroll
+        for (int h = 0; h < kHints; ++h) {
+            int best = -1, gain = 0;
+#pragma unroll
+            for (int k = 0; k < kCand; ++k) {
+                const int gk = tri[k] != kNoHint ? __popc(mask[k] & ~covered) : 0;
+                if (gk > gain)
+                    gain = gk, best = k;
+            }
+            uint32_t chosen = kNoHint;
+#pragma unroll
+            for (int k = 0; k < kCand; ++k)
+                if (k == best) {
+                    chosen = tri[k];
+                    covered |= mask[k];
+                    tri[k] = kNoHint;
+                }
+            hint[h] = chosen;
+        }
+    }
+};
+
+// Walks everything that reaches into the column the rays of receiver R (triangle ti) can sweep.  HINT = false: returns whether the certificate held for every
+// triangle found (ends at the first that may occlude).  HINT = true: ranks the triangles that shadow R's sample origins into `cands`.
+// The walk only QUEUES the triangles of the leaves it reaches (kSunQueue entries per lane in LDS); they are tested when some lane's queue is nearly full or
+// no lane walks any more, every lane with an entry testing one per step.  (Tested inside the walk -- up to eight candidates behind any node of any lane -- a wave
+// ran iterations x 8 test slots for the 20 candidates a lane has on average: 2.5 % of the lanes busy, 1.2 ms per wave, the longest wave 6.6 ms = the launch.)
+constexpr int kSunQueue = 40;
+template <bool HINT>
+__device__ bool sun_walk_column(const SunTableArgs& a, const lit::Receiver& R, bool active, uint32_t ti, SunCands& cands, uint32_t* queue, uint32_t& visits, uint32_t& tested)
 {
+    const double reach = (a.scene_hmax - R.h_min + a.F.margin) * a.F.tau + a.F.margin;
+    const double qa0 = R.bb_a[0] - reach, qa1 = R.bb_a[1] + reach, qb0 = R.bb_b[0] - reach, qb1 = R.bb_b[1] + reach, qh = R.h_min - a.F.margin;
+    bool alive = active;
+    int qn = 0; // entries in this lane's queue (queue[64 * k] = entry k)
+    auto queue_leaf = [&](int code) {
+        const uint32_t c = (uint32_t)~code, first = c >> 2, count = (c & 3u) + 1u;
+        for (uint32_t k = 0; k < count; ++k)
+            queue[64 * qn++] = first + k;
+    };
+    auto test_one = [&](uint32_t tj) {
+        ++tested;
+        const float4 o0 = a.S.tris[3 * tj], o1 = a.S.tris[3 * tj + 1], o2 = a.S.tris[3 * tj + 2];
+        const double w[3][3] = {{o0.x, o0.y, o0.z},
+                                {(double)o0.x + o0.w, (double)o0.y + o1.x, (double)o0.z + o1.y},
+                                {(double)o0.x + o1.z, (double)o0.y + o1.w, (double)o0.z + o2.x}};
+        lit::Tri O;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            lit::to_sun(a.F, w[i], O.a[i], O.b[i], O.h[i]);
+        if constexpr (HINT) {
+            if (tj != ti)
+                cands.insert(tj, lit::cover_mask(R, O));
+        } else {
+            alive = !lit::may_occlude(a.F, R, O);
+        }
+    };
+    int stack[64];
+    int sp = 0;
+    int node = active ? a.S.root : kTravDone;
+    if (node < 0) { // a scene of one leaf
+        queue_leaf(node);
+        node = kTravDone;
+    }
+    for (;;) {
+        const bool walking = node != kTravDone && alive && !(HINT && cands.top4_cover_all());
+        if (walking) {
+            ++visits;
+            const Bvh4Node nd = a.S.nodes[node];
+            const int ch[4] = {nd.child.x, nd.child.y, nd.child.z, nd.child.w};
+            node = kTravDone;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double lo[3], hi[3];
+                node_child_box(nd, q, lo, hi);
+                if (!(lo[0] <= hi[0])) // unused slot: inverted box
+                    continue;
+                // sun-space bounds of the world box: centre +- |axis| . half extent (padded: the boxes are floats)
+                const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+                const double e[3] = {0.5 * (hi[0] - lo[0]) + a.box_pad, 0.5 * (hi[1] - lo[1]) + a.box_pad, 0.5 * (hi[2] - lo[2]) + a.box_pad};
+                const double ca = c[0] * a.F.A[0] + c[1] * a.F.A[1] + c[2] * a.F.A[2];
+                const double ea = e[0] * fabs(a.F.A[0]) + e[1] * fabs(a.F.A[1]) + e[2] * fabs(a.F.A[2]);
+                if (ca + ea < qa0 || ca - ea > qa1)
+                    continue;
+                const double cb = c[0] * a.F.B[0] + c[1] * a.F.B[1] + c[2] * a.F.B[2];
+                const double eb = e[0] * fabs(a.F.B[0]) + e[1] * fabs(a.F.B[1]) + e[2] * fabs(a.F.B[2]);
+                if (cb + eb < qb0 || cb - eb > qb1)
+                    continue;
+                const double chh = c[0] * a.F.L[0] + c[1] * a.F.L[1] + c[2] * a.F.L[2];
+                const double eh = e[0] * fabs(a.F.L[0]) + e[1] * fabs(a.F.L[1]) + e[2] * fabs(a.F.L[2]);
+                if (chh + eh < qh) // wholly below the lowest ray origin
+                    continue;
+                // ... and against the receiver's FOOTPRINT, not only its box: a node wholly beyond one edge of the projected triangle -- pushed out by the
+                // offset box and by the drift a ray can have when it has climbed to the node's top, exactly the half-planes lit::may_occlude clips every
+                // triangle with -- holds nothing that can matter (may_occlude would clip each of its triangles to nothing; cover_mask finds no sample under
+                // them).  For a large receiver the box is twice the triangle.
+                if constexpr (NEB_SUN_EDGE_CULL) {
+                    const double rho = ((chh + eh) - R.h_min + a.F.margin) * a.F.tau + a.F.margin;
+                    bool outside = false;
+#pragma unroll
+                    for (int ed = 0; ed < 3; ++ed) {
+                        const double na = R.en_a[ed], nb = R.en_b[ed];
+                        const double lim = R.en_c[ed] + R.en_off[ed] + rho * (fabs(na) + fabs(nb));
+                        // least value of na * a + nb * b over the node's box (the box's sun-space extents ea, eb bound every corner)
+                        outside = outside || (na * ca + nb * cb - (fabs(na) * ea + fabs(nb) * eb) > lim);
+                    }
+                    if (outside)
+                        continue;
+                }
+                if (ch[q] < 0) {
+                    queue_leaf(ch[q]);
+                } else if (node == kTravDone) {
+                    node = ch[q];
+                } else if (sp < 64) {
+                    stack[sp++] = ch[q];
+                } else { // cannot happen (neb_gi_build_bvh bounds the depth); if it did, no certificate
+                    alive = false;
+                }
+            }
+            if (node == kTravDone && sp > 0)
+                node = stack[--sp];
+        }
+        // a node adds at most 4 leaves x 4 triangles
+        const bool wave_walks = __ballot(walking) != 0ull;
+        if (__ballot(qn > kSunQueue - 16) != 0ull || !wave_walks) {
+            while (__ballot(qn > 0 && alive) != 0ull)
+                if (qn > 0 && alive)
+                    test_one(queue[64 * --qn]);
+            if (!wave_walks)
+                break; // (a lane whose walk had ended has emptied its queue or lost its certificate)
+        }
+    }
+    return alive;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(64, PASS == 1 ? NEB_SUN_WAVES : 3) void sun_table_kernel(SunTableArgs a)
+{
+    static_assert(PASS == 1 || PASS == 2, "pass 1 = lit bits, pass 2 = hints");
     uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
     bool mine = ti < a.S.n_tris;
+    int primary = 0;
     if constexpr (PASS == 2) {
         mine = ti < (uint32_t)a.counts[3];
-        if (mine)
-            ti = a.hint_list[ti];
+        if (mine) {
+            const uint32_t entry = a.hint_list[ti]; // triangle | its primary side << 31
+            ti = entry & 0x7fffffffu;
+            primary = (int)(entry >> 31);
+        }
     }
-    if constexpr (PASS == 3) { // the lit pass of the triangles pass 1 ran out of budget on: the same walk to its end, in dense waves
-        mine = ti < (uint32_t)a.counts[4];
-        if (mine)
-            ti = a.retry_list[ti];
-    }
-    constexpr bool kLit = PASS == 0 || PASS == 1 || PASS == 3, kHint = PASS == 0 || PASS == 2;
-    bool undecided = false;
     uint32_t flags = 0;
-    uint32_t hint[kHints];
-    for (int h = 0; h < kHints; ++h)
-        hint[h] = kNoHint;
     bool hinted = false, listed = false;
-    uint32_t visits_total = 0;
+    __shared__ uint32_t sun_queue[kSunQueue * 64];
+    uint32_t visits = 0, tested = 0;
+    const unsigned long long clock0 = a.walk_stats ? wall_clock64() : 0ull;
     if (mine) {
         const float4 t0 = a.S.tris[3 * ti], t1 = a.S.tris[3 * ti + 1], t2 = a.S.tris[3 * ti + 2];
         // the triangle the traverser tests: (v0, v0 + e1, v0 + e2) with e1, e2 as stored
@@ -97,12 +264,11 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r6 = rec[6];
         const uint32_t geom = __float_as_uint(r6.w) & kGeomMask;
         const DevGeom g = a.S.geoms[geom];
-        lit::Receiver R[2];
-        R[0].valid = R[1].valid = false;
-        if (g.valid) { // (a submesh without its attribute streams ends the path at the hit: no shadow ray ever starts there)
+        double gn[3][3];
+        bool ok = g.valid; // (a submesh without its attribute streams ends the path at the hit: no shadow ray ever starts there)
+        if (ok) {
             const float n[3][3] = {{r0.x, r0.y, r0.z}, {r1.x, r1.y, r1.z}, {r2.x, r2.y, r2.z}};
-            double gn[3][3];
-            bool ok = true;
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
                 // GN = normalize(xform_dir(M, normalize(sum b_i n_i))) lies in the cone of xform_dir(M, n_i): (p, 0) * M, row vectors
                 const double x = (double)n[i][0] * g.m[0] + (double)n[i][1] * g.m[3] + (double)n[i][2] * g.m[6];
@@ -112,171 +278,46 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
                 ok = ok && l > 0.0 && l < 1e30;
                 gn[i][0] = x / l, gn[i][1] = y / l, gn[i][2] = z / l;
             }
+        }
+        SunCands cands;
+        cands.clear();
+        if constexpr (PASS == 1) {
+            // The side whose rays the hints are for (the one turned to the sun: the shader picks the side of GN the disk sample is on) is the one whose
+            // origins sit higher over the plane.
+            bool valid0 = false, valid1 = false, alive0 = false, alive1 = false;
+            double clo0 = 0.0, clo1 = 0.0;
             if (ok) {
-                lit::make_receiver(a.F, v, gn, +1, R[0]);
-                lit::make_receiver(a.F, v, gn, -1, R[1]);
+#pragma unroll 1
+                for (int sd = 0; sd < 2; ++sd) {
+                    lit::Receiver R;
+                    lit::make_receiver(a.F, v, gn, sd ? -1 : +1, R);
+                    // its own triangle first (the walk would meet it: the receiver lies in its own column) -- the side turned away from the sun ends here
+                    bool alive = R.valid && !lit::may_occlude(a.F, R, R.t);
+                    alive = sun_walk_column<false>(a, R, alive, ti, cands, sun_queue + (threadIdx.x & 63u), visits, tested);
+                    if (sd == 0)
+                        valid0 = R.valid, alive0 = alive, clo0 = R.c_lo;
+                    else
+                        valid1 = R.valid, alive1 = alive, clo1 = R.c_lo;
+                }
             }
-        }
-        bool alive[2] = {R[0].valid, R[1].valid};
-        // Occluder hints for the side the rays of this triangle start on (the one turned to the sun: the shader picks the side of
-        // GN the disk sample is on): the two triangles whose shadow covers most of the footprint.  gi_shade_kernel tries them
-        // with the traverser's own triangle test before it emits a shadow ray -- any hit answers "occluded" exactly.
-        const int primary = (R[0].valid && R[1].valid) ? (R[1].c_lo > R[0].c_lo ? 1 : 0) : (R[1].valid ? 1 : 0);
-        // the kCand candidates that cover most sample origins so far (cover_mask), best first
-        constexpr int kCand = 8;
-        uint32_t cand_tri[kCand], cand_mask[kCand];
-        int cand_pop[kCand];
-        for (int k = 0; k < kCand; ++k)
-            cand_tri[k] = kNoHint, cand_mask[k] = 0u, cand_pop[k] = 0;
-        if (R[0].valid || R[1].valid) {
-            // the column both sides' rays can sweep, in sun coordinates
-            double qa[2] = {1e300, -1e300}, qb[2] = {1e300, -1e300}, qh = 1e300;
-            for (int s = 0; s < 2; ++s)
-                if (R[s].valid) {
-                    if (PASS == 2 && s != primary)
-                        continue; // (the hint pass: the primary side's own column)
-                    const double reach = (a.scene_hmax - R[s].h_min + a.F.margin) * a.F.tau + a.F.margin;
-                    qa[0] = fmin(qa[0], R[s].bb_a[0] - reach), qa[1] = fmax(qa[1], R[s].bb_a[1] + reach);
-                    qb[0] = fmin(qb[0], R[s].bb_b[0] - reach), qb[1] = fmax(qb[1], R[s].bb_b[1] + reach);
-                    qh = fmin(qh, R[s].h_min - a.F.margin);
-                }
-            int stack[64];
-            int sp = 0;
-            int node = a.S.root;
-            uint32_t cands_seen = 0;
-            auto test_leaf = [&](int code) {
-                const uint32_t c = (uint32_t)~code, first = c >> 2, count = (c & 3u) + 1u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t tj = first + k;
-                    const float4 o0 = a.S.tris[3 * tj], o1 = a.S.tris[3 * tj + 1], o2 = a.S.tris[3 * tj + 2];
-                    const double w[3][3] = {{o0.x, o0.y, o0.z},
-                                            {(double)o0.x + o0.w, (double)o0.y + o1.x, (double)o0.z + o1.y},
-                                            {(double)o0.x + o1.z, (double)o0.y + o1.w, (double)o0.z + o2.x}};
-                    lit::Tri O;
-                    for (int i = 0; i < 3; ++i)
-                        lit::to_sun(a.F, w[i], O.a[i], O.b[i], O.h[i]);
-                    if (kLit)
-                        for (int s = 0; s < 2; ++s)
-                            if (alive[s] && lit::may_occlude(a.F, R[s], O))
-                                alive[s] = false;
-                    if (kHint && R[primary].valid && tj != ti) {
-                        const uint32_t m = lit::cover_mask(R[primary], O);
-                        const int pc = __popc(m);
-                        cands_seen += pc ? 1u : 0u;
-                        if (pc > cand_pop[kCand - 1]) { // insertion into the sorted candidate list
-                            int at = kCand - 1;
-                            while (at > 0 && cand_pop[at - 1] < pc) {
-                                cand_tri[at] = cand_tri[at - 1], cand_mask[at] = cand_mask[at - 1], cand_pop[at] = cand_pop[at - 1];
-                                --at;
-                            }
-                            cand_tri[at] = tj, cand_mask[at] = m, cand_pop[at] = pc;
-                        }
-                    }
-                }
-            };
-            if (node < 0) { // a scene of one leaf
-                test_leaf(node);
-                node = kTravDone;
-            }
-            constexpr uint32_t kAllSamples = (1u << lit::kCoverSamples) - 1u;
-            uint32_t visits = 0;
-            auto walk_done = [&]() {
-                if (PASS == 1 && a.lit_budget && visits >= a.lit_budget && (alive[0] || alive[1])) {
-                    undecided = true; // out of budget with something still unproven: pass 3 walks this triangle to the end
-                    return true;
-                }
-                if (PASS == 1 || PASS == 3)
-                    return !alive[0] && !alive[1]; // nothing left to prove
-                if (PASS == 2) // the four best cover every sample origin -- or the receiver has seen its budget of shadowing triangles
-                    return ((cand_mask[0] | cand_mask[1] | cand_mask[2] | cand_mask[3]) & kAllSamples) == kAllSamples || (a.hint_budget && cands_seen >= a.hint_budget);
-                return false; // (one pass: the whole column -- a side that is already known to be shadowed still wants its hints)
-            };
-            while (node != kTravDone && !walk_done()) {
-                ++visits;
-                ++visits_total;
-                const Bvh4Node nd = a.S.nodes[node];
-                const int ch[4] = {nd.child.x, nd.child.y, nd.child.z, nd.child.w};
-                node = kTravDone;
-                for (int q = 0; q < 4; ++q) {
-                    double lo[3], hi[3];
-                    node_child_box(nd, q, lo, hi);
-                    if (!(lo[0] <= hi[0])) // unused slot: inverted box
-                        continue;
-                    // sun-space bounds of the world box: centre +- |axis| . half extent (padded: the boxes are floats)
-                    const double c[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-                    const double e[3] = {0.5 * (hi[0] - lo[0]) + a.box_pad, 0.5 * (hi[1] - lo[1]) + a.box_pad, 0.5 * (hi[2] - lo[2]) + a.box_pad};
-                    const double ca = c[0] * a.F.A[0] + c[1] * a.F.A[1] + c[2] * a.F.A[2];
-                    const double ea = e[0] * fabs(a.F.A[0]) + e[1] * fabs(a.F.A[1]) + e[2] * fabs(a.F.A[2]);
-                    if (ca + ea < qa[0] || ca - ea > qa[1])
-                        continue;
-                    const double cb = c[0] * a.F.B[0] + c[1] * a.F.B[1] + c[2] * a.F.B[2];
-                    const double eb = e[0] * fabs(a.F.B[0]) + e[1] * fabs(a.F.B[1]) + e[2] * fabs(a.F.B[2]);
-                    if (cb + eb < qb[0] || cb - eb > qb[1])
-                        continue;
-                    const double chh = c[0] * a.F.L[0] + c[1] * a.F.L[1] + c[2] * a.F.L[2];
-                    const double eh = e[0] * fabs(a.F.L[0]) + e[1] * fabs(a.F.L[1]) + e[2] * fabs(a.F.L[2]);
-                    if (chh + eh < qh) // wholly below the lowest ray origin
-                        continue;
-                    // (round 5) ... and against the receiver's FOOTPRINT, not only its box: a node wholly beyond one edge of the projected triangle --
-                    // pushed out by the offset box and by the drift a ray can have when it has climbed to the node's top, exactly the half-planes
-                    // lit::may_occlude clips every triangle with -- holds nothing that can matter to that side (may_occlude would clip each of its
-                    // triangles to nothing; cover_mask finds no sample under them).  For a large receiver the box is twice the triangle.
-                    if constexpr (NEB_SUN_EDGE_CULL) {
-                        bool keep = false;
-#pragma unroll
-                        for (int sd = 0; sd < 2; ++sd) {
-                            if (!R[sd].valid || (PASS == 2 && sd != primary) || (kLit && !kHint && !alive[sd]))
-                                continue;
-                            const double rho = ((chh + eh) - R[sd].h_min + a.F.margin) * a.F.tau + a.F.margin;
-                            bool outside = false;
-#pragma unroll
-                            for (int ed = 0; ed < 3; ++ed) {
-                                const double na = R[sd].en_a[ed], nb = R[sd].en_b[ed];
-                                const double lim = R[sd].en_c[ed] + R[sd].en_off[ed] + rho * (fabs(na) + fabs(nb));
-                                // least value of na * a + nb * b over the node's box (the box's sun-space extents ea, eb bound every corner)
-                                outside = outside || (na * ca + nb * cb - (fabs(na) * ea + fabs(nb) * eb) > lim);
-                            }
-                            keep = keep || !outside;
-                        }
-                        if (!keep)
-                            continue;
-                    }
-                    if (ch[q] < 0) {
-                        test_leaf(ch[q]);
-                    } else if (node == kTravDone) {
-                        node = ch[q];
-                    } else if (sp < 64) {
-                        stack[sp++] = ch[q];
-                    } else { // cannot happen (neb_gi_build_bvh bounds the depth); if it did, no certificate
-                        alive[0] = alive[1] = false;
-                    }
-                }
-                if (node == kTravDone && sp > 0)
-                    node = stack[--sp];
-            }
-        }
-        flags = undecided ? 0u : (alive[0] ? 1u : 0u) | (alive[1] ? 2u : 0u);
-        if constexpr (PASS != 2) {
+            primary = (valid0 && valid1) ? (clo1 > clo0 ? 1 : 0) : (valid1 ? 1 : 0);
+            flags = (alive0 ? 1u : 0u) | (alive1 ? 2u : 0u);
             float4 w6 = r6;
             w6.w = __uint_as_float(geom | (flags << kLitShift));
             a.shade[8 * (size_t)ti + 6] = w6;
+            listed = primary ? (valid1 && !alive1) : (valid0 && !alive0);
         }
-        listed = (PASS == 1 || PASS == 3) && !undecided && R[primary].valid && !alive[primary];
-        // greedy cover: up to kHints candidates, each the one that adds most samples not yet covered
-        if (kHint && (PASS == 2 || !alive[primary])) { // (a lit side needs no hints: every ray of it is answered by the lit bit)
-            uint32_t covered = 0u;
-            for (int h = 0; h < kHints; ++h) {
-                int best = -1, gain = 0;
-                for (int k = 0; k < kCand; ++k) {
-                    const int gk = cand_tri[k] != kNoHint ? __popc(cand_mask[k] & ~covered) : 0;
-                    if (gk > gain)
-                        gain = gk, best = k;
-                }
-                if (best < 0)
-                    break;
-                hint[h] = cand_tri[best];
-                covered |= cand_mask[best];
-                cand_tri[best] = kNoHint;
+        uint32_t hint[kHints];
+#pragma unroll
+        for (int h = 0; h < kHints; ++h)
+            hint[h] = kNoHint;
+        if constexpr (PASS == 2) { // (a lit side needs no hints: every ray of it is answered by the lit bit)
+            if (ok) {
+                lit::Receiver R;
+                lit::make_receiver(a.F, v, gn, primary ? -1 : +1, R);
+                sun_walk_column<true>(a, R, R.valid, ti, cands, sun_queue + (threadIdx.x & 63u), visits, tested);
+                if (R.valid)
+                    cands.choose(hint);
             }
         }
         // r7 = {PrimitiveIndex, then kHints x 21-bit triangle indices and the side they are for: see pack_hints}
@@ -285,23 +326,28 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
         a.shade[8 * (size_t)ti + 7] = w7;
         hinted = hint[0] != kNoHint;
     }
-    const unsigned long long m0 = __ballot(kLit && (flags & 1u) != 0u), m1 = __ballot(kLit && (flags & 2u) != 0u), m2 = __ballot(hinted);
-    if (a.walk_stats) { // diagnostics (tools/sun_table_walks.py): how long the walks are -- per pass {sum of node visits, longest walk, walks over 1000 visits}
-        unsigned long long v = visits_total, mx = visits_total, big = visits_total > 1000u ? 1ull : 0ull;
+    const unsigned long long m0 = __ballot(PASS == 1 && (flags & 1u) != 0u), m1 = __ballot(PASS == 1 && (flags & 2u) != 0u), m2 = __ballot(hinted);
+    if (a.walk_stats) { // diagnostics (tools/sun_table_walks.py): per pass {node visits, longest walk, candidates tested, shadowing candidates, wave time sum / max in 10-ns ticks}
+        unsigned long long vs = visits, mx = visits, ts = tested;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            v += __shfl_down(v, off);
+            vs += __shfl_down(vs, off);
             mx = max(mx, (unsigned long long)__shfl_down(mx, off));
-            big += __shfl_down(big, off);
+            ts += __shfl_down(ts, off);
         }
         if ((threadIdx.x & 63u) == 0) {
-            atomicAdd(a.walk_stats + 3 * PASS + 0, v);
-            atomicMax(a.walk_stats + 3 * PASS + 1, mx);
-            atomicAdd(a.walk_stats + 3 * PASS + 2, big);
+            const unsigned long long dt = wall_clock64() - clock0;
+            unsigned long long* w = a.walk_stats + 6 * (PASS - 1);
+            atomicAdd(w + 0, vs);
+            atomicMax(w + 1, mx);
+            atomicAdd(w + 2, ts);
+            atomicAdd(w + 3, dt);
+            atomicMax(w + 4, dt);
+            atomicAdd(w + 5, 1ull);
         }
     }
-    const unsigned long long m3 = __ballot(listed), m4 = __ballot(undecided);
-    unsigned long long base = 0, base4 = 0;
+    const unsigned long long m3 = __ballot(listed);
+    unsigned long long base = 0;
     if ((threadIdx.x & 63u) == 0) {
         if (m0)
             atomicAdd(a.counts + 0, (unsigned long long)__popcll(m0));
@@ -311,18 +357,11 @@ __global__ __launch_bounds__(64) void sun_table_kernel(SunTableArgs a)
             atomicAdd(a.counts + 2, (unsigned long long)__popcll(m2));
         if (m3)
             base = atomicAdd(a.counts + 3, (unsigned long long)__popcll(m3));
-        if (m4)
-            base4 = atomicAdd(a.counts + 4, (unsigned long long)__popcll(m4));
     }
-    if (PASS == 1 && m4) {
-        base4 = (unsigned long long)__shfl((int)(uint32_t)base4, 0);
-        if (undecided)
-            a.retry_list[(uint32_t)base4 + (uint32_t)__popcll(m4 & ((1ull << (threadIdx.x & 63u)) - 1ull))] = ti;
-    }
-    if ((PASS == 1 || PASS == 3) && m3) { // one atomic per wave: the wave's listed triangles go to consecutive slots
+    if (PASS == 1 && m3) { // one atomic per wave: the wave's listed triangles go to consecutive slots
         base = (unsigned long long)__shfl((int)(uint32_t)base, 0);
         if (listed)
-            a.hint_list[(uint32_t)base + (uint32_t)__popcll(m3 & ((1ull << (threadIdx.x & 63u)) - 1ull))] = ti;
+            a.hint_list[(uint32_t)base + (uint32_t)__popcll(m3 & ((1ull << (threadIdx.x & 63u)) - 1ull))] = ti | ((uint32_t)primary << 31);
     }
 }
 
@@ -445,31 +484,17 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     a.shade = const_cast<float4*>(g->view.shade);
     a.counts = g->d_sun_counts;
     a.walk_stats = getenv("NEB_SUN_WALK_STATS") ? g->d_sun_counts + 8 : nullptr;
-    static const bool one_pass = getenv("NEB_SUN_TABLE_PASSES") && atoi(getenv("NEB_SUN_TABLE_PASSES")) == 1; // (A/B arm: round 4's single walk)
-    if (one_pass) {
-        a.hint_list = a.retry_list = nullptr;
-        a.hint_budget = a.lit_budget = 0;
-        hipLaunchKernelGGL(sun_table_kernel<0>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
-    } else {
-        if (g->sun_hint_list_cap < g->view.n_tris) { // (a scene rebuild may have changed the reference count)
-            void* p = nullptr;
-            if (hipError_t em = hipMalloc(&p, 2 * (size_t)g->view.n_tris * sizeof(uint32_t)); em != hipSuccess)
-                return em;
-            g->allocs.push_back(p);
-            g->d_sun_hint_list = (uint32_t*)p;
-            g->sun_hint_list_cap = g->view.n_tris;
-        }
-        a.hint_list = g->d_sun_hint_list;
-        a.retry_list = g->d_sun_hint_list + g->view.n_tris; // (the second half of the same allocation)
-        static const uint32_t lit_budget = getenv("NEB_SUN_LIT_BUDGET") ? (uint32_t)atoi(getenv("NEB_SUN_LIT_BUDGET")) : kSunLitBudget;
-        a.lit_budget = lit_budget;
-        static const uint32_t budget = getenv("NEB_SUN_HINT_BUDGET") ? (uint32_t)atoi(getenv("NEB_SUN_HINT_BUDGET")) : kSunHintBudget;
-        a.hint_budget = budget;
-        hipLaunchKernelGGL(sun_table_kernel<1>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
-        if (a.lit_budget)
-            hipLaunchKernelGGL(sun_table_kernel<3>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL(sun_table_kernel<2>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a); // (waves past the list's end leave at once)
+    if (g->sun_hint_list_cap < g->view.n_tris) { // (a scene rebuild may have changed the reference count)
+        void* p = nullptr;
+        if (hipError_t em = hipMalloc(&p, (size_t)g->view.n_tris * sizeof(uint32_t)); em != hipSuccess)
+            return em;
+        g->allocs.push_back(p);
+        g->d_sun_hint_list = (uint32_t*)p;
+        g->sun_hint_list_cap = g->view.n_tris;
     }
+    a.hint_list = g->d_sun_hint_list;
+    hipLaunchKernelGGL(sun_table_kernel<1>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(sun_table_kernel<2>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a); // (waves past the list's end leave at once)
     if (hipError_t em = mark_rewrite(g, stream); em != hipSuccess)
         return em;
     memcpy(g->sun_table_key, key, sizeof(key));

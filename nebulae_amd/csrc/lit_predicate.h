@@ -206,6 +206,26 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
     if (smax <= 0.0)
         return false;
     const double rho = smax * F.tau + F.margin;    // ... and drifted sideways
+    const double bound = R.c_lo - R.grad1 * rho - F.margin;
+    // Two shortcuts that decide most candidates without the clip below (round 5: the build's time is these tests, not the walk).  (1) cannot change the
+    // answer: the quantity tested at the end, f = h - plane_R(a, b), is LINEAR over O, and the clipped polygon is a part of O -- if no vertex of O rises
+    // above the bound, no vertex of the polygon does (the receiver's coplanar neighbours, everything below it).  (2) is sound and a little sharper than the
+    // clip: every ray origin lies in the lateral box bb, a ray drifts at most rho, so O wholly outside bb pushed out by rho cannot be met -- the three
+    // edge half-planes alone form a triangle whose corners reach beyond that box (an obtuse receiver's far corner), where the clip says "may".
+    {
+        bool above = false;
+        for (int i = 0; i < 3; ++i)
+            above = above || !(O.h[i] - (R.h0 + R.ga * O.a[i] + R.gb * O.b[i]) <= bound);
+        if (!above)
+            return false;
+        double a0 = O.a[0], a1 = O.a[0], b0 = O.b[0], b1 = O.b[0];
+        for (int i = 1; i < 3; ++i) {
+            a0 = O.a[i] < a0 ? O.a[i] : a0, a1 = O.a[i] > a1 ? O.a[i] : a1;
+            b0 = O.b[i] < b0 ? O.b[i] : b0, b1 = O.b[i] > b1 ? O.b[i] : b1;
+        }
+        if (a1 < R.bb_a[0] - rho || a0 > R.bb_a[1] + rho || b1 < R.bb_b[0] - rho || b0 > R.bb_b[1] + rho)
+            return false;
+    }
     // clip O (as a 3-D polygon) by the three vertical planes through R's edges, pushed out by the drift and the offset box
     double pa[8], pb[8], ph[8], qa[8], qb[8], qh[8];
     int n = 3;
@@ -237,7 +257,6 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
     if (n == 0)
         return false;
     // s = h_q - h_o <= [h_q - plane_R(q_ab)] + grad1 * rho - c_lo; linear over the clipped polygon: the maximum is at a vertex
-    const double bound = R.c_lo - R.grad1 * rho - F.margin;
     for (int i = 0; i < n; ++i) {
         const double f = ph[i] - (R.h0 + R.ga * pa[i] + R.gb * pb[i]);
         // (an intersection point is computed with rounding of ~1e-16 relative: covered by the margin)
@@ -251,6 +270,12 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
 // a ray towards the centre of the sun disk would leave through O: bit k of the mask.  Only RANKS occluder hints
 // (gi_sun_table.hip): a hint is tried with the traverser's own triangle test, so a poor estimate costs speed, never correctness.
 constexpr int kCoverSamples = 28;
+// cover_mask counts a sample when O's height there exceeds the sample origin's by 1e-3: h_O - (h0 + ga a + gb b) > cover_floor(R) at the sample's (a, b)
+NEB_LIT_HD double cover_floor(const Receiver& R)
+{
+    const double ma = 0.5 * (R.off_a[0] + R.off_a[1]), mb = 0.5 * (R.off_b[0] + R.off_b[1]), mc = 0.5 * (R.c_lo + R.c_hi);
+    return 1e-3 + mc - R.ga * ma - R.gb * mb;
+}
 NEB_LIT_HD unsigned cover_mask(const Receiver& R, const Tri& O)
 {
     // quick reject on the lateral boxes
@@ -261,28 +286,44 @@ NEB_LIT_HD unsigned cover_mask(const Receiver& R, const Tri& O)
     }
     if (oa1 < R.bb_a[0] || oa0 > R.bb_a[1] || ob1 < R.bb_b[0] || ob0 > R.bb_b[1])
         return 0u;
+    { // (the height difference is linear over O: nowhere above the sample origins' plane, no sample counted -- the receiver's coplanar neighbours)
+        const double fl = cover_floor(R);
+        bool above = false;
+        for (int i = 0; i < 3; ++i)
+            above = above || O.h[i] - (R.h0 + R.ga * O.a[i] + R.gb * O.b[i]) > fl;
+        if (!above)
+            return 0u;
+    }
     const double ua = O.a[1] - O.a[0], ub = O.b[1] - O.b[0], wa = O.a[2] - O.a[0], wb = O.b[2] - O.b[0];
     const double det = ua * wb - ub * wa;
     if (det == 0.0)
         return 0u; // edge-on to the sun: no area to stand in
     const double inv = 1.0 / det;
-    const double ma = 0.5 * (R.off_a[0] + R.off_a[1]), mb = 0.5 * (R.off_b[0] + R.off_b[1]), mc = 0.5 * (R.c_lo + R.c_hi);
+    // The sample origins are a lattice p(r, c) = P + bu E1 + bv E2 on R's projection; the barycentrics (s, t) of p in O's projection, the third one
+    // u = 1 - s - t, and the height of O over the sample origin there are all AFFINE in (bu, bv): three values each, then one fma per row and one per sample.
+    const double ma = 0.5 * (R.off_a[0] + R.off_a[1]), mb = 0.5 * (R.off_b[0] + R.off_b[1]);
+    const double e1a = R.t.a[1] - R.t.a[0], e1b = R.t.b[1] - R.t.b[0], e2a = R.t.a[2] - R.t.a[0], e2b = R.t.b[2] - R.t.b[0];
+    const double da = R.t.a[0] + ma - O.a[0], db = R.t.b[0] + mb - O.b[0];
+    const double s0 = (da * wb - db * wa) * inv, su = (e1a * wb - e1b * wa) * inv, sv = (e2a * wb - e2b * wa) * inv;
+    const double t0 = (ua * db - ub * da) * inv, tu = (ua * e1b - ub * e1a) * inv, tv = (ua * e2b - ub * e2a) * inv;
+    const double u0 = 1.0 - s0 - t0, uu = -su - tu, uv = -sv - tv;
+    const double dh1 = O.h[1] - O.h[0], dh2 = O.h[2] - O.h[0];
+    // f(p) = h_O(p) - (h0 + ga pa + gb pb) must exceed cover_floor(R) (see there)
+    const double d0 = O.h[0] + s0 * dh1 + t0 * dh2 - (R.h0 + R.ga * (R.t.a[0] + ma) + R.gb * (R.t.b[0] + mb)) - cover_floor(R);
+    const double du = su * dh1 + tu * dh2 - (R.ga * e1a + R.gb * e1b), dv = sv * dh1 + tv * dh2 - (R.ga * e2a + R.gb * e2b);
     unsigned mask = 0u;
     int k = 0;
-    for (int r = 0; r < 7; ++r)
+    for (int r = 0; r < 7; ++r) {
+        const double bu = (r + 1.0 / 3.0) / 7.0;
+        const double sr = s0 + bu * su, tr = t0 + bu * tu, ur = u0 + bu * uu, dr = d0 + bu * du;
         for (int c = 0; c < 7 - r; ++c, ++k) {
-            const double bu = (r + 1.0 / 3.0) / 7.0, bv = (c + 1.0 / 3.0) / 7.0;
-            const double pa = R.t.a[0] + bu * (R.t.a[1] - R.t.a[0]) + bv * (R.t.a[2] - R.t.a[0]) + ma;
-            const double pb = R.t.b[0] + bu * (R.t.b[1] - R.t.b[0]) + bv * (R.t.b[2] - R.t.b[0]) + mb;
-            const double da = pa - O.a[0], db = pb - O.b[0];
-            const double s = (da * wb - db * wa) * inv, t = (ua * db - ub * da) * inv; // barycentrics of the sample in O's projection
-            if (s < 0.0 || t < 0.0 || s + t > 1.0)
-                continue;
-            const double ho = O.h[0] + s * (O.h[1] - O.h[0]) + t * (O.h[2] - O.h[0]);
-            const double hr = R.h0 + R.ga * (pa - ma) + R.gb * (pb - mb) + mc;
-            if (ho > hr + 1e-3)
+            const double bv = (c + 1.0 / 3.0) / 7.0;
+            const double sk = sr + bv * sv, tk = tr + bv * tv, uk = ur + bv * uv, dk = dr + bv * dv;
+            const double in = sk < tk ? (sk < uk ? sk : uk) : (tk < uk ? tk : uk);
+            if (in >= 0.0 && dk > 0.0)
                 mask |= 1u << k;
         }
+    }
     return mask;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tuning only: durations of the sun-table build kernels (rocprofv3 --kernel-trace --stats over one short bench run) and the sides proven lit, for the in-tree
-# library ("product") or build_variants/lib_<name>.so; environment settings may be given as name:VAR=value.  usage (GPU box): bash tools/ab_sun_table.sh product noedge product:NEB_SUN_TABLE_PASSES=1
+# library ("product") or build_variants/lib_<name>.so; environment settings may be given as name:VAR=value.  usage (GPU box): bash tools/ab_sun_table.sh product sw2
 case " $* " in *" --gpus "*) echo "$0 refuses --gpus"; exit 2;; esac
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"

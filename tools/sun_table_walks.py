@@ -22,8 +22,9 @@ r.submit_commands_gi_pathtrace()  # (builds the table)
 out = (C.c_uint64 * 12)()
 assert r._lib.neb_gi_debug_sun_walk_stats(r._ctx, out) == 0
 n = sc.num_triangles
-for p, name in ((1, "lit pass"), (2, "hint pass")):
-    v, mx, big = int(out[3 * p]), int(out[3 * p + 1]), int(out[3 * p + 2])
-    print(f"{name}: {v} node visits = {v / n:.1f} per triangle of the scene; longest walk {mx} visits; {big} walks over 1000 visits")
+for p, name in ((0, "lit pass"), (1, "hint pass")):
+    v, mx, tested, ticks, longest, waves = (int(out[6 * p + k]) for k in range(6))
+    print(f"{name}: {v} node visits = {v / n:.1f} per triangle of the scene, longest walk {mx}; {tested} candidate triangles tested = {tested / n:.1f} per triangle; "
+          f"{waves} waves, {ticks / 100 / max(waves, 1):.1f} us per wave, longest {longest / 100:.1f} us, sum {ticks / 1e5:.1f} wave-ms")
 print(r.sun_table_stats())
 r.destroy()
