@@ -14,7 +14,7 @@
 // Both live in the spare bits / last 12 bytes of the triangle's 128-byte shading record, which gi_shade_kernel has in LDS anyway:
 // not one extra byte of traffic for the flags, 48 bytes per hint tried.  The answer is the traversal's own
 // (tests/test_sun_table_gpu.py: radiance, hit records and sun-visibility flags bit-identical with the table on and off, every GI scene
-// and the bench frame).  Rebuilt (6 ms at 262 k triangles) when sunLightDirection / sunTanHalfAngle have changed AND held for two
+// and the bench frame).  Rebuilt (3 ms at 262 k triangles) when sunLightDirection / sunTanHalfAngle have changed AND held for two
 // dispatches, or the scene is rebuilt; a sun that moves every frame -- the reference marks such frames dynamic,
 // src/DeferredRenderer.cpp:169-171 -- is traced the plain way meanwhile.
 //
@@ -24,6 +24,7 @@
 // (What the lit bits alone are worth: 8 us -- the unoccluded rays of an open court leave the tree after 3 node visits on average;
 // the hints and the compaction of what is left, gi.hip, are the other 77.)
 #include <cstdlib>
+#include <type_traits>
 
 #include "gi_device.h"
 #include "lit_predicate.h"
@@ -121,45 +122,144 @@ struct SunCands {
     }
 };
 
-// Walks everything that reaches into the column the rays of receiver R (triangle ti) can sweep.  HINT = false: returns whether the certificate held for every
-// triangle found (ends at the first that may occlude).  HINT = true: ranks the triangles that shadow R's sample origins into `cands`.
-// The walk only QUEUES the triangles of the leaves it reaches (kSunQueue entries per lane in LDS); they are tested when some lane's queue is nearly full or
-// no lane walks any more, every lane with an entry testing one per step.  (Tested inside the walk -- up to eight candidates behind any node of any lane -- a wave
-// ran iterations x 8 test slots for the 20 candidates a lane has on average: 2.5 % of the lanes busy, 1.2 ms per wave, the longest wave 6.6 ms = the launch.)
-constexpr int kSunQueue = 40;
-template <bool HINT>
-__device__ bool sun_walk_column(const SunTableArgs& a, const lit::Receiver& R, bool active, uint32_t ti, SunCands& cands, uint32_t* queue, uint32_t& visits, uint32_t& tested)
+// What a lane of the wave needs of ANOTHER lane's receiver to test a candidate for it, through LDS (field f of lane l at view[64 * f + l]).
+template <class Fn>
+__device__ __forceinline__ void each_field(lit::OccludeView& V, Fn fn)
 {
+    fn(0, V.h_min), fn(1, V.c_lo), fn(2, V.grad1), fn(3, V.h0), fn(4, V.ga), fn(5, V.gb), fn(6, V.bb_a[0]), fn(7, V.bb_a[1]), fn(8, V.bb_b[0]), fn(9, V.bb_b[1]);
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+        fn(10 + e, V.en_a[e]), fn(13 + e, V.en_b[e]), fn(16 + e, V.en_c[e]), fn(19 + e, V.en_off[e]);
+}
+template <class Fn>
+__device__ __forceinline__ void each_field(lit::CoverView& V, Fn fn)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        fn(i, V.t.a[i]), fn(3 + i, V.t.b[i]);
+    fn(6, V.bb_a[0]), fn(7, V.bb_a[1]), fn(8, V.bb_b[0]), fn(9, V.bb_b[1]), fn(10, V.off_a[0]), fn(11, V.off_a[1]), fn(12, V.off_b[0]), fn(13, V.off_b[1]);
+    fn(14, V.c_lo), fn(15, V.c_hi), fn(16, V.h0), fn(17, V.ga), fn(18, V.gb);
+}
+constexpr int kOccludeFields = 22, kCoverFields = 19;
+__device__ __forceinline__ void view_of(const lit::Receiver& R, lit::OccludeView& V)
+{
+    V.h_min = R.h_min, V.c_lo = R.c_lo, V.grad1 = R.grad1, V.h0 = R.h0, V.ga = R.ga, V.gb = R.gb;
+    V.bb_a[0] = R.bb_a[0], V.bb_a[1] = R.bb_a[1], V.bb_b[0] = R.bb_b[0], V.bb_b[1] = R.bb_b[1];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+        V.en_a[e] = R.en_a[e], V.en_b[e] = R.en_b[e], V.en_c[e] = R.en_c[e], V.en_off[e] = R.en_off[e];
+}
+__device__ __forceinline__ void view_of(const lit::Receiver& R, lit::CoverView& V)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        V.t.a[i] = R.t.a[i], V.t.b[i] = R.t.b[i];
+    V.bb_a[0] = R.bb_a[0], V.bb_a[1] = R.bb_a[1], V.bb_b[0] = R.bb_b[0], V.bb_b[1] = R.bb_b[1];
+    V.off_a[0] = R.off_a[0], V.off_a[1] = R.off_a[1], V.off_b[0] = R.off_b[0], V.off_b[1] = R.off_b[1];
+    V.c_lo = R.c_lo, V.c_hi = R.c_hi, V.h0 = R.h0, V.ga = R.ga, V.gb = R.gb;
+}
+
+// what one wave keeps in LDS during a walk (one wave = one workgroup)
+constexpr int kSunQueue = 32;
+template <bool HINT>
+struct SunWaveLds {
+    uint32_t queue[kSunQueue * 64];               // per lane: the candidate triangles its walk has reached and nobody has tested yet
+    uint32_t result[HINT ? kSunQueue * 64 : 64];  // hints: the cover mask of queue entry k of lane l at [64 * k + l]; lit bits: [l] != 0 once a candidate of lane l may occlude
+    uint32_t start[64];                           // exclusive prefix sum of the lanes' queue lengths
+    uint32_t own_tri[64];                         // the receivers' own triangles
+    double view[(HINT ? kCoverFields : kOccludeFields) * 64];
+};
+
+// Walks everything that reaches into the column the rays of receiver R (triangle ti) can sweep.  HINT = false: returns whether the certificate held for every
+// triangle found (ends soon after the first that may occlude).  HINT = true: ranks the triangles that shadow R's sample origins into `cands`.  EVERY lane of the
+// wave calls this (active = false: nothing to walk) -- the walk only QUEUES the triangles of the leaves it reaches; when some lane's queue is nearly full or no
+// lane walks any more the WAVE tests what its lanes have queued, pair p = (receiver, candidate) on lane p % 64 whoever the receiver belongs to.
+// (Tested inside the walk -- up to eight candidates behind any node of any lane -- a wave ran iterations x 8 test slots for the 20 candidates a lane has on
+// average: 2.5 % of the lanes busy, 1.2 ms per wave, the longest wave 6.6 ms = the launch.  Each lane testing its own queue: the longest wave 4.2 ms.)
+template <bool HINT>
+__device__ bool sun_walk_column(const SunTableArgs& a, const lit::Receiver& R, bool active, uint32_t ti, SunCands& cands, SunWaveLds<HINT>& lds, uint32_t& visits, uint32_t& tested)
+{
+    using View = typename std::conditional<HINT, lit::CoverView, lit::OccludeView>::type;
+    const uint32_t lane = threadIdx.x & 63u;
     const double reach = (a.scene_hmax - R.h_min + a.F.margin) * a.F.tau + a.F.margin;
     const double qa0 = R.bb_a[0] - reach, qa1 = R.bb_a[1] + reach, qb0 = R.bb_b[0] - reach, qb1 = R.bb_b[1] + reach, qh = R.h_min - a.F.margin;
     bool alive = active;
-    int qn = 0; // entries in this lane's queue (queue[64 * k] = entry k)
+    uint32_t qn = 0; // entries in this lane's queue (queue[64 * k + lane] = entry k)
+    {
+        View mine;
+        view_of(R, mine);
+        each_field(mine, [&](int f, double& x) { lds.view[64 * f + lane] = x; });
+        lds.own_tri[lane] = ti;
+        if (!HINT)
+            lds.result[lane] = 0u;
+    }
     auto queue_leaf = [&](int code) {
         const uint32_t c = (uint32_t)~code, first = c >> 2, count = (c & 3u) + 1u;
         for (uint32_t k = 0; k < count; ++k)
-            queue[64 * qn++] = first + k;
+            lds.queue[64 * qn++ + lane] = first + k;
     };
-    auto test_one = [&](uint32_t tj) {
-        ++tested;
-        const float4 o0 = a.S.tris[3 * tj], o1 = a.S.tris[3 * tj + 1], o2 = a.S.tris[3 * tj + 2];
-        const double w[3][3] = {{o0.x, o0.y, o0.z},
-                                {(double)o0.x + o0.w, (double)o0.y + o1.x, (double)o0.z + o1.y},
-                                {(double)o0.x + o1.z, (double)o0.y + o1.w, (double)o0.z + o2.x}};
-        lit::Tri O;
+    // the wave empties its lanes' queues
+    auto test_queued = [&]() {
+        uint32_t incl = qn; // inclusive prefix sum over the lanes
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            lit::to_sun(a.F, w[i], O.a[i], O.b[i], O.h[i]);
-        if constexpr (HINT) {
-            if (tj != ti)
-                cands.insert(tj, lit::cover_mask(R, O));
-        } else {
-            alive = !lit::may_occlude(a.F, R, O);
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            incl += lane >= (uint32_t)off ? up : 0u;
         }
+        const uint32_t total = __shfl(incl, 63);
+        lds.start[lane] = incl - qn;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0; base < total; base += 64) {
+            const uint32_t p = base + lane;
+            if (p < total) {
+                uint32_t o = 0;
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1)
+                    o += lds.start[o + step] <= p ? step : 0u;
+                const uint32_t k = p - lds.start[o];
+                const uint32_t tj = lds.queue[64 * k + o];
+                uint32_t mask = 0u;
+                if (tj < a.S.n_tris && (HINT ? tj != lds.own_tri[o] : lds.result[o] == 0u)) { // (a receiver that has lost its certificate needs no more tests)
+                    ++tested;
+                    View V;
+                    each_field(V, [&](int f, double& x) { x = lds.view[64 * f + o]; });
+                    const float4 o0 = a.S.tris[3 * tj], o1 = a.S.tris[3 * tj + 1], o2 = a.S.tris[3 * tj + 2];
+                    const double w[3][3] = {{o0.x, o0.y, o0.z},
+                                            {(double)o0.x + o0.w, (double)o0.y + o1.x, (double)o0.z + o1.y},
+                                            {(double)o0.x + o1.z, (double)o0.y + o1.w, (double)o0.z + o2.x}};
+                    lit::Tri O;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        lit::to_sun(a.F, w[i], O.a[i], O.b[i], O.h[i]);
+                    if constexpr (HINT) {
+                        mask = lit::cover_mask(V, O);
+                    } else {
+                        if (lit::may_occlude(a.F, V, O))
+                            lds.result[o] = 1u;
+                    }
+                }
+                if constexpr (HINT)
+                    lds.result[64 * k + o] = mask;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (HINT) {
+            for (uint32_t k = 0; k < qn; ++k) {
+                const uint32_t m = lds.result[64 * k + lane];
+                if (m)
+                    cands.insert(lds.queue[64 * k + lane], m);
+            }
+        } else {
+            alive = alive && lds.result[lane] == 0u;
+        }
+        qn = 0;
     };
     int stack[64];
     int sp = 0;
     int node = active ? a.S.root : kTravDone;
-    if (node < 0) { // a scene of one leaf
+    if (node != kTravDone && node < 0) { // a scene of one leaf
         queue_leaf(node);
         node = kTravDone;
     }
@@ -223,19 +323,17 @@ __device__ bool sun_walk_column(const SunTableArgs& a, const lit::Receiver& R, b
         }
         // a node adds at most 4 leaves x 4 triangles
         const bool wave_walks = __ballot(walking) != 0ull;
-        if (__ballot(qn > kSunQueue - 16) != 0ull || !wave_walks) {
-            while (__ballot(qn > 0 && alive) != 0ull)
-                if (qn > 0 && alive)
-                    test_one(queue[64 * --qn]);
+        if (__ballot(qn > (uint32_t)kSunQueue - 16u) != 0ull || !wave_walks) {
+            test_queued();
             if (!wave_walks)
-                break; // (a lane whose walk had ended has emptied its queue or lost its certificate)
+                break;
         }
     }
     return alive;
 }
 
 template <int PASS>
-__global__ __launch_bounds__(64, PASS == 1 ? NEB_SUN_WAVES : 3) void sun_table_kernel(SunTableArgs a)
+__global__ __launch_bounds__(64, PASS == 1 ? NEB_SUN_WAVES : 2) void sun_table_kernel(SunTableArgs a)
 {
     static_assert(PASS == 1 || PASS == 2, "pass 1 = lit bits, pass 2 = hints");
     uint32_t ti = blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,21 +349,26 @@ __global__ __launch_bounds__(64, PASS == 1 ? NEB_SUN_WAVES : 3) void sun_table_k
     }
     uint32_t flags = 0;
     bool hinted = false, listed = false;
-    __shared__ uint32_t sun_queue[kSunQueue * 64];
+    __shared__ SunWaveLds<PASS == 2> lds;
     uint32_t visits = 0, tested = 0;
     const unsigned long long clock0 = a.walk_stats ? wall_clock64() : 0ull;
+    // (every lane of the wave goes through the walks below, with or without a triangle of its own: the wave tests its lanes' candidates together)
+    double v[3][3], gn[3][3];
+    float4 r6 = {0.f, 0.f, 0.f, 0.f};
+    uint32_t geom = 0;
+    bool ok = false;
     if (mine) {
         const float4 t0 = a.S.tris[3 * ti], t1 = a.S.tris[3 * ti + 1], t2 = a.S.tris[3 * ti + 2];
         // the triangle the traverser tests: (v0, v0 + e1, v0 + e2) with e1, e2 as stored
-        const double v[3][3] = {{t0.x, t0.y, t0.z},
-                                {(double)t0.x + t0.w, (double)t0.y + t1.x, (double)t0.z + t1.y},
-                                {(double)t0.x + t1.z, (double)t0.y + t1.w, (double)t0.z + t2.x}};
+        v[0][0] = t0.x, v[0][1] = t0.y, v[0][2] = t0.z;
+        v[1][0] = (double)t0.x + t0.w, v[1][1] = (double)t0.y + t1.x, v[1][2] = (double)t0.z + t1.y;
+        v[2][0] = (double)t0.x + t1.z, v[2][1] = (double)t0.y + t1.w, v[2][2] = (double)t0.z + t2.x;
         const float4* rec = a.S.shade + 8 * (size_t)ti;
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r6 = rec[6];
-        const uint32_t geom = __float_as_uint(r6.w) & kGeomMask;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        r6 = rec[6];
+        geom = __float_as_uint(r6.w) & kGeomMask;
         const DevGeom g = a.S.geoms[geom];
-        double gn[3][3];
-        bool ok = g.valid; // (a submesh without its attribute streams ends the path at the hit: no shadow ray ever starts there)
+        ok = g.valid; // (a submesh without its attribute streams ends the path at the hit: no shadow ray ever starts there)
         if (ok) {
             const float n[3][3] = {{r0.x, r0.y, r0.z}, {r1.x, r1.y, r1.z}, {r2.x, r2.y, r2.z}};
 #pragma unroll
@@ -279,49 +382,55 @@ __global__ __launch_bounds__(64, PASS == 1 ? NEB_SUN_WAVES : 3) void sun_table_k
                 gn[i][0] = x / l, gn[i][1] = y / l, gn[i][2] = z / l;
             }
         }
-        SunCands cands;
-        cands.clear();
-        if constexpr (PASS == 1) {
-            // The side whose rays the hints are for (the one turned to the sun: the shader picks the side of GN the disk sample is on) is the one whose
-            // origins sit higher over the plane.
-            bool valid0 = false, valid1 = false, alive0 = false, alive1 = false;
-            double clo0 = 0.0, clo1 = 0.0;
-            if (ok) {
+    }
+    if (!ok) { // (something finite for the arithmetic of a lane that only helps)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            v[i][0] = v[i][1] = v[i][2] = 0.0, gn[i][0] = gn[i][1] = 0.0, gn[i][2] = 1.0;
+    }
+    SunCands cands;
+    cands.clear();
+    uint32_t hint[kHints];
+#pragma unroll
+    for (int h = 0; h < kHints; ++h)
+        hint[h] = kNoHint;
+    if constexpr (PASS == 1) {
+        // The side whose rays the hints are for (the one turned to the sun: the shader picks the side of GN the disk sample is on) is the one whose
+        // origins sit higher over the plane.
+        bool valid0 = false, valid1 = false, alive0 = false, alive1 = false;
+        double clo0 = 0.0, clo1 = 0.0;
 #pragma unroll 1
-                for (int sd = 0; sd < 2; ++sd) {
-                    lit::Receiver R;
-                    lit::make_receiver(a.F, v, gn, sd ? -1 : +1, R);
-                    // its own triangle first (the walk would meet it: the receiver lies in its own column) -- the side turned away from the sun ends here
-                    bool alive = R.valid && !lit::may_occlude(a.F, R, R.t);
-                    alive = sun_walk_column<false>(a, R, alive, ti, cands, sun_queue + (threadIdx.x & 63u), visits, tested);
-                    if (sd == 0)
-                        valid0 = R.valid, alive0 = alive, clo0 = R.c_lo;
-                    else
-                        valid1 = R.valid, alive1 = alive, clo1 = R.c_lo;
-                }
-            }
-            primary = (valid0 && valid1) ? (clo1 > clo0 ? 1 : 0) : (valid1 ? 1 : 0);
-            flags = (alive0 ? 1u : 0u) | (alive1 ? 2u : 0u);
+        for (int sd = 0; sd < 2; ++sd) {
+            lit::Receiver R;
+            lit::make_receiver(a.F, v, gn, sd ? -1 : +1, R);
+            const bool valid = ok && R.valid;
+            // its own triangle first (the walk would meet it: the receiver lies in its own column) -- the side turned away from the sun ends here
+            bool alive = valid && !lit::may_occlude(a.F, R, R.t);
+            alive = sun_walk_column<false>(a, R, alive, ti, cands, lds, visits, tested);
+            if (sd == 0)
+                valid0 = valid, alive0 = alive, clo0 = R.c_lo;
+            else
+                valid1 = valid, alive1 = alive, clo1 = R.c_lo;
+        }
+        primary = (valid0 && valid1) ? (clo1 > clo0 ? 1 : 0) : (valid1 ? 1 : 0);
+        flags = (alive0 ? 1u : 0u) | (alive1 ? 2u : 0u);
+        if (mine) {
             float4 w6 = r6;
             w6.w = __uint_as_float(geom | (flags << kLitShift));
             a.shade[8 * (size_t)ti + 6] = w6;
-            listed = primary ? (valid1 && !alive1) : (valid0 && !alive0);
         }
-        uint32_t hint[kHints];
-#pragma unroll
-        for (int h = 0; h < kHints; ++h)
-            hint[h] = kNoHint;
-        if constexpr (PASS == 2) { // (a lit side needs no hints: every ray of it is answered by the lit bit)
-            if (ok) {
-                lit::Receiver R;
-                lit::make_receiver(a.F, v, gn, primary ? -1 : +1, R);
-                sun_walk_column<true>(a, R, R.valid, ti, cands, sun_queue + (threadIdx.x & 63u), visits, tested);
-                if (R.valid)
-                    cands.choose(hint);
-            }
-        }
+        listed = mine && (primary ? (valid1 && !alive1) : (valid0 && !alive0));
+    } else { // (a lit side needs no hints: every ray of it is answered by the lit bit)
+        lit::Receiver R;
+        lit::make_receiver(a.F, v, gn, primary ? -1 : +1, R);
+        const bool valid = ok && R.valid;
+        sun_walk_column<true>(a, R, valid, ti, cands, lds, visits, tested);
+        if (valid)
+            cands.choose(hint);
+    }
+    if (mine) {
         // r7 = {PrimitiveIndex, then kHints x 21-bit triangle indices and the side they are for: see pack_hints}
-        float4 w7 = rec[7];
+        float4 w7 = a.S.shade[8 * (size_t)ti + 7];
         pack_hints(hint, (uint32_t)primary, w7);
         a.shade[8 * (size_t)ti + 7] = w7;
         hinted = hint[0] != kNoHint;

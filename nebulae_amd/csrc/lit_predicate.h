@@ -197,8 +197,19 @@ NEB_LIT_HD void make_receiver(const Frame& F, const double v[3][3], const double
     R.valid = true;
 }
 
+// The parts of a Receiver may_occlude / cover_mask read, under the same names (both are templates over the receiver's type): the device build hands these
+// from lane to lane through LDS, so that any lane of a wave can test a candidate for any other (gi_sun_table.hip).
+struct OccludeView {
+    double h_min, c_lo, grad1, h0, ga, gb, bb_a[2], bb_b[2], en_a[3], en_b[3], en_c[3], en_off[3];
+};
+struct CoverView {
+    struct { double a[3], b[3]; } t;
+    double bb_a[2], bb_b[2], off_a[2], off_b[2], c_lo, c_hi, h0, ga, gb;
+};
+
 // Can a shadow ray from receiver R meet triangle O?  false = certainly not.
-NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
+template <class RV>
+NEB_LIT_HD bool may_occlude(const Frame& F, const RV& R, const Tri& O)
 {
     double hmax = O.h[0] > O.h[1] ? O.h[0] : O.h[1];
     hmax = O.h[2] > hmax ? O.h[2] : hmax;
@@ -271,12 +282,14 @@ NEB_LIT_HD bool may_occlude(const Frame& F, const Receiver& R, const Tri& O)
 // (gi_sun_table.hip): a hint is tried with the traverser's own triangle test, so a poor estimate costs speed, never correctness.
 constexpr int kCoverSamples = 28;
 // cover_mask counts a sample when O's height there exceeds the sample origin's by 1e-3: h_O - (h0 + ga a + gb b) > cover_floor(R) at the sample's (a, b)
-NEB_LIT_HD double cover_floor(const Receiver& R)
+template <class RV>
+NEB_LIT_HD double cover_floor(const RV& R)
 {
     const double ma = 0.5 * (R.off_a[0] + R.off_a[1]), mb = 0.5 * (R.off_b[0] + R.off_b[1]), mc = 0.5 * (R.c_lo + R.c_hi);
     return 1e-3 + mc - R.ga * ma - R.gb * mb;
 }
-NEB_LIT_HD unsigned cover_mask(const Receiver& R, const Tri& O)
+template <class RV>
+NEB_LIT_HD unsigned cover_mask(const RV& R, const Tri& O)
 {
     // quick reject on the lateral boxes
     double oa0 = O.a[0], oa1 = O.a[0], ob0 = O.b[0], ob1 = O.b[0];
