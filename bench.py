@@ -688,6 +688,8 @@ def main(argv=None, rt=None, emit=None):
     assert all(w.ran_svgf), "SVGF was skipped inside the timed region"
     if do_gi:  # (as of the ray count that ended the timed region: sides proven lit, shadow rays the table answered in those K frames)
         bvh["sun_table"] = r.sun_table_stats()
+        ms = r.sun_table_build_ms()
+        bvh["sun_table"]["build_ms"] = None if ms is None else round(ms, 2)
     # the settled rate: the same K steps, timed the same way, once the context has run SETTLE_FRAMES frames in all
     settle_run = max(Workload.SETTLE_FRAMES - warmup_run - args.steps, 0)
     dt_settled, _ = w.timed(args.steps, settle_run)

@@ -371,6 +371,9 @@ int neb_gi_traversal_stats(neb_ctx* ctx, uint64_t out[5]);
  * out = {triangle sides proven lit on the +normal side, on the -normal side (last build), shadow rays answered by the table as of
  * the last neb_gi_ray_count call (they are part of its count: a ray = a visibility query), table builds so far}. */
 int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream);
+/* Device time of the last build of the table (its two launches, between events on the stream it was enqueued on), in milliseconds.  Waits for that build.
+ * NEB_ERR_STATE when no table has been built. */
+int neb_gi_sun_table_build_ms(neb_ctx* ctx, float* ms);
 /* Diagnostics (collected while "gi_debug_hits" is 1, as of the last neb_gi_ray_count call): where the closest-hit pass's waves spend
  * their loop iterations -- {waves, loop iterations, iterations that ran a node phase, lanes live in those, iterations that ran a leaf
  * phase, lanes live in those}; a wave executes every phase some lane needs, so lanes / (64 x iterations) is the lane utilisation. */

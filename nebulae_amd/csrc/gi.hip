@@ -1397,6 +1397,19 @@ int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream)
     return NEB_OK;
 }
 
+int neb_gi_sun_table_build_ms(neb_ctx* ctx, float* ms)
+{
+    if (!ctx || !ctx->gi || !ms)
+        return NEB_ERR_INVALID_ARG;
+    GiState* g = ctx->gi;
+    if (!g->sun_table_builds || !g->sun_build_ev[1])
+        return gi_fail(ctx, NEB_ERR_STATE, "neb_gi_sun_table_build_ms: no table has been built");
+    GI_GUARD(ctx);
+    GI_HIP(ctx, hipEventSynchronize(g->sun_build_ev[1]));
+    GI_HIP(ctx, hipEventElapsedTime(ms, g->sun_build_ev[0], g->sun_build_ev[1]));
+    return NEB_OK;
+}
+
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream)
 {
     if (!ctx || !host)

@@ -51,6 +51,9 @@ void gi_destroy(GiState* g)
         (void)hipFree(p);
     if (g->sun_table_event)
         (void)hipEventDestroy(g->sun_table_event);
+    for (hipEvent_t& e : g->sun_build_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     delete g;
 }
 

@@ -203,6 +203,7 @@ struct GiState {
     // alternates streams) waits for this event first, or its shade pass could read the previous sun's lit bits of records the
     // 15-ms build has not reached yet.
     hipEvent_t sun_table_event = nullptr;   // recorded behind every launch that rewrites the flags
+    hipEvent_t sun_build_ev[2] = {nullptr, nullptr}; // around the last build's two launches (neb_gi_sun_table_build_ms)
     hipStream_t sun_table_stream = nullptr; // ... on this stream
     bool sun_table_event_pending = false;   // not yet seen complete
     hipStream_t last_dispatch_stream = nullptr; // stream of the last dispatch that read the flags (a rewrite on another stream waits for the device)

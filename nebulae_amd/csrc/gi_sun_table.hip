@@ -602,8 +602,16 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         g->sun_hint_list_cap = g->view.n_tris;
     }
     a.hint_list = g->d_sun_hint_list;
+    for (hipEvent_t& ev : g->sun_build_ev)
+        if (!ev)
+            if (hipError_t em = hipEventCreate(&ev); em != hipSuccess)
+                return em;
+    if (hipError_t em = hipEventRecord(g->sun_build_ev[0], stream); em != hipSuccess)
+        return em;
     hipLaunchKernelGGL(sun_table_kernel<1>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(sun_table_kernel<2>, dim3((g->view.n_tris + 63) / 64), dim3(64), 0, stream, a); // (waves past the list's end leave at once)
+    if (hipError_t em = hipEventRecord(g->sun_build_ev[1], stream); em != hipSuccess)
+        return em;
     if (hipError_t em = mark_rewrite(g, stream); em != hipSuccess)
         return em;
     memcpy(g->sun_table_key, key, sizeof(key));

@@ -236,6 +236,13 @@ class DeferredRenderer:
         self._check(self._lib.neb_gi_sun_table_stats(self._ctx, v, C.c_void_p(self.info.stream if self.info else 0)), "neb_gi_sun_table_stats")
         return dict(zip(("lit_plus", "lit_minus", "rays_answered", "builds"), [int(x) for x in v]))
 
+    def sun_table_build_ms(self):
+        """device time of the last build of the sun table, or None when none has been built"""
+        ms = C.c_float()
+        if self._lib.neb_gi_sun_table_build_ms(self._ctx, C.byref(ms)) != 0:
+            return None
+        return float(ms.value)
+
     def set_debug_hits(self, on=True):
         self.svgf.set_option("gi_debug_hits", int(on))
 

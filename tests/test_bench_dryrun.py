@@ -100,6 +100,9 @@ class DryRuntime:
             def sun_table_stats(self):
                 return {"lit_plus": 0, "lit_minus": 0, "rays_answered": 0, "builds": 0}
 
+            def sun_table_build_ms(self):
+                return None
+
             def _rows(self):
                 return self.svgf.row_begin, self.svgf.row_end
 

@@ -82,6 +82,7 @@ def test_table_on_and_off_give_the_same_bits(name, spp, vertices):
         _same(a, b)
     st, st_off = on.sun_table_stats(), off.sun_table_stats()
     assert st["builds"] == 1 and st_off["builds"] == 0 and st_off["rays_answered"] == 0
+    assert 0.0 < on.sun_table_build_ms() < 1e3 and off.sun_table_build_ms() is None  # (device time of the build; nothing to report without one)
     if name.startswith("atrium"):  # an open court under the sun: a good share of the queries is answered by the table
         vis = (a[1]["flags"] & 1).astype(bool) & (a[1]["t"] > 0)
         assert st["lit_plus"] > 0.01 * sc.num_triangles and st["rays_answered"] >= 0.5 * vis.sum() * (1 if spp * (vertices - 1) == 1 else 0), (st, int(vis.sum()))
