@@ -316,8 +316,16 @@ class StripRenderer(DeferredRenderer):
             return None
         comm = C.c_void_p()
         rc = lib.neb_strips_comm_create(self._device, self.part.N, self.rank, raw[:128], C.byref(comm))
-        if rc != 0:
-            raise NebError(f"neb_strips_comm_create failed ({rc}): {lib.neb_strips_last_error().decode()}")
+        # every rank learns whether EVERY rank has its communicator: one that failed must not leave the others waiting in an exchange
+        flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+        flag = flag.cuda() if on_cuda else flag
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.cpu()[0]) == 0:
+            if rc == 0:
+                lib.neb_strips_comm_destroy(comm)
+            if required:
+                raise NebError(f"neb_strips_comm_create failed on {'this rank' if rc != 0 else 'another rank'} ({rc}): {lib.neb_strips_last_error().decode()}")
+            return None
         return comm
 
     # ---- the one-call strip frame of the C ABI (neb_strip_frame*, strips.hip): the partition arithmetic and the enqueue order below, in C ----
