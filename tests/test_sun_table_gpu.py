@@ -325,3 +325,36 @@ def test_a_new_sun_with_two_dispatches_in_flight_on_two_streams():
         r.destroy()
     assert float(np.abs(outs[0][..., :3]).max()) > 0.2
     assert np.array_equal(outs[0], outs[1])
+
+
+def _tiny_scene(kind):
+    """scenes whose tree is a single leaf or a root over two leaves: the build's walk starts (and ends) at a leaf code"""
+    sc = S.Scene("tiny-" + kind)
+    m = sc.add_material(albedo=(0.7, 0.6, 0.5, 1), rm=(0.8, 0.0))
+    floor = S._quad((-2, -1, 1), (2, -1, 1), (2, -1, -3), (-2, -1, -3))  # faces +y, under the default sun (.5, -1, -.2)
+    if kind == "one_triangle":
+        P, N, UV, I = floor
+        sc.add_geometry(P[:3].copy(), N[:3].copy(), UV[:3].copy(), np.array([0, 1, 2], np.uint32), material=m)
+    elif kind == "quad":
+        sc.add_geometry(*floor, material=m)
+    else:  # a floor with a small roof over a part of it: lit and shadowed receivers, occluder hints
+        sc.add_geometry(*S._merge([floor, S._quad((-0.5, 0.2, -0.5), (-0.5, 0.2, -1.5), (0.5, 0.2, -1.5), (0.5, 0.2, -0.5))]), material=m)
+    return sc
+
+
+@pytest.mark.parametrize("kind", ["one_triangle", "quad", "roofed"])
+def test_trees_of_one_or_two_leaves(kind):
+    sc, cam, W, H = _tiny_scene(kind), S.orbit_camera(yaw_deg=15.0, pitch_deg=70.0, distance=3.0), 160, 120
+    on, off = _pair(W, H)
+    for f in (3, 4):
+        a = _frame(on, sc, cam, W, H, f, 2, 3)
+        if f == 3:
+            off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f))
+            off.svgf.set_option("gi_sun_table", 0)
+        b = _frame(off, sc, cam, W, H, f, 2, 3)
+        _same(a, b)
+    st = on.sun_table_stats()
+    assert st["builds"] == 1 and st["lit_plus"] + st["lit_minus"] >= 1, st  # (the open floor is proven lit on its upper side)
+    print(f"[tiny {kind}] {sc.num_triangles} triangles, {on.scene_info()[1]} nodes: {st}")
+    on.destroy()
+    off.destroy()
