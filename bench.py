@@ -362,7 +362,9 @@ class GpuRuntime:
         return stream.cuda_stream
 
     def new_stream(self):
-        return self.torch.cuda.Stream()
+        # (experiment: NEB_BENCH_SIDE_PRIORITY = the HIP priority of the side stream(s) that carry the next frame's closest-hit walk: lower = more urgent)
+        prio = os.environ.get("NEB_BENCH_SIDE_PRIORITY")
+        return self.torch.cuda.Stream(priority=int(prio)) if prio is not None else self.torch.cuda.Stream()
 
     def synchronize(self):
         self.torch.cuda.synchronize()
@@ -405,6 +407,9 @@ class Workload:
         self.own = self.part.owned(rank)
         self.res = self.part.resident(rank)
         self.stream = rt.current_stream()
+        if os.environ.get("NEB_BENCH_MAIN_PRIORITY") is not None and hasattr(rt, "torch"):  # (experiment: the frame's own stream with a HIP priority)
+            self.stream = rt.torch.cuda.Stream(priority=int(os.environ["NEB_BENCH_MAIN_PRIORITY"]))
+            rt.torch.cuda.set_stream(self.stream)
         self.sh = rt.stream_handle(self.stream)
         r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1, stream=self.sh))
         r.submit_commands_gbuffer()          # G-buffer of this rank's resident rows, slot "current" of frame 1
