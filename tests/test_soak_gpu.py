@@ -96,3 +96,49 @@ def test_three_hundred_frames_of_moving_and_resting_stay_finite_allocate_nothing
     again, ran2, st2, _ = _long_run(W, H, sc, cam0)
     assert ran2 == ran and st2["builds"] == st["builds"] and st2["lit_plus"] == st["lit_plus"] and st2["lit_minus"] == st["lit_minus"]
     assert np.array_equal(final, again), float(np.abs(final - again).max())
+
+
+def test_two_host_threads_each_with_its_own_context():
+    """A context is not thread-safe (include/nebulae_hip.h) -- but two contexts are two contexts: a host may drive each from its own thread, at the same
+    time, on one device.  Same bits as one after the other."""
+    import threading
+
+    cases = [scenes()["atrium_small"], scenes()["cornell"]]
+    made = [(make(), cam, W, H) for make, cam, W, H in cases]
+
+    def run(k, out, errors, stream=None):
+        try:
+            sc, cam, W, H = made[k]
+            r = DeferredRenderer()
+            r.init(W, H, atrous_levels=4)
+            for f in range(1, 41):
+                r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f, stream=stream.cuda_stream if stream else 0))
+                r.submit_commands_gbuffer()
+                r.submit_commands_pbr_lighting()
+                r.submit_commands_gi_pathtrace()
+                r.submit_commands_svgf_denoising()
+                r.end_frame()
+                if f == 20:  # (a new sun half way: each context rebuilds its own table)
+                    r.sun.direction = (-0.3, -1.0, 0.4)
+            if stream:
+                stream.synchronize()
+            out[k] = (r.svgf.download(PLANE_RADIANCE), r.sun_table_stats())
+            r.destroy()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    serial, errors = {}, []
+    for k in range(2):
+        run(k, serial, errors)
+    assert not errors, errors
+    both = {}
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    threads = [threading.Thread(target=run, args=(k, both, errors, streams[k])) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert both[k][1] == serial[k][1], (both[k][1], serial[k][1])
+        assert np.array_equal(both[k][0], serial[k][0]), (k, float(np.abs(both[k][0] - serial[k][0]).max()))
