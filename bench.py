@@ -450,6 +450,8 @@ class Workload:
             self.mode = (forced if forced != "split" or splittable else None) or ("defer" if (world > 1 and own_px <= 300_000) or not splittable else "split")
             if self.mode == "defer" and not forced and args.overlap == "auto" and not (world > 1 and own_px <= 300_000):
                 self.mode = None  # (several samples per pixel on a big strip: nothing to gain)
+            if self.mode == "split" and not forced and args.overlap == "auto" and own_px > 6_000_000:
+                self.mode = None  # (measured, tools/size_sweep.sh: 2560x1440 gains 1.3 %, 3840x2160 LOSES 2.5 % -- its launches fill the chip for long enough as they are)
         self.overlap = self.mode is not None
         self.depth = 2 if self.mode == "defer" else 0
         self.sides = [rt.new_stream() for _ in range(2 if self.mode == "defer" else 1 if self.mode == "split" else 0)]
