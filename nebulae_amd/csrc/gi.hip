@@ -158,18 +158,12 @@ __device__ __forceinline__ void count_rays(uint32_t* block_counts, uint32_t mine
 #define NEB_RG_STACK 12
 #endif
 constexpr int kRgStack = NEB_RG_STACK;
-static_assert(32 * (kRgStack * 256 + 1024 + NEB_RG_DEFER_Q * 256) <= 160 * 1024 || NEB_TRACE_WAVES < 8, "LDS budget of the closest-hit pass: 32 waves per CU of stacks and child slots in 160 KB");
+static_assert(32 * (kRgStack * 256 + 1024) <= 160 * 1024 || NEB_TRACE_WAVES < 8, "LDS budget of the closest-hit pass: 32 waves per CU of stacks and child slots in 160 KB");
 template <bool FAST, bool FAST_TRIG>
 __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(GiArgs a)
 {
     __shared__ int stack_mem[kRgStack * 64];
     __shared__ int child_slot_mem[256];
-#if NEB_RG_DEFER_Q
-    __shared__ int pend_mem[NEB_RG_DEFER_Q * 64];
-    int* const pend_lane = pend_mem + threadIdx.x;
-#else
-    int* const pend_lane = nullptr;
-#endif
     uint32_t x, y;
     size_t i64;
     bool active;
@@ -226,8 +220,8 @@ __global__ __launch_bounds__(64, NEB_TRACE_WAVES) void gi_raygen_trace_kernel(Gi
         }
         if (bounce && !a.raygen_only && a.S.n_tris) {
             Hit hit;
-            const bool found = a.stats ? traverse_t<false, true, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane, pend_lane)
-                                       : traverse_t<false, false, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane, pend_lane);
+            const bool found = a.stats ? traverse_t<false, true, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane)
+                                       : traverse_t<false, false, kRgStack, true>(a.S, org, dir, 0.01f, kTraceMax, stack_mem + lane, hit, stack_mem, child_slot_mem + 4u * lane);
             if (found)
                 h = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
             if (a.stats) { // diagnostics only

@@ -391,23 +391,15 @@ constexpr int kTravDone = (int)0x80000000;
 // Measured and moved out of the product (git tag r05-traversal-arms holds them all, docs/NOTEBOOK.md 10.1 their numbers): the 128-byte
 // exact-plane walk and tail suspension (round 2); "pop-ahead" (the next node requested before the leaf's triangle tests: one memory wait
 // per iteration), the top of the tree in LDS, branch-free pushes, the four child codes read up front, multi-wave workgroups (round 5).
-#ifndef NEB_RG_DEFER_Q
-#define NEB_RG_DEFER_Q 0 // tuning arm (closest-hit walks through traverse_t<.., FAST>): leaves a lane may hold untested while it walks on (a power of two; 0 = off)
-#endif
-#ifndef NEB_RG_DEFER_T
-#define NEB_RG_DEFER_T 16 // ... and the lanes with a pending leaf that make the wave run a leaf phase
-#endif
-template <bool ANY_HIT, bool STATS, bool LDS_SELECT, class Stack, int DEFER_Q = 0>
+template <bool ANY_HIT, bool STATS, bool LDS_SELECT, class Stack>
 __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, float3 d, float tmin, Stack& st, int& node, Hit& hit, bool& found,
-                                              LdsInt* child_slots = nullptr, LdsInt* pend = nullptr)
+                                              LdsInt* child_slots = nullptr)
 {
-    static_assert(DEFER_Q == 0 || (!ANY_HIT && (DEFER_Q & (DEFER_Q - 1)) == 0), "deferred leaves: closest-hit walks, a power-of-two queue");
-    uint32_t pn = 0, ph = 0; // DEFER_Q: leaves held untested (entry k of this lane's ring at pend[64 * k]), the oldest at ph
     const float3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const float3 oinv = f3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
     const bool negx = d.x < 0.0f, negy = d.y < 0.0f, negz = d.z < 0.0f;
     constexpr uint32_t kMiss = 0xffffffffu;
-    while (node != kTravDone || (DEFER_Q && pn != 0u)) {
+    while (node != kTravDone) {
         if (STATS) {
             const uint32_t nn = (uint32_t)__popcll(__ballot(node >= 0));
             hit.w_iters++;
@@ -496,37 +488,17 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
         // Any-hit rays batch their leaf steps: a lane that holds a leaf waits until kLeafBatch lanes of the wave do (or
         // none has a node left), so the triangle code runs with fuller waves (shadow pass 213 -> 206 us; the closest-hit
         // pass, whose lanes need the shrunk hit.t at once, measured no gain at 4 / 12 and lost at 24).
-        if constexpr (DEFER_Q != 0) {
-            // Deferred leaves (tuning arm): a lane that lands on a leaf QUEUES it and walks on with its next node -- without the nearer hit the leaf
-            // may hold -- and the wave runs a leaf phase (every lane with a queued leaf tests its oldest) only when NEB_RG_DEFER_T lanes have one,
-            // a lane's queue is full, or no lane has a node left.  Leaves are tested in the order they were met: the same hit, ties included.
-            while (node < 0 && node != kTravDone && pn < (uint32_t)DEFER_Q) {
-                pend[64u * ((ph + pn) & (uint32_t)(DEFER_Q - 1))] = node;
-                ++pn;
-                node = st.empty() ? kTravDone : st.pop();
-            }
-        }
-        bool holds_leaf = node < 0 && node != kTravDone;
+        const bool holds_leaf = node < 0 && node != kTravDone;
         bool run_leaves = true;
         if (ANY_HIT && kLeafBatch > 1)
             run_leaves = __popcll(__ballot(holds_leaf)) >= kLeafBatch || __ballot(node >= 0) == 0ull;
-        int leaf_code = node;
-        if constexpr (DEFER_Q != 0) {
-            run_leaves = __ballot(holds_leaf) != 0ull || __popcll(__ballot(pn != 0u)) >= NEB_RG_DEFER_T || __ballot(node >= 0) == 0ull;
-            holds_leaf = pn != 0u;
-            if (holds_leaf && run_leaves) {
-                leaf_code = pend[64u * ph];
-                ph = (ph + 1u) & (uint32_t)(DEFER_Q - 1);
-                --pn;
-            }
-        }
         if (STATS) {
             const uint32_t nl = (uint32_t)__popcll(__ballot(holds_leaf && run_leaves));
             hit.w_leaf_iters += nl ? 1u : 0u;
             hit.w_leaf_lanes += nl;
         }
         if (holds_leaf && run_leaves) {
-            const uint32_t code = (uint32_t)~leaf_code;
+            const uint32_t code = (uint32_t)~node;
             const uint32_t first = code >> 2, count = (code & 3u) + 1u;
             if (STATS)
                 hit.tri_tests += count;
@@ -567,8 +539,7 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
                 node = kTravDone;
                 return;
             }
-            if constexpr (DEFER_Q == 0)
-                node = st.empty() ? kTravDone : st.pop();
+            node = st.empty() ? kTravDone : st.pop();
         }
     }
     if constexpr (!ANY_HIT)
@@ -580,7 +551,7 @@ __device__ __forceinline__ void traverse_core(const SceneView& S, float3 o, floa
 // per lane, see traverse_core).
 template <bool ANY_HIT, bool STATS, int N = kLdsStack, bool FAST = false>
 __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, float tmax, int* lds_stack, Hit& hit, int* lds_array = nullptr,
-                           int* child_slots = nullptr, int* pend = nullptr)
+                           int* child_slots = nullptr)
 {
     hit.t = tmax;
     hit.tri = ~0u;
@@ -599,10 +570,7 @@ __device__ bool traverse_t(const SceneView& S, float3 o, float3 d, float tmin, f
     int node = walkable ? S.root : kTravDone;
     if constexpr (FAST) {
         TravStackA<N> st((LdsInt*)lds_stack, (LdsInt*)lds_array, spill_mem);
-        if constexpr (!ANY_HIT && NEB_RG_DEFER_Q != 0)
-            traverse_core<ANY_HIT, STATS, true, TravStackA<N>, NEB_RG_DEFER_Q>(S, o, d, tmin, st, node, hit, found, (LdsInt*)child_slots, (LdsInt*)pend);
-        else
-            traverse_core<ANY_HIT, STATS, !ANY_HIT>(S, o, d, tmin, st, node, hit, found, (LdsInt*)child_slots);
+        traverse_core<ANY_HIT, STATS, !ANY_HIT>(S, o, d, tmin, st, node, hit, found, (LdsInt*)child_slots);
     } else {
         TravStackT<N> st{(LdsInt*)lds_stack, spill_mem, 0};
         traverse_core<ANY_HIT, STATS, false>(S, o, d, tmin, st, node, hit, found);
