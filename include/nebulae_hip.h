@@ -13,7 +13,8 @@
  * NEB_OK (0) or a negative neb_status, never throws; neb_last_error() gives
  * the message for the last failure on that context (the reference throws
  * HrException / asserts instead, src/nri/stdafx.h:31-98).  A context is not
- * thread-safe: the caller serialises, as the reference's single render thread does.
+ * thread-safe: the caller serialises, as the reference's single render thread does;
+ * different contexts may be driven from different threads at the same time (tests/test_soak_gpu.py).
  */
 #ifndef NEBULAE_HIP_H
 #define NEBULAE_HIP_H

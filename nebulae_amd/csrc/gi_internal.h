@@ -99,32 +99,35 @@ constexpr int kMaxLeafTris = NEB_MAX_LEAF_TRIS;
 // The geometry word of a triangle's shading record (r6.w) carries the sun-visibility table in its two top bits
 // (gi_sun_table.hip): bit kLitShift = every shadow ray leaving the triangle on its +GN side is unoccluded, bit kLitShift + 1 = -GN side.
 constexpr uint32_t kLitShift = 30u, kGeomMask = (1u << kLitShift) - 1u;
-// ... and r7.yzw = occluder hints: the (up to) kHints triangles most likely to shadow rays that start on this one, as 21-bit
-// indices (a triangle whose index does not fit is simply not hinted at) + the side (0: +GN, 1: -GN) they were chosen for
+// ... and r7.yzw = occluder hints: the (up to) kHints triangles most likely to shadow rays that start on this one, as 23-bit
+// indices (scenes of up to 8.4 M triangles; a triangle whose index does not fit is simply no candidate: gi_sun_table.hip) + the side
+// (0: +GN, 1: -GN) they were chosen for.  Bits 0-22 hint 0, 23-45 hint 1, 46-68 hint 2, 69-91 hint 3, bit 95 the side.
+// (Round 4 had 21 bits: in leaf order the top of a scene -- what shadows a sun ray -- sorts LAST, so at 2.6 M triangles nearly every
+// occluder was out of range and the hints answered nothing.)
 constexpr int kHints = 4;
-constexpr uint32_t kNoHint = 0x1fffffu;
+constexpr uint32_t kNoHint = 0x7fffffu;
 __host__ __device__ inline void pack_hints(const uint32_t hint[kHints], uint32_t side, float4& r7)
 {
     uint32_t h[kHints];
     for (int k = 0; k < kHints; ++k)
         h[k] = hint[k] < kNoHint ? hint[k] : kNoHint;
-    const unsigned long long lo = (unsigned long long)h[0] | ((unsigned long long)h[1] << 21) | ((unsigned long long)h[2] << 42);
+    const unsigned long long lo = (unsigned long long)h[0] | ((unsigned long long)h[1] << 23) | ((unsigned long long)(h[2] & 0x3ffffu) << 46);
     union { uint32_t u; float f; } y, z, w;
     y.u = (uint32_t)lo;
-    z.u = (uint32_t)(lo >> 32) | (side << 31);
-    w.u = h[3];
+    z.u = (uint32_t)(lo >> 32);
+    w.u = (h[2] >> 18) | (h[3] << 5) | (side << 31);
     r7.y = y.f, r7.z = z.f, r7.w = w.f;
 }
 __host__ __device__ inline void unpack_hints(const float4& r7, uint32_t hint[kHints], uint32_t& side)
 {
     union { float f; uint32_t u; } y, z, w;
     y.f = r7.y, z.f = r7.z, w.f = r7.w;
-    const unsigned long long lo = (unsigned long long)y.u | ((unsigned long long)(z.u & 0x7fffffffu) << 32);
+    const unsigned long long lo = (unsigned long long)y.u | ((unsigned long long)z.u << 32);
     hint[0] = (uint32_t)lo & kNoHint;
-    hint[1] = (uint32_t)(lo >> 21) & kNoHint;
-    hint[2] = (uint32_t)(lo >> 42) & kNoHint;
-    hint[3] = w.u & kNoHint;
-    side = z.u >> 31;
+    hint[1] = (uint32_t)(lo >> 23) & kNoHint;
+    hint[2] = ((uint32_t)(lo >> 46) | (w.u << 18)) & kNoHint;
+    hint[3] = (w.u >> 5) & kNoHint;
+    side = w.u >> 31;
 }
 
 struct SceneView {

@@ -80,7 +80,7 @@ struct SunCands {
     }
     __device__ void insert(uint32_t tj, uint32_t m)
     {
-        int pc = __popc(m);
+        int pc = tj < kNoHint ? __popc(m) : 0; // (a triangle whose index does not fit a hint's 23 bits is no candidate: it would end the list of hints where it stands)
         seen += pc ? 1u : 0u;
 #pragma unroll
         for (int k = 0; k < kCand; ++k) { // (behind the entries that cover as many: first found stays first)
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64, PASS == 1 ? NEB_SUN_WAVES : 2) void sun_table_k
             cands.choose(hint);
     }
     if (mine) {
-        // r7 = {PrimitiveIndex, then kHints x 21-bit triangle indices and the side they are for: see pack_hints}
+        // r7 = {PrimitiveIndex, then kHints x 23-bit triangle indices and the side they are for: see pack_hints}
         float4 w7 = a.S.shade[8 * (size_t)ti + 7];
         pack_hints(hint, (uint32_t)primary, w7);
         a.shade[8 * (size_t)ti + 7] = w7;

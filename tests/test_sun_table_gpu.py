@@ -358,3 +358,23 @@ def test_trees_of_one_or_two_leaves(kind):
     print(f"[tiny {kind}] {sc.num_triangles} triangles, {on.scene_info()[1]} nodes: {st}")
     on.destroy()
     off.destroy()
+
+
+def test_hints_reach_occluders_in_a_scene_of_2_6_million_triangles():
+    """A hint is a 23-bit triangle index.  In leaf order the TOP of a scene -- what shadows a sun ray -- sorts last: with round 4's 21 bits nearly every
+    occluder of a 2.6 M-triangle scene was out of range and the hints answered nothing (0.59 M of 4.0 M queries, the lit bits alone, against 1.75 M)."""
+    W, H = 640, 360
+    sc, cam = S.atrium_standin(target_triangles=2_600_000, tex_size=64), S.sponza_camera()
+    assert sc.num_triangles > (1 << 21)
+    on, off = _pair(W, H)
+    a = _frame(on, sc, cam, W, H, 3)
+    off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=3))
+    off.svgf.set_option("gi_sun_table", 0)
+    b = _frame(off, sc, cam, W, H, 3)
+    _same(a, b)
+    st = on.sun_table_stats()
+    shadow_queries = a[2] - W * H  # (a ray = a query: one bounce ray per pixel + one sun-visibility query per hit)
+    print(f"[2.6 M triangles] {st}; {st['rays_answered']} of {shadow_queries} sun-visibility queries answered by the table")
+    assert st["rays_answered"] > 0.7 * shadow_queries, (st, shadow_queries)
+    on.destroy()
+    off.destroy()
