@@ -123,9 +123,10 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *                       the 1-ulp hardware forms an HLSL compiler emits (default).  The two differ by ~1e-7 relative, except where the
  *                       BRDF itself is ill-conditioned (mirror-like roughness: the GGX denominator cancels), where it can be percents;
  *   "gi_sun_table":     1 (default) / 0: answer the sun-visibility query of a hit from the per-triangle table where it is proven
- *                       (neb_gi_sun_table_stats) instead of tracing the shadow ray, and trace the rest from compacted ray lists;
- *                       2 = the table answers but the remaining rays keep the sorted / tiled pass (A/B arm); results are bit-identical
- *                       in all three;
+ *                       (neb_gi_sun_table_stats) instead of tracing the shadow ray, and trace the rest -- from compacted ray lists or
+ *                       through the sorted pass, whichever two timed dispatches after each table build say is faster
+ *                       (neb_gi_shadow_tail_mode); 3 = always the lists, 2 = always the sorted / tiled pass; results are bit-identical
+ *                       in all of them.  No table is built for a sun disk wider than 3.4 degrees (sunTanHalfAngle > 0.03);
  *   "gi_sun_hints":     4 (default), 2 or 0: how many of a triangle's occluder hints the shade pass tries (with the traverser's own
  *                       triangle test) before it leaves the shadow ray to the list pass; results are bit-identical in all three;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);
@@ -375,6 +376,10 @@ int neb_gi_sun_table_stats(neb_ctx* ctx, uint64_t out[4], neb_stream stream);
 /* Device time of the last build of the table (its two launches, between events on the stream it was enqueued on), in milliseconds.  Waits for that build.
  * NEB_ERR_STATE when no table has been built. */
 int neb_gi_sun_table_build_ms(neb_ctx* ctx, float* ms);
+/* Which pass takes the shadow rays the sun table leaves ("gi_sun_table" = 1): *mode = 0 the compacted lists, 1 the sorted pass, -1 not decided yet
+ * for the current table (the first two dispatches after a build are the timed ones); us (may be NULL) = the two times of the last measurement
+ * {lists, sorted pass}, shade + shadow launches between events, in microseconds.  Does not synchronise. */
+int neb_gi_shadow_tail_mode(neb_ctx* ctx, int* mode, float us[2]);
 /* Diagnostics (collected while "gi_debug_hits" is 1, as of the last neb_gi_ray_count call): where the closest-hit pass's waves spend
  * their loop iterations -- {waves, loop iterations, iterations that ran a node phase, lanes live in those, iterations that ran a leaf
  * phase, lanes live in those}; a wave executes every phase some lane needs, so lanes / (64 x iterations) is the lane utilisation. */

@@ -113,6 +113,7 @@ def _gi_sigs():
         "neb_gi_debug_set_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
         "neb_gi_debug_sun_walk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
         "neb_gi_sun_table_build_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+        "neb_gi_shadow_tail_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
         "neb_gi_sun_table_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
         "neb_gi_download_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
         "neb_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),

@@ -312,7 +312,7 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
     }
     if (!strcmp(key, "gi_sun_table")) {
         if (gi_set_sun_table(ctx, value) != NEB_OK)
-            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_table needs a scene (neb_gi_set_scene) and 0, 1 or 2");
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_table needs a scene (neb_gi_set_scene) and 0 .. 3");
         return NEB_OK;
     }
     if (!strcmp(key, "gi_sun_hints")) {

@@ -1036,7 +1036,26 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
     }
     a.sun_table = g->sun_table_state == 1 ? 1u : 0u;
     a.hint_pairs = (uint32_t)g->sun_hints / 2u;
-    const bool compact = a.sun_table && g->compact_shadow;
+    // the pass that takes the rays the table leaves: the compacted lists, unless the measurement of this table said the sorted pass (GiState::tail_tune)
+    int tail_slot = -1; // 0 / 2: this dispatch is one of the two timed ones (events tail_ev[slot], [slot + 1] around its shade + shadow launches)
+    if (a.sun_table && g->compact_shadow && g->tail_tune && phase != 1) {
+        if (g->tail_phase == 3 && hipEventQuery(g->tail_ev[1]) == hipSuccess && hipEventQuery(g->tail_ev[3]) == hipSuccess) {
+            float ms_lists = 0.f, ms_sorted = 0.f;
+            if (hipEventElapsedTime(&ms_lists, g->tail_ev[0], g->tail_ev[1]) == hipSuccess && hipEventElapsedTime(&ms_sorted, g->tail_ev[2], g->tail_ev[3]) == hipSuccess) {
+                g->tail_us[0] = ms_lists * 1e3f, g->tail_us[1] = ms_sorted * 1e3f;
+                g->tail_sorted = ms_sorted < 0.95f * ms_lists; // (the lists stay unless the sorted pass is clearly faster)
+            }
+            g->tail_phase = 0;
+        } else if (g->tail_phase == 1 || g->tail_phase == 2) {
+            tail_slot = g->tail_phase == 1 ? 0 : 2;
+            for (int k = 0; k < 2; ++k)
+                if (!g->tail_ev[tail_slot + k])
+                    GI_HIP(ctx, hipEventCreate(&g->tail_ev[tail_slot + k]));
+            g->tail_phase++;
+        }
+        (void)hipGetLastError(); // (hipErrorNotReady from a query is an answer, not a failure)
+    }
+    const bool compact = a.sun_table && g->compact_shadow && (tail_slot >= 0 ? tail_slot == 0 : !g->tail_sorted);
     const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
     if (sort_shadow || g->sort_bounce) {
         if (!ds.d_sort) {
@@ -1124,6 +1143,8 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
                 hipLaunchKernelGGL(gi_bounce_trace_kernel, grid, block, 0, (hipStream_t)stream, a);
             }
             a.list_set = ds.list_epoch & 1u;
+            if (tail_slot >= 0 && s == 0 && b == 1)
+                GI_HIP(ctx, hipEventRecord(g->tail_ev[tail_slot], (hipStream_t)stream));
             if (kFastShade && !g->exact_shade)
                 hipLaunchKernelGGL(gi_shade_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
             else
@@ -1150,6 +1171,8 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
             }
         }
     }
+    if (tail_slot >= 0)
+        GI_HIP(ctx, hipEventRecord(g->tail_ev[tail_slot + 1], (hipStream_t)stream));
     GI_HIP(ctx, hipGetLastError());
     if (phase == 1) {
         ds.split_c = *c;
@@ -1410,6 +1433,17 @@ int neb_gi_sun_table_build_ms(neb_ctx* ctx, float* ms)
     return NEB_OK;
 }
 
+int neb_gi_shadow_tail_mode(neb_ctx* ctx, int* mode, float us[2])
+{
+    if (!ctx || !ctx->gi || !mode)
+        return NEB_ERR_INVALID_ARG;
+    const GiState* g = ctx->gi;
+    *mode = g->tail_phase != 0 ? -1 : (g->tail_sorted ? 1 : 0);
+    if (us)
+        us[0] = g->tail_us[0], us[1] = g->tail_us[1];
+    return NEB_OK;
+}
+
 int neb_gi_download_hits(neb_ctx* ctx, neb_gi_hit* host, neb_stream stream)
 {
     if (!ctx || !host)
@@ -1514,10 +1548,14 @@ int gi_set_defer_resolve(neb_ctx* ctx, int on)
 }
 int gi_set_sun_table(neb_ctx* ctx, int on)
 {
-    if (!ctx->gi || on < 0 || on > 2)
+    if (!ctx->gi || on < 0 || on > 3)
         return NEB_ERR_STATE;
-    ctx->gi->sun_table = on != 0;
-    ctx->gi->compact_shadow = on != 2; // 2 (A/B arm): the table answers, but the remaining rays keep the sorted / tiled shadow pass
+    GiState* g = ctx->gi;
+    g->sun_table = on != 0;
+    g->compact_shadow = on != 2; // 2: the table answers, but the remaining rays always keep the sorted / tiled shadow pass
+    g->tail_tune = on == 1;      // 1: lists or sorted pass, whichever the measurement of this table says; 3: always the lists
+    g->tail_sorted = false;
+    g->tail_phase = (g->tail_tune && g->sun_table_state == 1) ? 1 : 0;
     return NEB_OK;
 }
 int gi_set_sun_hints(neb_ctx* ctx, int n)

@@ -54,6 +54,9 @@ void gi_destroy(GiState* g)
     for (hipEvent_t& e : g->sun_build_ev)
         if (e)
             (void)hipEventDestroy(e);
+    for (hipEvent_t& e : g->tail_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     delete g;
 }
 

@@ -214,6 +214,15 @@ struct GiState {
     unsigned long long table_rays = 0; // shadow rays answered by the table as of the last neb_gi_ray_count
     int sun_hints = 4;                // option "gi_sun_hints": occluder hints the shade pass tries per hit (0, 2 or 4)
     bool compact_shadow = true;       // with the table on: the rays it leaves are compacted into lists by the shade pass ("gi_sun_table" = 2: off)
+    // Which pass takes the rays the table leaves is MEASURED once per table build ("gi_sun_table" = 1, the default): the first dispatch with a new table
+    // runs the compacted lists between two events, the second the sorted pass (same bits), a later one reads both times and keeps the faster -- the lists
+    // win for most suns (0.51 against 0.58 ms of GI on the bench frame), the sorted pass where the table leaves many long rays (a sun straight overhead:
+    // 0.79 against 0.92).  3 = always lists, 2 = always the sorted pass.
+    bool tail_tune = true;
+    int tail_phase = 0;               // 0 decided / nothing to decide, 1 time the lists next, 2 time the sorted pass next, 3 both enqueued: waiting for their events
+    bool tail_sorted = false;         // the decision for this table
+    hipEvent_t tail_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float tail_us[2] = {0.f, 0.f};    // the two times of the last measurement {lists, sorted pass}
 };
 hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_t stream);
 hipError_t gi_sun_table_order(GiState* g, hipStream_t stream);

@@ -243,6 +243,12 @@ class DeferredRenderer:
             return None
         return float(ms.value)
 
+    def shadow_tail_mode(self):
+        """-> (mode, (us_lists, us_sorted)): 0 the compacted lists take the rays the sun table leaves, 1 the sorted pass, -1 not decided yet for this table"""
+        mode, us = C.c_int(), (C.c_float * 2)()
+        self._check(self._lib.neb_gi_shadow_tail_mode(self._ctx, C.byref(mode), us), "neb_gi_shadow_tail_mode")
+        return int(mode.value), (float(us[0]), float(us[1]))
+
     def set_debug_hits(self, on=True):
         self.svgf.set_option("gi_debug_hits", int(on))
 

@@ -378,3 +378,41 @@ def test_hints_reach_occluders_in_a_scene_of_2_6_million_triangles():
     assert st["rays_answered"] > 0.7 * shadow_queries, (st, shadow_queries)
     on.destroy()
     off.destroy()
+
+
+def test_no_table_for_a_wide_sun_disk_and_the_tail_is_chosen_by_measurement():
+    """A disk of 10 degrees gets no table (its columns widen with the disk: 8 ms of build and no gain at 5 degrees on the bench scene, 70 ms at 30) -- every ray
+    is traced, same bits.  Back under the reference's 0.58-degree sun the table is built, and which pass takes the rays it leaves -- the compacted lists or the
+    sorted pass -- is decided from two timed dispatches: undecided for the first two frames of a new table, decided afterwards, the same bits throughout."""
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    on, off = _pair(W, H)
+    off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    off.svgf.set_option("gi_sun_table", 0)
+    for r in (on, off):
+        r.sun.rough_diameter = 10.0
+    for f in (2, 3, 4):
+        _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+    st = on.sun_table_stats()
+    assert st["builds"] == 0 and st["rays_answered"] == 0 and on.sun_table_build_ms() is None, st
+    for r in (on, off):
+        r.sun.rough_diameter = 0.58
+    modes = []
+    for f in range(5, 12):
+        _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+        torch.cuda.synchronize()
+        modes.append(on.shadow_tail_mode())
+    st = on.sun_table_stats()
+    assert st["builds"] == 1 and st["rays_answered"] > 0, st
+    # frame 5: built at once (there was no table to keep meanwhile), the lists timed; 6: the sorted pass timed; 7: both times read
+    assert [m for m, _ in modes[:2]] == [-1, -1] and all(m in (0, 1) for m, _ in modes[2:]), modes
+    lists_us, sorted_us = modes[-1][1]
+    assert lists_us > 0.0 and sorted_us > 0.0 and (modes[-1][0] == 1) == (sorted_us < 0.95 * lists_us), modes[-1]
+    print(f"[tail] lists {lists_us:.0f} us, sorted pass {sorted_us:.0f} us -> {'sorted pass' if modes[-1][0] else 'lists'}")
+    # the forced forms give the same bits
+    for mode in (3, 2, 1):
+        on.svgf.set_option("gi_sun_table", mode)
+        for f in (12, 13):
+            _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+    on.destroy()
+    off.destroy()

@@ -1,0 +1,49 @@
+"""The sun table under other suns: build time, sides proven lit, share of the sun-visibility queries it answers, GI dispatch time with and without it -- and the
+same bits either way.  Low suns make long columns (a ray can drift far before it leaves the scene), wide disks wide ones.   python tools/sun_sweep.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from nebulae_amd import scene as S  # noqa: E402
+from nebulae_amd.renderer import DeferredRenderer, RenderInfo  # noqa: E402
+from nebulae_amd.svgf import PLANE_RADIANCE, SLOT_CURRENT  # noqa: E402
+
+W, H = 1920, 1080
+sc, cam = S.atrium_standin(), S.sponza_camera()
+suns = [((0.5, -1.0, -0.2), 0.58), ((0.0, -1.0, 0.0), 0.58), ((1.0, -0.3, 0.2), 0.58), ((1.0, -0.1, 0.0), 0.58), ((1.0, -0.02, 0.3), 0.58), ((0.5, -1.0, -0.2), 5.0),
+        ((0.5, -1.0, -0.2), 30.0), ((0.3, 1.0, 0.1), 0.58)]
+rs = {}
+for table in (1, 3, 2, 0):
+    r = DeferredRenderer()
+    r.init(W, H, atrous_levels=5)
+    r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    r.svgf.set_option("gi_sun_table", table)
+    if table == 2:
+        r.svgf.set_option("gi_sort_rays", 1)
+    r.submit_commands_gbuffer()
+    rs[table] = r
+for direction, diameter in suns:
+    res = {}
+    for table, r in rs.items():
+        r.sun.direction, r.sun.rough_diameter = direction, diameter
+        t = []
+        for f in range(2, 9):  # (the first frame with a new sun is traced the plain way; the table is built for the second)
+            r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=f))
+            r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+            r.ray_count(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.submit_commands_gi_pathtrace()
+            torch.cuda.synchronize()
+            t.append((time.perf_counter() - t0) * 1e6)
+        res[table] = (r.svgf.download(PLANE_RADIANCE), r.ray_count(), r.sun_table_stats(), r.sun_table_build_ms(), float(np.median(t[3:])))
+    (a, rays, st, ms, us_auto), (b, rays_b, _, _, us_off), (c2, _, _, _, us_sorted), (c3, _, _, _, us_lists) = res[1], res[0], res[2], res[3]
+    mode, (t_l, t_s) = rs[1].shadow_tail_mode()
+    print(f"sun {direction}, disk {diameter} deg: build {ms if ms is None else round(ms, 2)} ms, lit {st['lit_plus']} + {st['lit_minus']}, {st['rays_answered']} of {rays - W * H} queries "
+          f"answered ({st['rays_answered'] / (rays - W * H):.2f}); GI dispatch: default {us_auto:.0f} us (tail mode {mode}: timed {t_l:.0f} / {t_s:.0f}), lists {us_lists:.0f}, "
+          f"sorted tail {us_sorted:.0f}, no table {us_off:.0f}; same bits: {all(bool(np.array_equal(a, x)) for x in (b, c2, c3)) and rays == rays_b}", flush=True)
