@@ -697,6 +697,8 @@ def main(argv=None, rt=None, emit=None):
         bvh["sun_table"] = r.sun_table_stats()
         ms = r.sun_table_build_ms()
         bvh["sun_table"]["build_ms"] = None if ms is None else round(ms, 2)
+        mode, (us_lists, us_sorted) = r.shadow_tail_mode()  # which pass takes the rays the table leaves: measured by the library once per table build
+        bvh["sun_table"]["tail"] = {"mode": {0: "lists", 1: "sorted pass", -1: "undecided"}[mode], "timed_us": {"lists": round(us_lists, 1), "sorted_pass": round(us_sorted, 1)}}
     # the settled rate: the same K steps, timed the same way, once the context has run SETTLE_FRAMES frames in all
     settle_run = max(Workload.SETTLE_FRAMES - warmup_run - args.steps, 0)
     dt_settled, _ = w.timed(args.steps, settle_run)

@@ -103,6 +103,9 @@ class DryRuntime:
             def sun_table_build_ms(self):
                 return None
 
+            def shadow_tail_mode(self):
+                return 0, (0.0, 0.0)
+
             def _rows(self):
                 return self.svgf.row_begin, self.svgf.row_end
 
