@@ -1257,6 +1257,11 @@ int neb_gi_set_scene(neb_ctx* ctx, const neb_geometry_desc* geoms, uint32_t n_ge
                     w[k][1] = a[0] * m[1] + a[1] * m[5] + a[2] * m[9] + m[13];
                     w[k][2] = a[0] * m[2] + a[1] * m[6] + a[2] * m[10] + m[14];
                     for (int q = 0; q < 3; ++q) {
+                        // (a position that is not a finite number has no place in a tree: min / max drop NaNs silently, the SAH's areas would not)
+                        if (!(fabsf(w[k][q]) <= 3.0e38f)) {
+                            delete g;
+                            return gi_fail(ctx, NEB_ERR_OUT_OF_RANGE, "neb_gi_set_scene: a vertex position (after the instance transform) is not a finite number");
+                        }
                         smin[q] = fminf(smin[q], w[k][q]);
                         smax[q] = fmaxf(smax[q], w[k][q]);
                     }

@@ -79,6 +79,7 @@ class DeferredRenderer:
     # ---- DeferredRenderer::InitPathtracerScene + InitRTAccelerationStructures (:978-1030,1083-1086) ----
     def init_pathtracer_scene(self, scene, stream=0):
         G, ng, M, nm, T, nt = scene.descs()
+        self._scene = None  # (neb_gi_set_scene lets go of the old scene first: if the new one is refused the context has none)
         self._check(self._lib.neb_gi_set_scene(self._ctx, G, ng, M, nm, T, nt), "neb_gi_set_scene")
         self._check(self._lib.neb_gi_build_bvh(self._ctx, C.c_void_p(stream)), "neb_gi_build_bvh")
         self._scene = scene

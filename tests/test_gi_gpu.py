@@ -157,6 +157,19 @@ def test_edge_cases_empty_scene_single_triangle_and_missing_attributes():
     r.gi_ui.max_path_vertices = 9
     with pytest.raises(NebError):
         r.submit_commands_gi_pathtrace()
+    r.gi_ui.max_path_vertices = 2
+    # (d) a vertex position that is not a finite number is refused at upload (the context then has no scene); a good scene after it works
+    for bad in (float("nan"), float("inf")):
+        broken = S.Scene("broken")
+        mb = broken.add_material(albedo=(0.5, 0.5, 0.5, 1))
+        broken.add_geometry([[-5, 1.5, -5], [5, bad, -5], [0, 1.5, 5]], [[0, -1, 0]] * 3, [[0, 0], [1, 0], [0, 1]], [0, 1, 2], mb)
+        with pytest.raises(NebError):
+            r.begin_frame(RenderInfo(scene=broken, camera=cam, frame_index=3))
+    r.begin_frame(RenderInfo(scene=one, camera=cam, frame_index=3))
+    upload_gbuffer(r, gb)
+    r.svgf.upload(PLANE_RADIANCE, SLOT_CURRENT, np.zeros((H, W, 4), np.float32))
+    r.submit_commands_gi_pathtrace()
+    assert np.isfinite(r.svgf.download(PLANE_RADIANCE)).all()
     r.destroy()
 
 
