@@ -1038,6 +1038,7 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
     a.hint_pairs = (uint32_t)g->sun_hints / 2u;
     // the pass that takes the rays the table leaves: the compacted lists, unless the measurement of this table said the sorted pass (GiState::tail_tune)
     int tail_slot = -1; // 0 / 2: this dispatch is one of the two timed ones (events tail_ev[slot], [slot + 1] around its shade + shadow launches)
+    bool tail_warm = false;
     if (a.sun_table && g->compact_shadow && g->tail_tune && phase != 1) {
         if (g->tail_phase == 3 && hipEventQuery(g->tail_ev[1]) == hipSuccess && hipEventQuery(g->tail_ev[3]) == hipSuccess) {
             float ms_lists = 0.f, ms_sorted = 0.f;
@@ -1046,6 +1047,10 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
                 g->tail_sorted = ms_sorted < 0.95f * ms_lists; // (the lists stay unless the sorted pass is clearly faster)
             }
             g->tail_phase = 0;
+        } else if (g->tail_phase == 1 && !ds.d_list) {
+            // (the lists are allocated by this very dispatch: its first run pays for touching them -- it runs untimed, the next one counts)
+        } else if (g->tail_phase == 2 && !ds.d_sort && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow)) {
+            tail_warm = true; // the same for the sorted pass's buffers
         } else if (g->tail_phase == 1 || g->tail_phase == 2) {
             tail_slot = g->tail_phase == 1 ? 0 : 2;
             for (int k = 0; k < 2; ++k)
@@ -1055,7 +1060,7 @@ static int gi_dispatch(neb_ctx* ctx, const neb_gi_constants* c, uint32_t row0, u
         }
         (void)hipGetLastError(); // (hipErrorNotReady from a query is an answer, not a failure)
     }
-    const bool compact = a.sun_table && g->compact_shadow && (tail_slot >= 0 ? tail_slot == 0 : !g->tail_sorted);
+    const bool compact = a.sun_table && g->compact_shadow && !tail_warm && (tail_slot >= 0 ? tail_slot == 0 : !g->tail_sorted);
     const bool sort_shadow = !compact && (g->sort_shadow_auto ? a.n_px >= 1500000u : g->sort_shadow);
     if (sort_shadow || g->sort_bounce) {
         if (!ds.d_sort) {
