@@ -337,12 +337,19 @@ def _tiny_scene(kind):
         sc.add_geometry(P[:3].copy(), N[:3].copy(), UV[:3].copy(), np.array([0, 1, 2], np.uint32), material=m)
     elif kind == "quad":
         sc.add_geometry(*floor, material=m)
-    else:  # a floor with a small roof over a part of it: lit and shadowed receivers, occluder hints
+    elif kind == "roofed":  # a floor with a small roof over a part of it: lit and shadowed receivers, occluder hints
         sc.add_geometry(*S._merge([floor, S._quad((-0.5, 0.2, -0.5), (-0.5, 0.2, -1.5), (0.5, 0.2, -1.5), (0.5, 0.2, -0.5))]), material=m)
+    else:  # the roofed floor + triangles without area: a point, a doubled vertex, three collinear vertices, and one a millionth of a unit wide
+        P = np.array([[0.3, 0.0, -1.0]] * 3 + [[0.0, 0.1, -1.0], [0.0, 0.1, -1.0], [0.4, 0.1, -1.2]] + [[-1.0, 0.3, -2.0], [0.0, 0.3, -2.0], [1.0, 0.3, -2.0]]
+                     + [[-0.2, 0.15, -0.8], [0.2, 0.15, -0.8], [0.0, 0.15, -0.800001]], np.float32)
+        N = np.tile(np.array([[0.0, 1.0, 0.0]], np.float32), (12, 1))
+        UV = np.zeros((12, 2), np.float32)
+        slivers = (P, N, UV, np.arange(12, dtype=np.uint32))
+        sc.add_geometry(*S._merge([floor, S._quad((-0.5, 0.2, -0.5), (-0.5, 0.2, -1.5), (0.5, 0.2, -1.5), (0.5, 0.2, -0.5)), slivers]), material=m)
     return sc
 
 
-@pytest.mark.parametrize("kind", ["one_triangle", "quad", "roofed"])
+@pytest.mark.parametrize("kind", ["one_triangle", "quad", "roofed", "roofed_with_degenerate_triangles"])
 def test_trees_of_one_or_two_leaves(kind):
     sc, cam, W, H = _tiny_scene(kind), S.orbit_camera(yaw_deg=15.0, pitch_deg=70.0, distance=3.0), 160, 120
     on, off = _pair(W, H)
@@ -355,6 +362,7 @@ def test_trees_of_one_or_two_leaves(kind):
         _same(a, b)
     st = on.sun_table_stats()
     assert st["builds"] == 1 and st["lit_plus"] + st["lit_minus"] >= 1, st  # (the open floor is proven lit on its upper side)
+    assert np.isfinite(a[0]).all()
     print(f"[tiny {kind}] {sc.num_triangles} triangles, {on.scene_info()[1]} nodes: {st}")
     on.destroy()
     off.destroy()
