@@ -263,10 +263,16 @@ __device__ bool sun_walk_column(const SunTableArgs& a, const lit::Receiver& R, b
         queue_leaf(node);
         node = kTravDone;
     }
+    // A receiver the size of a wall strip has a column the size of the scene: its hint walk would be the launch (the long-thin stand-in: 2021 node visits
+    // for one triangle, 15.7 of the build's 18 ms in ONE wave, against 47 on average) -- and four hints cannot cover such a receiver anyway.  The hint walk
+    // of a receiver ends after kSunHintVisits nodes with the best candidates it has met (hints are only hints).  The bench scene's longest is 219.
+    constexpr uint32_t kSunHintVisits = 320u;
+    uint32_t walked = 0;
     for (;;) {
-        const bool walking = node != kTravDone && alive && !(HINT && cands.top4_cover_all());
+        const bool walking = node != kTravDone && alive && !(HINT && (cands.top4_cover_all() || walked >= kSunHintVisits));
         if (walking) {
             ++visits;
+            ++walked;
             const Bvh4Node nd = a.S.nodes[node];
             const int ch[4] = {nd.child.x, nd.child.y, nd.child.z, nd.child.w};
             node = kTravDone;

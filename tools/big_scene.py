@@ -1,5 +1,5 @@
 """Scenes eight and ten times the bench's (2.0 and 2.6 M triangles; hints index triangles with 23 bits, 8.4 M -- round 4's 21 bits lost nearly every occluder at 2.6 M): BVH build, sun-table build,
-a few 1080p frames with the table on and off -- same bits -- and their times.   python tools/big_scene.py [triangles]"""
+a few 1080p frames with the table on and off -- same bits -- and their times.   python tools/big_scene.py [triangles [long_thin]]"""
 import os
 import sys
 import time
@@ -15,7 +15,8 @@ from nebulae_amd.svgf import PLANE_RADIANCE  # noqa: E402
 
 W, H = 1920, 1080
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-sc, cam = S.atrium_standin(target_triangles=n, tex_size=256), S.sponza_camera()
+long_thin = len(sys.argv) > 2 and sys.argv[2] == "long_thin"  # (the real Sponza's pathology: full-length strips and beams, aspect ratios up to 190 : 1)
+sc, cam = S.atrium_standin(target_triangles=n, tex_size=256, long_thin=long_thin), S.sponza_camera()
 out = {}
 for table in (1, 0):
     r = DeferredRenderer()

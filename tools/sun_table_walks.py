@@ -1,4 +1,4 @@
-"""How long are the sun-table build's walks?  NEB_SUN_WALK_STATS=1 python tools/sun_table_walks.py"""
+"""How long are the sun-table build's walks?  NEB_SUN_WALK_STATS=1 python tools/sun_table_walks.py [long_thin]"""
 import ctypes as C
 import os
 import sys
@@ -12,7 +12,7 @@ from nebulae_amd.renderer import DeferredRenderer, RenderInfo
 from nebulae_amd.svgf import PLANE_RADIANCE, SLOT_CURRENT
 
 W, H = 640, 360
-sc, cam = S.atrium_standin(), S.sponza_camera()
+sc, cam = S.atrium_standin(long_thin=len(sys.argv) > 1 and sys.argv[1] == "long_thin"), S.sponza_camera()
 r = DeferredRenderer()
 r.init(W, H, atrous_levels=5)
 r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=3))
