@@ -127,6 +127,10 @@ int neb_svgf_get_params(const neb_ctx* ctx, neb_svgf_params* out);
  *                       through the sorted pass, whichever two timed dispatches after each table build say is faster
  *                       (neb_gi_shadow_tail_mode); 3 = always the lists, 2 = always the sorted / tiled pass; results are bit-identical
  *                       in all of them.  No table is built for a sun disk wider than 3.4 degrees (sunTanHalfAngle > 0.03);
+ *   "gi_sun_hold":      how many consecutive dispatches a NEW sun must be seen on before a table is built for it (a build costs five frames' time):
+ *                       0 (default) = two -- or 32 when the table it replaces served fewer than 32 dispatches (a sun that moves in steps of a few
+ *                       frames: a build per step would cost more than no table at all); N >= 2 pins the count.  A sun that changes every
+ *                       dispatch is never built for; meanwhile every shadow ray is traced.  Results never depend on it;
  *   "gi_sun_hints":     4 (default), 2 or 0: how many of a triangle's occluder hints the shade pass tries (with the traverser's own
  *                       triangle test) before it leaves the shadow ray to the list pass; results are bit-identical in all three;
  *   "gi_max_bvh_depth": 1..21, the deepest BVH4 neb_gi_build_bvh accepts (default 21 = traversal stack / 3);

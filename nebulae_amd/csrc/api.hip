@@ -315,6 +315,11 @@ int neb_set_option(neb_ctx* ctx, const char* key, int value)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_table needs a scene (neb_gi_set_scene) and 0 .. 3");
         return NEB_OK;
     }
+    if (!strcmp(key, "gi_sun_hold")) {
+        if (gi_set_sun_hold(ctx, value) != NEB_OK)
+            return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_hold needs a scene (neb_gi_set_scene) and 0 or 2 .. 100000");
+        return NEB_OK;
+    }
     if (!strcmp(key, "gi_sun_hints")) {
         if (gi_set_sun_hints(ctx, value) != NEB_OK)
             return fail(ctx, NEB_ERR_STATE, "neb_set_option: gi_sun_hints needs a scene (neb_gi_set_scene) and 0, 2 or 4");

@@ -1563,6 +1563,14 @@ int gi_set_sun_table(neb_ctx* ctx, int on)
     g->tail_phase = (g->tail_tune && g->sun_table_state == 1) ? 1 : 0;
     return NEB_OK;
 }
+int gi_set_sun_hold(neb_ctx* ctx, int n)
+{
+    if (!ctx->gi || n < 0 || n == 1 || n > 100000)
+        return NEB_ERR_STATE;
+    ctx->gi->sun_hold_option = n;
+    ctx->gi->sun_hold = n > 0 ? (uint32_t)n : 2u;
+    return NEB_OK;
+}
 int gi_set_sun_hints(neb_ctx* ctx, int n)
 {
     if (!ctx->gi || (n != 0 && n != 2 && n != 4))

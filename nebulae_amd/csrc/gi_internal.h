@@ -195,7 +195,12 @@ struct GiState {
     // the sun-visibility table in the shading records (gi_sun_table.hip)
     bool sun_table = true;            // option "gi_sun_table"
     int sun_table_state = 0;          // 0: the records carry no flags; 1: flags of sun_table_key = this frame's sun; 2: flags of another sun (ignored)
-    float sun_table_pending[4] = {0, 0, 0, 0}; // a new sun seen once: the table follows when it is seen again
+    float sun_table_pending[4] = {0, 0, 0, 0}; // a new sun seen once: the table follows when it has been seen sun_hold times in a row
+    // A build costs five frames' time and earns a tenth of a frame per dispatch: a table pays for itself after ~30 dispatches.  A new sun is built for when it
+    // has held for TWO dispatches -- unless the table it replaces lived fewer than kSunTableLife dispatches (a sun that moves in steps: a build per step made
+    // the frames twice as slow as no table at all), then for kSunHoldAfterShortLife.  "gi_sun_hold" = N pins the count (0 = this rule).
+    uint32_t sun_hold = 2, sun_seen = 0, sun_table_age = 0;
+    int sun_hold_option = 0;
     float sun_table_key[4] = {0, 0, 0, 0}; // {sunLightDirection, sunTanHalfAngle} the flags were built for
     unsigned long long* d_sun_counts = nullptr; // sides proven lit {+, -} by the last build
     uint32_t* d_sun_hint_list = nullptr;        // two-pass build: triangles whose primary side the first pass left unproven

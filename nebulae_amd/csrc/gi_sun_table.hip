@@ -541,16 +541,26 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
     }
     if (g->sun_table_state != 0 && !memcmp(key, g->sun_table_key, sizeof(key))) {
         g->sun_table_state = 1; // (back to the sun the flags were built for)
+        g->sun_table_age++;
         return hipSuccess;
     }
     // A new sun.  The build takes milliseconds -- twenty frames' worth -- so a sun that is being dragged (a new direction every
     // frame; the reference marks those frames dynamic, src/DeferredRenderer.cpp:169-171) is not chased: the flags in the records
     // stay those of the old sun and are IGNORED (state 2: every shadow ray is traced, as without the table) until the same new sun
-    // has been seen on two consecutive dispatches.  The very first build has nothing to wait for.
-    if (g->sun_table_state != 0 && memcmp(key, g->sun_table_pending, sizeof(key))) {
-        memcpy(g->sun_table_pending, key, sizeof(key));
+    // has been seen on sun_hold consecutive dispatches: two -- or kSunHoldAfterShortLife when the table it replaces lived fewer than kSunTableLife dispatches
+    // (a sun that moves in steps of a few frames: a build per step costs more than no table at all; see GiState::sun_hold).  The very first build has nothing
+    // to wait for.
+    constexpr uint32_t kSunTableLife = 32u, kSunHoldAfterShortLife = 32u;
+    if (g->sun_table_state != 0) {
+        if (memcmp(key, g->sun_table_pending, sizeof(key)) || g->sun_table_state == 1) { // (state 1: the table's own sun was the last one seen)
+            memcpy(g->sun_table_pending, key, sizeof(key));
+            g->sun_seen = 0;
+            if (g->sun_table_state == 1) // the table has just lost its sun: how long did it serve?
+                g->sun_hold = g->sun_hold_option > 0 ? (uint32_t)g->sun_hold_option : (g->sun_table_age < kSunTableLife ? kSunHoldAfterShortLife : 2u);
+        }
         g->sun_table_state = 2;
-        return hipSuccess;
+        if (++g->sun_seen < g->sun_hold)
+            return hipSuccess;
     }
     const float dd = key[0] * key[0] + key[1] * key[1] + key[2] * key[2];
     // The certificate's slack grows with the scene's coordinates (lit_predicate.h: an ulp there is what fp32 hit points and triangle tests
@@ -625,6 +635,8 @@ hipError_t gi_sun_table_update(GiState* g, const neb_gi_constants& c, hipStream_
         return em;
     memcpy(g->sun_table_key, key, sizeof(key));
     g->sun_table_state = 1;
+    g->sun_table_age = 0;
+    g->sun_seen = 0;
     g->sun_table_builds++;
     g->tail_phase = g->tail_tune ? 1 : 0; // (a new table: which pass takes what it leaves is measured again)
     g->tail_sorted = false;

@@ -106,6 +106,7 @@ int gi_set_max_bvh_depth(neb_ctx* ctx, int depth);
 int gi_set_exact_shade(neb_ctx* ctx, int on);
 int gi_set_sun_table(neb_ctx* ctx, int on);
 int gi_set_sun_hints(neb_ctx* ctx, int n);
+int gi_set_sun_hold(neb_ctx* ctx, int n);
 
 } // namespace neb
 

@@ -118,6 +118,8 @@ def test_the_table_follows_the_sun():
     on, off = _pair(W, H)
     off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
     off.svgf.set_option("gi_sun_table", 0)
+    on.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    on.svgf.set_option("gi_sun_hold", 2)  # (a table for every sun that is seen twice, however short the last one lived: the default would wait for 32 sightings here)
     suns = [((0.5, -1.0, -0.2), 0.58), ((-0.3, -1.0, 0.4), 0.58), ((-0.3, -1.0, 0.4), 3.0), ((0.0, -1.0, 0.0), 0.0), ((0.5, -1.0, -0.2), 0.58)]
     f, builds = 2, 0
     for idx, (direction, diameter) in enumerate(suns):
@@ -292,6 +294,7 @@ def test_a_new_sun_with_two_dispatches_in_flight_on_two_streams():
         direct = torch.full_like(rad[0], 0.125)
         if mode == "two_streams":
             r.set_defer_resolve(2)
+            r.svgf.set_option("gi_sun_hold", 2)  # (three suns in fourteen frames: a table for each that is seen twice)
         else:
             r.svgf.set_option("gi_sun_table", 0)
         resolved = [None, None]
@@ -423,5 +426,40 @@ def test_no_table_for_a_wide_sun_disk_and_the_tail_is_chosen_by_measurement():
         on.svgf.set_option("gi_sun_table", mode)
         for f in (12, 13):
             _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+    on.destroy()
+    off.destroy()
+
+
+def test_a_sun_that_moves_in_steps_is_not_built_for_at_every_step():
+    """A build costs five frames' time and earns a tenth of a frame per dispatch.  A new sun gets its table when it has been seen twice -- unless the table it
+    replaces served fewer than 32 dispatches: then when it has held for 32 (a sun stepping every four frames with a build per step made the frames twice as
+    slow as no table at all).  Same bits whatever the table does."""
+    make, cam, W, H = scenes()["atrium_small"]
+    sc = make()
+    on, off = _pair(W, H)
+    off.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
+    off.svgf.set_option("gi_sun_table", 0)
+    f = 2
+
+    def run(direction, frames, check_every=1):
+        nonlocal f
+        for r in (on, off):
+            r.sun.direction = direction
+        for k in range(frames):
+            if k % check_every == 0 or k == frames - 1:
+                _same(_frame(on, sc, cam, W, H, f), _frame(off, sc, cam, W, H, f))
+            else:
+                _frame(on, sc, cam, W, H, f)
+            f += 1
+        return on.sun_table_stats()["builds"]
+
+    assert run((0.5, -1.0, -0.2), 4) == 1            # the first sun: at once
+    assert run((0.4, -1.0, -0.2), 4) == 1            # its table served 3 dispatches when the sun moved on: from now a sun must hold for 32
+    assert run((0.3, -1.0, -0.2), 4) == 1
+    assert run((0.2, -1.0, -0.2), 4) == 1
+    assert run((0.1, -1.0, -0.2), 31, check_every=10) == 1
+    assert run((0.1, -1.0, -0.2), 2) == 2            # seen 32 times: built
+    assert run((0.1, -1.0, -0.2), 40, check_every=13) == 2   # a table that serves long ...
+    assert run((0.0, -1.0, -0.2), 2) == 3            # ... is followed by one built at the second sighting again
     on.destroy()
     off.destroy()

@@ -23,6 +23,7 @@ for table in (1, 3, 2, 0):
     r.init(W, H, atrous_levels=5)
     r.begin_frame(RenderInfo(scene=sc, camera=cam, frame_index=1))
     r.svgf.set_option("gi_sun_table", table)
+    r.svgf.set_option("gi_sun_hold", 2)  # (eight suns, seven frames each: a table for every one)
     if table == 2:
         r.svgf.set_option("gi_sort_rays", 1)
     r.submit_commands_gbuffer()
