@@ -144,6 +144,26 @@ namespace Neb
             return d;
         }
 
+        // The sun-visibility table (no reference counterpart: the reference's shadow rays go to TraceRay, assets/shaders/pathtracer.hlsl:567-569) is built
+        // and kept up to date by SubmitCommandsGIPathtrace itself; these report what it does.
+        struct SunTableStats
+        {
+            uint64_t sidesLitPlus = 0, sidesLitMinus = 0, raysAnswered = 0, builds = 0;
+            float lastBuildMs = 0.0f;      // 0 when no table has been built
+            int shadowTailMode = -1;       // 0: the rays the table leaves go through the compacted lists, 1: through the sorted pass, -1: not measured yet for this table
+        };
+        SunTableStats GetSunTableStats(neb_stream commandList) const
+        {
+            SunTableStats s;
+            uint64_t v[4] = {0, 0, 0, 0};
+            ThrowIfFailed(m_svgf.Context(), neb_gi_sun_table_stats(m_svgf.Context(), v, commandList), "neb_gi_sun_table_stats");
+            s.sidesLitPlus = v[0], s.sidesLitMinus = v[1], s.raysAnswered = v[2], s.builds = v[3];
+            if (s.builds)
+                ThrowIfFailed(m_svgf.Context(), neb_gi_sun_table_build_ms(m_svgf.Context(), &s.lastBuildMs), "neb_gi_sun_table_build_ms");
+            ThrowIfFailed(m_svgf.Context(), neb_gi_shadow_tail_mode(m_svgf.Context(), &s.shadowTailMode, nullptr), "neb_gi_shadow_tail_mode");
+            return s;
+        }
+
     private:
         SVGFDenoiser& m_svgf;
     };
